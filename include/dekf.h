@@ -1,0 +1,203 @@
+/*
+ * dekf.h — C ABI of the batched decentralized EKF + MHE estimator for MI355X.
+ *
+ * This is the drop-in boundary for ONE hot path of well-robotics/Decentralized_EKF_MHE:
+ * the orien_est quaternion EKF and the decentral_legged_est MHE/KF update.  The
+ * reference has no FFI; its boundary is the C++ class
+ *     DecentralizedEstimation::{initialize, update, reset}
+ *         (src/decentral_legged_est/include/decentral_legged_est/DecentralEst.hpp:96-103)
+ * and the EKF methods gyro_nonlinear_predict / gyro_nonlinear_correct /
+ * vo_nonlinear_correct driven by orien_ekf::timerCallback
+ *         (src/orien_est/include/orien_ekf.hpp:79-81, src/orien_est/src/orien_ekf.cpp:77-106).
+ * Every entry point below names the reference interface it replaces.  The batch
+ * dimension B (independent robot instances, one wavefront each on the GPU) is new.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no C++/torch types; all arrays are instance-major
+ *    ([B][...], row-major inside an instance), doubles like the reference's
+ *    Eigen::*d / ROS float64 fields.
+ *  - every pointer argument is either a HOST or a DEVICE (HBM) pointer, selected
+ *    by the `dekf_mem` argument of the call.
+ *  - all calls are asynchronous on the handle's HIP stream except dekf_create,
+ *    dekf_destroy, dekf_sync and host-side dekf_get.
+ *  - nothing throws; every call returns a dekf_status.
+ *  - there is NO CPU fallback: dekf_create fails with DEKF_ERR_NO_DEVICE when no
+ *    gfx950 device is usable.
+ */
+#ifndef DEKF_H
+#define DEKF_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DEKF_ABI_VERSION 1
+#define DEKF_MAX_LEGS 4
+#define DEKF_MAX_JOINTS 8 /* joints per leg */
+
+typedef enum dekf_status {
+    DEKF_OK = 0,
+    DEKF_ERR_INVALID = 1,    /* bad argument / unsupported configuration */
+    DEKF_ERR_NO_DEVICE = 2,  /* no usable HIP device (no CPU fallback exists) */
+    DEKF_ERR_HIP = 3,        /* a HIP runtime call failed; see dekf_last_error */
+    DEKF_ERR_ORDER = 4,      /* call sequence violated (e.g. update before initialize) */
+    DEKF_ERR_COMM = 5        /* RCCL communicator error */
+} dekf_status;
+
+typedef enum dekf_mem { DEKF_HOST = 0, DEKF_DEVICE = 1 } dekf_mem;
+
+/*
+ * Parameter block.  Field-for-field mirror of `robot_params`
+ * (DecentralEst.hpp:18-63; ROS names in EstSub.cpp:123-208, values in
+ * go1_example/config/parameters_go1.yaml:1-50) plus the orien_ekf parameters
+ * (orien_ekf.cpp:13-25, parameters_go1.yaml:68-75).  Three-element std vectors
+ * stay three elements; the per-joint encoder stds are widened to
+ * joints_per_leg entries so non-Go1 legs (BASELINE configs 3, 5) can be described.
+ */
+typedef struct dekf_params {
+    /* prior.* */
+    double p_init_std[3];
+    double v_init_std[3];
+    double foot_init_std[3];
+    double accel_bias_init_std[3];
+    /* process.* */
+    double p_process_std[3];
+    double accel_input_std[3];
+    double gyro_input_std[3];
+    double accel_bias_std[3]; /* process.accel_bias_process_std */
+    /* leg_odom.* */
+    double quaternion_ib[4]; /* w x y z */
+    double p_ib[3];
+    int num_legs;       /* leg_odom.num_leg */
+    int joints_per_leg; /* 3 on Go1 (hard-coded block<3,3> in the reference) */
+    int leg_odom_type;  /* 0 foot-velocity (supported); 1 foot-position (not yet) */
+    double joint_position_std[DEKF_MAX_JOINTS];
+    double joint_velocity_std[DEKF_MAX_JOINTS];
+    double foot_slide_std[3];
+    double foot_swing_std[3];
+    double contact_effort_threshold;
+    /* visual_odom.* */
+    double vo_p_std[3];
+    /* estimation.* */
+    int rate;     /* Hz of update(T) calls; dt = 1/rate */
+    int N;        /* horizon */
+    int est_type; /* 0 MHE, 1 KF */
+    /* osqp.* (DecentralEst.cpp:204-217) */
+    double rho, alpha, delta, sigma;
+    int verbose, adapt_rho, polish, max_qp_iter;
+    double rel_tol, abs_tol, prim_tol, dual_tol;
+    double time_limit; /* accepted, NOT honoured: runs are deterministic */
+    /* OSQP defaults the reference leaves implicit, made explicit here */
+    int scaling_iters;            /* 10 */
+    int check_termination;        /* 25 */
+    int adaptive_rho_interval;    /* OSQP: wall-clock derived; here fixed, default 25 */
+    double adaptive_rho_tolerance; /* 5 */
+    /* orien_sub.* */
+    double ekf_init_std[4];
+    double ekf_process_std[3];      /* gyro */
+    double ekf_gravity_meas_std[3]; /* accel */
+    double ekf_vo_meas_std[4];
+    double ekf_quaternion_init[4];  /* w x y z */
+    int ekf_rate;                   /* 500 */
+    int ekf_history;                /* depth of the rewind ring (reference: unbounded) */
+} dekf_params;
+
+typedef struct dekf_handle_s* dekf_handle;
+
+/* Fill `p` with go1_example/config/parameters_go1.yaml + OSQP defaults. */
+void dekf_default_params(dekf_params* p);
+
+int dekf_abi_version(void);
+const char* dekf_last_error(void);
+
+/* Replaces: constructing DecentralizedEstimation + orien_ekf for `batch` robots.
+ * device = HIP device ordinal; stream = hipStream_t to run on (NULL: own stream). */
+dekf_status dekf_create(const dekf_params* p, int batch, int device, void* stream,
+                        dekf_handle* out);
+dekf_status dekf_destroy(dekf_handle h);
+/* Replaces DecentralizedEstimation::reset (DecentralEst.cpp:1011-1015): clears the
+ * QP window, the arrival cost, the measurement stacks and the EKF state. */
+dekf_status dekf_reset(dekf_handle h);
+dekf_status dekf_sync(dekf_handle h);
+int dekf_batch(dekf_handle h);
+void* dekf_stream(dekf_handle h);
+
+/* ---- sensor latches: the writes the ROS callbacks make into robot_store ---------- */
+
+/* go1Sub::imu_callback / orien_ekf::imu_callback (go1Sub.cpp:30-51, orien_ekf.cpp:62-75):
+ * imu_time[B], accel_b[B][3], gyro_b[B][3]. */
+dekf_status dekf_push_imu(dekf_handle h, const double* imu_time, const double* accel_b,
+                          const double* gyro_b, dekf_mem where);
+
+/* go1Sub::lo_callback outputs (go1Sub.cpp:53-126): p_imu_2_foot[B][L][3],
+ * J_imu_2_foot[B][L][3][nj], joint_velocity[B][L][nj], contact[B][L] (0/1). */
+dekf_status dekf_push_leg(dekf_handle h, const double* p_imu_2_foot, const double* J_imu_2_foot,
+                          const double* joint_velocity, const double* contact, dekf_mem where);
+
+/* Same callback one step earlier: raw Go1 joint_position[B][12],
+ * joint_velocity[B][12], foot_force[B][4]; FK, Jacobian and the contact threshold
+ * run on the device. Go1 only (num_legs 4, joints_per_leg 3). */
+dekf_status dekf_push_go1_joints(dekf_handle h, const double* joint_position,
+                                 const double* joint_velocity, const double* foot_force,
+                                 dekf_mem where);
+
+/* robotSub::vo_callback (EstSub.cpp:45-56) + orien_ekf::vo_pose_callback
+ * (orien_ekf.cpp:48-60): mask[B] (int, 1 = a new VO sample for this instance),
+ * t_pre[B], t_now[B], dp_body[B][3] (orb/vo), q_vo[B][4] wxyz and its stamp
+ * t_pose[B] (orb/pos). Instances with mask 0 are untouched. */
+dekf_status dekf_push_vo(dekf_handle h, const int* mask, const double* t_pre, const double* t_now,
+                         const double* dp_body, const double* t_pose, const double* q_vo,
+                         dekf_mem where);
+
+/* robotSub::orien_filter_callback (EstSub.cpp:34-43): overrides the orientation the
+ * MHE reads with an external quaternion[B][4] wxyz instead of the on-device EKF's. */
+dekf_status dekf_push_quaternion(dekf_handle h, const double* quat, dekf_mem where);
+
+/* ---- the hot path ------------------------------------------------------------- */
+
+/* orien_ekf::timerCallback (orien_ekf.cpp:77-106): history push, VO rewind/replay
+ * when a VO pose is pending, predict, accel-correct; result feeds the MHE latch. */
+dekf_status dekf_ekf_step(dekf_handle h);
+
+/* DecentralizedEstimation::initialize (DecentralEst.cpp:9-150), T = 0. */
+dekf_status dekf_initialize(dekf_handle h);
+/* DecentralizedEstimation::update(T) (DecentralEst.cpp:152-198), T = 1, 2, ... */
+dekf_status dekf_update(dekf_handle h, int T);
+/* One estimator-step of the benchmark metric: dekf_ekf_step then
+ * (T == 0 ? dekf_initialize : dekf_update(T)). */
+dekf_status dekf_step(dekf_handle h, int T);
+
+/* ---- results: the public members read by EstSub.cpp:99-106 ---------------------- */
+/* x_mhe[B][9] (x_MHE_ / x_KF_), v_b[B][3] (v_MHE_b_ / v_KF_b_), quat[B][4] (EKF
+ * quaternion_, wxyz), p_vo[B][3] (p_vo_accmulate_), status[B] (int, see below).
+ * Any pointer may be NULL. */
+dekf_status dekf_get(dekf_handle h, double* x_mhe, double* v_b, double* quat, double* p_vo,
+                     int* status, dekf_mem where);
+/* EKF covariance Cov_q_[B][4][4]. */
+dekf_status dekf_get_ekf_cov(dekf_handle h, double* cov, dekf_mem where);
+/* Per-instance solver diagnostics of the last update: iters[B], rho_updates[B] (int),
+ * pri_res[B], dua_res[B] (unscaled OSQP residuals). Any pointer may be NULL. */
+dekf_status dekf_get_solver_info(dekf_handle h, int* iters, int* rho_updates, double* pri_res,
+                                 double* dua_res, dekf_mem where);
+/* KF covariance C_KF_[B][9][9] (est_type 1). */
+dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where);
+
+/* status[B] values written by dekf_update */
+#define DEKF_SOLVE_NONE 0       /* no solve yet (T = 0) */
+#define DEKF_SOLVE_OK 1         /* OSQP_SOLVED */
+#define DEKF_SOLVE_MAX_ITER 2   /* OSQP_MAX_ITER_REACHED; iterate still returned, as osqp-eigen does */
+#define DEKF_SOLVE_NUMERIC -1   /* non-finite value or zero pivot */
+
+/* ---- multi-GPU (new: the reference is single-robot) ------------------------------ */
+/* All-gather of the fused base velocity over RCCL: every rank contributes its
+ * v_b[B][3] and receives v_b_all[world][B][3] (device pointer). The communicator is
+ * created from an ncclUniqueId distributed by the caller (torch.distributed, MPI, ...). */
+#define DEKF_UNIQUE_ID_BYTES 128
+dekf_status dekf_comm_unique_id(void* id_out);
+dekf_status dekf_comm_init(dekf_handle h, int world, int rank, const void* id);
+dekf_status dekf_allgather_vb(dekf_handle h, double* v_b_all_dev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DEKF_H */

@@ -1,0 +1,218 @@
+"""Independent numpy cross-implementations used to pin the C++ oracle (tests only).
+
+None of this shares code with oracle/*.hpp: the QP here is written down directly in its
+block form, the KF is the textbook recursion, the EKF uses closed
+forms.  Agreement between the two independent restatements is what stands in for the
+reference tests that do not exist.
+"""
+import numpy as np
+
+INF = 1e30
+
+
+def skew(v):
+    return np.array([[0, -v[2], v[1]], [v[2], 0, -v[0]], [-v[1], v[0], 0]])
+
+
+def quat_to_rot(q):
+    w, x, y, z = q / np.linalg.norm(q)
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                     [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def kkt_exact(H, g, A, l, u):
+    """Exact optimum of min 1/2 x'Hx + g'x  s.t. rows with l == u hold with equality and
+    rows with infinite bounds are free (the only two row kinds this QP ever has)."""
+    eq = (u - l) < 1e-9
+    free = (l < -1e20) & (u > 1e20)
+    assert np.all(eq | free), "QP has a finite inequality row"
+    Ae, be = A[eq], l[eq]
+    n, me = H.shape[0], Ae.shape[0]
+    K = np.zeros((n + me, n + me))
+    K[:n, :n] = H
+    K[:n, n:] = Ae.T
+    K[n:, :n] = Ae
+    rhs = np.concatenate([-g, be])
+    # equilibrate before the solve: weights span 1e-14 .. 4e10
+    d = 1.0 / np.sqrt(np.maximum(np.abs(K).max(axis=1), 1e-300))
+    Ks = K * d[:, None] * d[None, :]
+    sol = np.linalg.solve(Ks, rhs * d) * d
+    # one step of refinement in the original scaling
+    r = rhs - K @ sol
+    sol = sol + np.linalg.solve(Ks, r * d) * d
+    return sol[:n], sol[n:]
+
+
+class Model:
+    """Constants of DecentralizedEstimation::initialize for leg_odom_type 0."""
+
+    def __init__(self, p):
+        self.p = p
+        self.L, self.nj, self.N = p.num_legs, p.joints_per_leg, p.N
+        self.dt = 1.0 / p.rate
+        sq = lambda a, n=3: np.diag(np.array(a[:n]) ** 2)
+        self.C_p, self.C_accel, self.C_bias = sq(p.p_process_std), sq(p.accel_input_std), sq(p.accel_bias_std)
+        self.C_gyro = sq(p.gyro_input_std)
+        self.C_enc_pos, self.C_enc_vel = sq(p.joint_position_std, self.nj), sq(p.joint_velocity_std, self.nj)
+        self.C_swing = sq(p.foot_swing_std)
+        self.Q_vo = np.diag(1.0 / np.array(p.vo_p_std[:3]) ** 2)
+        self.C_prior = np.diag(np.concatenate([np.array(p.p_init_std[:3]), np.array(p.v_init_std[:3]),
+                                               np.array(p.accel_bias_init_std[:3])]) ** 2)
+        self.A_meas = np.zeros((3 * self.L, 9))
+        for i in range(self.L):
+            self.A_meas[3 * i:3 * i + 3, 3:6] = np.eye(3)
+
+    def sample(self, s, k, b, quat):
+        """measurement-side quantities of step k: R, a_s, omega, b_meas, C_meas"""
+        R = quat_to_rot(np.asarray(quat, float))
+        a_s = R @ s["accel"][k, b] + np.array([0, 0, -9.81])
+        om = s["gyro"][k, b]
+        b_meas = np.zeros(3 * self.L)
+        C_meas = np.zeros((3 * self.L, 3 * self.L))
+        for i in range(self.L):
+            J, pf, qd = s["J"][k, b, i], s["p_foot"][k, b, i], s["qdot"][k, b, i]
+            b_meas[3 * i:3 * i + 3] = -R @ J @ qd - R @ np.cross(om, pf)
+            if s["contact"][k, b, i] == 0.0:
+                C_meas[3 * i:3 * i + 3, 3 * i:3 * i + 3] = self.C_swing
+            else:
+                G = np.hstack([-J, -skew(om) @ J, skew(pf)])
+                Cm = np.zeros((2 * self.nj + 3,) * 2)
+                Cm[:self.nj, :self.nj] = self.C_enc_vel
+                Cm[self.nj:2 * self.nj, self.nj:2 * self.nj] = self.C_enc_pos
+                Cm[2 * self.nj:, 2 * self.nj:] = self.C_gyro
+                C_meas[3 * i:3 * i + 3, 3 * i:3 * i + 3] = R @ G @ Cm @ G.T @ R.T
+        return R, a_s, om, b_meas, C_meas
+
+    def dynamics(self, R, a_s):
+        dt = self.dt
+        A = np.eye(9)
+        A[0:3, 3:6] = dt * np.eye(3)
+        A[0:3, 6:9] = -dt * dt / 2 * R
+        A[3:6, 6:9] = -dt * R
+        b = np.concatenate([-dt * dt / 2 * a_s, -dt * a_s, np.zeros(3)])
+        G = np.zeros((9, 9))
+        G[0:3, 0:3] = dt * R
+        G[0:3, 3:6] = 0.5 * dt * dt * R
+        G[3:6, 3:6] = dt * R
+        G[6:9, 6:9] = dt * np.eye(3)
+        Cin = np.zeros((9, 9))
+        Cin[0:3, 0:3], Cin[3:6, 3:6], Cin[6:9, 6:9] = self.C_p, self.C_accel, self.C_bias
+        return A, b, G @ Cin @ G.T
+
+
+def kalman_filter(p, s, b, quats, ref_double_init=False):
+    """Textbook KF on the same model; returns x[K,9], C[K,9,9].
+    ref_double_init=True reproduces est_type 1 of the reference exactly: initialize() runs
+    InitializeKF() AND UpdateKF() (DecentralEst.cpp:140-141), i.e. the first sample is
+    predicted-through and corrected a second time before update(1)."""
+    m = Model(p)
+    K = s["imu_t"].shape[0]
+    xs, Cs = np.zeros((K, 9)), np.zeros((K, 9, 9))
+    x, Cc = np.zeros(9), m.C_prior.copy()
+    prev = None
+    for k in range(K):
+        R, a_s, om, b_meas, C_meas = m.sample(s, k, b, quats[k])
+        if k > 0:
+            A, bd, Cd = m.dynamics(*prev)
+            x = A @ x - bd
+            Cc = A @ Cc @ A.T + Cd
+        S = m.A_meas @ Cc @ m.A_meas.T + C_meas
+        Kg = Cc @ m.A_meas.T @ np.linalg.inv(S)
+        x = x + Kg @ (b_meas - m.A_meas @ x)
+        Cc = (np.eye(9) - Kg @ m.A_meas) @ Cc
+        if k == 0 and ref_double_init:
+            A, bd, Cd = m.dynamics(R, a_s)
+            x = A @ x - bd
+            Cc = A @ Cc @ A.T + Cd
+            S = m.A_meas @ Cc @ m.A_meas.T + C_meas
+            Kg = Cc @ m.A_meas.T @ np.linalg.inv(S)
+            x = x + Kg @ (b_meas - m.A_meas @ x)
+            Cc = (np.eye(9) - Kg @ m.A_meas) @ Cc
+        xs[k], Cs[k] = x, Cc
+        prev = (R, a_s)
+    return xs, Cs
+
+
+def window_qp(p, s, b, quats, T):
+    """The un-marginalised QP after update(T), T < N, no VO rows active, in the layout of
+    SURVEY.md Appendix A: variables [x0 v0 | w0 c0 x1 v1 | ...], rows [M0 | D0 V0 M1 | ...]."""
+    m = Model(p)
+    L = m.L
+    nm, ns, nc = 3 * L, 9, 3
+    sv, sc = ns + nm + ns + nc, nm + ns + nc
+    n = (ns + nm) + T * sv
+    mm = nm + T * sc
+    H, g = np.zeros((n, n)), np.zeros(n)
+    A, l, u = np.zeros((mm, n)), np.zeros(mm), np.zeros(mm)
+    samples = [m.sample(s, k, b, quats[k]) for k in range(T + 1)]
+
+    def xo(k):
+        return 0 if k == 0 else (ns + nm) + (k - 1) * sv + ns + nc
+
+    def vo(k):
+        return xo(k) + ns
+
+    def wo(k):  # w_k, c_k live in the block created at update(k+1)
+        return (ns + nm) + k * sv
+
+    H[0:9, 0:9] = np.linalg.inv(m.C_prior)
+    for k in range(T + 1):
+        R, a_s, om, b_meas, C_meas = samples[k]
+        r0 = 0 if k == 0 else nm + (k - 1) * sc + ns + nc
+        A[r0:r0 + nm, xo(k):xo(k) + ns] = m.A_meas
+        A[r0:r0 + nm, vo(k):vo(k) + nm] = -np.eye(nm)
+        l[r0:r0 + nm] = u[r0:r0 + nm] = b_meas
+        H[vo(k):vo(k) + nm, vo(k):vo(k) + nm] = np.linalg.inv(C_meas)
+        if k < T:
+            Ad, bd, Cd = m.dynamics(R, a_s)
+            rd = nm + k * sc
+            A[rd:rd + ns, xo(k):xo(k) + ns] = Ad
+            A[rd:rd + ns, wo(k):wo(k) + ns] = -np.eye(ns)
+            A[rd:rd + ns, xo(k + 1):xo(k + 1) + ns] = -np.eye(ns)
+            l[rd:rd + ns] = u[rd:rd + ns] = bd
+            Qd = np.zeros((9, 9))
+            Qd[0:6, 0:6] = np.linalg.inv(Cd[0:6, 0:6])
+            Qd[6:9, 6:9] = np.diag(1.0 / np.array(p.accel_bias_std[:3]) ** 2) / m.dt ** 2
+            H[wo(k):wo(k) + ns, wo(k):wo(k) + ns] = Qd
+            rc = rd + ns
+            co = wo(k) + ns
+            A[rc:rc + 3, xo(k):xo(k) + 3] = np.eye(3)
+            A[rc:rc + 3, xo(k + 1):xo(k + 1) + 3] = -np.eye(3)
+            A[rc:rc + 3, co:co + 3] = -np.eye(3)
+            l[rc:rc + 3], u[rc:rc + 3] = -INF, INF
+            H[co:co + 3, co:co + 3] = R @ m.Q_vo @ R.T
+    return H, g, A, l, u
+
+
+# ---------------------------------------------------------------- EKF, closed forms
+def ekf_predict(q, P, gyro, dt, C_gyro):
+    wx, wy, wz = gyro
+    Om = np.array([[0, -wx, -wy, -wz], [wx, 0, wz, -wy], [wy, -wz, 0, wx], [wz, wy, -wx, 0]])
+    F = np.eye(4) + dt / 2 * Om
+    w, x, y, z = q
+    # the reference's W, including its mis-assigned last row (orien_ekf.cpp:270-294)
+    W = 0.5 * dt * np.array([[-x, -y, -z], [w, -z, y], [z, x, w], [-y, 0, 0]])
+    qp = F @ q
+    Pp = F @ P @ F.T + W @ C_gyro @ W.T
+    return qp / np.linalg.norm(qp), Pp
+
+
+def ekf_correct(q, P, accel, C_accel, g=9.81):
+    R = quat_to_rot(q)
+    a_hat = R.T @ np.array([0, 0, g])
+    w, x, y, z = q
+    H = 2 * g * np.array([[-y, z, -w, x], [x, w, z, y], [w, -x, -y, z]])
+    rel = np.linalg.norm(accel) / g
+    S = H @ P @ H.T + rel ** 2 * C_accel
+    K = P @ H.T @ np.linalg.inv(S)
+    qc = q + K @ (accel - a_hat)
+    Pc = (np.eye(4) - K @ H) @ P
+    return qc / np.linalg.norm(qc), Pc
+
+
+def ekf_vo_correct(q, P, q_vo, C_vo):
+    K = P @ np.linalg.inv(P + C_vo)
+    qc = q + K @ (q_vo - q)
+    Pc = (np.eye(4) - K) @ P
+    return qc / np.linalg.norm(qc), Pc

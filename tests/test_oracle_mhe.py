@@ -1,0 +1,173 @@
+"""Pins for the estimator-core oracle (the reference ships no tests: SURVEY.md §4, §8c).
+
+KA1  MHE optimum == Kalman filter state on the same log (no VO), through marginalisation.
+KA2  the oracle's OSQP restatement lands within 1e-4 rel of the exact KKT optimum.
+KA3  window dimensions 54/36 at T=1 and 648/468 in steady state (Go1, N=20).
+plus: oracle QP == an independently written block-form QP for T < N.
+"""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import ref_numpy as RN
+from decentralized_ekf_mhe_amd import go1_params, cassie_params
+from decentralized_ekf_mhe_amd.streams import make_streams
+
+
+def _params(N=20, est_type=0):
+    p = go1_params()
+    p.ekf_rate = p.rate
+    p.N = N
+    p.est_type = est_type
+    return p
+
+
+def _run(p, s, b, nsteps, on_step=None):
+    pipe = O.Pipe(p)
+    quats = []
+    for k in range(nsteps):
+        pipe.feed(s, k, b)
+        pipe.step(k)
+        quats.append(pipe.quat())
+        if on_step:
+            on_step(k, pipe)
+    return pipe, np.array(quats)
+
+
+def relerr(a, b, floor=1e-6):
+    return np.max(np.abs(a - b)) / max(np.max(np.abs(b)), floor)
+
+
+# Tolerance of every ADMM-vs-optimum comparison in this repo (BASELINE.json: "states within
+# 1e-4 rel-tol"): per 3-vector block of x, |a-b|_inf <= RTOL*|b|_inf + ATOL.  ATOL equals OSQP's own
+# eps_abs = 1e-6 (parameters_go1.yaml:49) and only matters for blocks that are ~0: the accel-bias
+# block starts at 0 under a 1e-4 prior std and is only weakly observable, so an eps = 1e-6 ADMM
+# iterate (the reference's own output) is not 1e-4-relative there either.
+RTOL, ATOL = 1e-4, 1e-6
+
+
+def close(a, b):
+    return np.max(np.abs(a - b)) <= RTOL * np.max(np.abs(b)) + ATOL
+
+
+def test_dimensions_ka3():
+    p = _params()
+    s = make_streams(p, 1, 30, vo=False)
+    dims = {}
+
+    def grab(k, pipe):
+        H, g, A, l, u = pipe.est.qp()
+        dims[k] = (H.shape[0], A.shape[0])
+
+    _run(p, s, 0, 30, grab)
+    assert dims[0] == (21, 12)
+    assert dims[1] == (54, 36)
+    assert dims[19] == (21 + 19 * 33, 12 + 19 * 24)
+    for k in range(20, 30):
+        assert dims[k] == (648, 468)
+
+
+def test_qp_matches_block_form():
+    p = _params()
+    s = make_streams(p, 2, 8, vo=False)
+    for b in range(2):
+        qps = {}
+        pipe, quats = _run(p, s, b, 8, lambda k, pp: qps.__setitem__(k, pp.est.qp()))
+        for T in (1, 4, 7):
+            H, g, A, l, u = qps[T]
+            H2, g2, A2, l2, u2 = RN.window_qp(p, s, b, quats, T)
+            assert H.shape == H2.shape and A.shape == A2.shape
+            # compare per 3x3 block (entries far below their block's scale are round-off)
+            nb = H.shape[0] // 3
+            dH = np.abs(H - H2).reshape(nb, 3, nb, 3).max(axis=(1, 3))
+            sH = np.abs(H2).reshape(nb, 3, nb, 3).max(axis=(1, 3))
+            assert np.all(dH <= 1e-9 * sH), float(np.max(dH / np.maximum(sH, 1e-300)))
+            assert np.max(np.abs(A - A2)) < 1e-13
+            assert np.max(np.abs(g - g2)) == 0.0
+            fin = np.abs(l2) < 1e20
+            assert np.array_equal(fin, np.abs(l) < 1e20)
+            assert np.max(np.abs(l[fin] - l2[fin])) < 1e-12
+            assert np.max(np.abs(u[fin] - u2[fin])) < 1e-12
+            assert np.all(l[~fin] == -1e30) and np.all(u[~fin] == 1e30)
+
+
+@pytest.mark.parametrize("N", [5, 20])
+def test_mhe_equals_kf_ka1(N):
+    """exact optimum of the oracle's (marginalised) QP == oracle KF == numpy KF"""
+    nsteps = 3 * N + 5
+    p = _params(N=N)
+    s = make_streams(p, 1, nsteps, vo=False)
+    exact = {}
+
+    def grab(k, pipe):
+        if k >= 1:
+            H, g, A, l, u = pipe.est.qp()
+            x, _ = RN.kkt_exact(H, g, A, l, u)
+            exact[k] = (x[-21:-12].copy(), pipe.est.get()[0].copy(), pipe.est.solver_info())
+
+    pipe, quats = _run(p, s, 0, nsteps, grab)
+    pk = _params(N=N, est_type=1)
+    kf_states = {}
+    _run(pk, s, 0, nsteps, lambda k, pp: kf_states.__setitem__(k, pp.est.get()[0].copy()))
+    xs_np, _ = RN.kalman_filter(p, s, 0, quats)
+    xs_np_ref, _ = RN.kalman_filter(p, s, 0, quats, ref_double_init=True)
+    for k in sorted(exact):
+        x_exact, x_admm, info = exact[k]
+        for blk in (slice(0, 3), slice(3, 6), slice(6, 9)):
+            assert relerr(kf_states[k][blk], xs_np_ref[k][blk]) < 1e-8, k   # oracle KF == numpy KF
+        for blk in (slice(0, 3), slice(3, 6), slice(6, 9)):
+            assert relerr(x_exact[blk], xs_np[k][blk]) < 1e-7, (k, blk)   # KA1
+            assert close(x_admm[blk], x_exact[blk]), (k, blk)     # KA2
+        assert info["status"] == 1 and info["iters"] % 25 == 0
+
+
+def test_admm_vs_exact_with_vo_ka2():
+    """VO rows active (equality bounds written by the Bezier branch, 24-dim marginalisation).
+    An eps = 1e-6 OSQP iterate is NOT always 1e-4-relative to the optimum here: in the first
+    steps after VO rows switch on (rho jumps 0.1 -> ~20) the velocity block is off by up to
+    ~2e-4 relative (measured: 7e-5 abs at |v| = 0.39), because OSQP's dual tolerance scales
+    with |Px| ~ 1e8.  That is the reference algorithm's own accuracy, so the bound here is
+    5x the repo tolerance; HIP-vs-oracle parity (same algorithm) is held to RTOL/ATOL."""
+    p = _params()
+    nsteps = 70
+    s = make_streams(p, 2, nsteps, vo=True)
+    for b in range(2):
+        worst = 0.0
+        seen_vo = [0]
+
+        def grab(k, pipe):
+            nonlocal worst
+            if k < 1:
+                return
+            H, g, A, l, u = pipe.est.qp()
+            vo_rows = np.arange(21, A.shape[0], 24)
+            if len(vo_rows):
+                seen_vo[0] += int(np.sum(np.abs(l[vo_rows]) < 1e20))
+            x, _ = RN.kkt_exact(H, g, A, l, u)
+            xa = pipe.est.get()[0]
+            for blk in (slice(0, 3), slice(3, 6), slice(6, 9)):
+                ref = x[-21:-12][blk]
+                worst = max(worst, np.max(np.abs(xa[blk] - ref)) / (RTOL * np.max(np.abs(ref)) + ATOL))
+
+        _run(p, s, b, nsteps, grab)
+        assert seen_vo[0] > 50, "VO branch never became active"
+        assert worst <= 5.0, worst
+
+
+def test_cassie_shape_runs():
+    """2 legs x 5 joints (BASELINE config 3 shape): dims 27/18 per step and KA1"""
+    p = cassie_params()
+    p.ekf_rate = p.rate
+    p.N = 6
+    s = make_streams(p, 1, 20, vo=False)
+    out = {}
+
+    def grab(k, pipe):
+        H, g, A, l, u = pipe.est.qp()
+        out[k] = (H.shape[0], A.shape[0], RN.kkt_exact(H, g, A, l, u)[0][-15:-6] if k else None)
+
+    pipe, quats = _run(p, s, 0, 20, grab)
+    assert out[19][:2] == (5 * 27 + 15, 5 * 18 + 6)
+    xs_np, _ = RN.kalman_filter(p, s, 0, quats)
+    for k in range(1, 20):
+        assert relerr(out[k][2][3:6], xs_np[k][3:6]) < 1e-7
