@@ -1,0 +1,130 @@
+// cfg.h — constants of one estimator handle, passed by value to every kernel, and the
+// layout of the per-instance state in HBM.
+//
+// HBM layout (all fp64 unless noted), B = instances on this GPU:
+//   sensor latch   [B][...] instance-major, exactly what dekf_push_* receives
+//   EKF state      [field][B] field-major (one thread per instance -> coalesced)
+//   EKF history    [slot][27][B]   ring of (gyro3, accel3, t, q4, P16)
+//   MHE stack      [B][ring]        imu time, R (9) per pushed sample; ring = 4N+1
+//                                   (the reference trims its stacks to 4N+1, DecentralEst.cpp:963)
+//   MHE window     [B][N+1][REC]    one record per window step (see Rec below)
+//   arrival cost   [B][81 + 9]      M_p, n_p (MheSrb.cpp:594-598)
+//   solver scratch [B][GWS]         factor + scaled data of the ADMM solve (streamed from L2)
+// One wavefront owns one instance in the MHE kernels, so instance-major keeps every
+// access of a wave inside one contiguous slab.
+#pragma once
+#include "../../include/dekf.h"
+#include "wave.h"
+
+namespace dekf {
+
+constexpr double OSQP_INFTY = 1e30;
+constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e6, RHO_EQ_OVER_RHO_INEQ = 1e3, RHO_TOL = 1e-4;
+constexpr double MIN_SCALING = 1e-4, MAX_SCALING = 1e4;
+
+struct DevCfg {
+    int B, L, nj, N, nm;  // nm = 3L
+    int SV, SC;           // per-step variable / row block: 9+nm+12, nm+12
+    int ring;             // 4N+1 stack entries
+    int wcap;             // N+1 window records
+    int rec;              // doubles per window record
+    int est_type;
+    double dt;
+    // estimator constants (DecentralEst.cpp:39-51, 236-253)
+    double C_p[3], C_accel[3], C_accel_bias[3], C_gyro[3];
+    double C_enc_pos[DEKF_MAX_JOINTS], C_enc_vel[DEKF_MAX_JOINTS];
+    double C_swing[3], Q_swing[3], Q_vo[3], Q_bias_dt2[3];
+    double Q_prior[9], C_prior[9];
+    // OSQP settings (DecentralEst.cpp:204-217 + defaults)
+    double rho0, sigma, alpha, eps_abs, eps_rel;
+    int max_iter, scaling, check_termination, adaptive_rho, adaptive_rho_interval;
+    double adaptive_rho_tolerance;
+    // EKF (orien_ekf.cpp:13-31)
+    double ekf_dt, ekf_Cgyro[3], ekf_Caccel[3], ekf_Cvo[4], ekf_P0[4], ekf_q0[4];
+    int ekf_hist;
+};
+
+// window record of step k (doubles)
+struct Rec {
+    // R_sb (9) | a_s (3) | gyro (3) | Qd 6x6 sym packed (21) | Qc 3x3 sym packed (6) |
+    // vo flag (1) | vo bound (3) | bm (nm) | Qm L x sym packed (6L)
+    static constexpr int R = 0, AS = 9, GY = 12, QD = 15, QC = 36, VOF = 42, VOB = 43, BM = 46;
+    DEKF_FN static int qm(int nm) { return BM + nm; }
+    DEKF_FN static int len(int L) { return BM + 3 * L + 6 * L; }
+};
+
+// packed symmetric index, i <= j, n x n
+DEKF_FN int symidx(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
+DEKF_FN double symget(const double* s, int i, int j, int n) { return i <= j ? s[symidx(i, j, n)] : s[symidx(j, i, n)]; }
+
+// variable / row indices of the QP in the reference's own order
+// (x_k v_k w_k c_k per step; Meas_k Dyn_k VO_k per step — SURVEY.md Appendix A)
+struct Idx {
+    int nm, SV, SC;
+    DEKF_FN int x(int k, int j) const { return k * SV + j; }
+    DEKF_FN int v(int k, int r) const { return k * SV + 9 + r; }
+    DEKF_FN int w(int k, int r) const { return k * SV + 9 + nm + r; }
+    DEKF_FN int c(int k, int a) const { return k * SV + 18 + nm + a; }
+    DEKF_FN int rm(int k, int r) const { return k * SC + r; }
+    DEKF_FN int rd(int k, int r) const { return k * SC + nm + r; }
+    DEKF_FN int rv(int k, int a) const { return k * SC + nm + 9 + a; }
+};
+
+// global-memory scratch of one solve (doubles), K_max = N steps
+struct Gws {
+    // D (n) | E (m) | lo (m) | hi (m) | rho (m) | Sv (K*6L) | Sw (K*24) | Sc (K*6) |
+    // Wm (K*6L) | Wd (K*24) | Wc (K*6) | PA (K*81) | Sinv (K*81) | Wk (K*81)
+    int n_pad, m_pad, K;
+    int D, E, lo, hi, rho, Sv, Sw, Sc, Wm, Wd, Wc, PA, Sinv, Wk, total;
+    DEKF_FN void init(int N, int L) {
+        K = N;
+        int nm = 3 * L;
+        n_pad = N * (9 + nm + 12);
+        m_pad = N * (nm + 12);
+        int o = 0;
+        D = o; o += n_pad;
+        E = o; o += m_pad;
+        lo = o; o += m_pad;
+        hi = o; o += m_pad;
+        rho = o; o += m_pad;
+        Sv = o; o += K * 6 * L;
+        Sw = o; o += K * 24;
+        Sc = o; o += K * 6;
+        Wm = o; o += K * 6 * L;
+        Wd = o; o += K * 24;
+        Wc = o; o += K * 6;
+        PA = o; o += K * 81;
+        Sinv = o; o += K * 81;
+        Wk = o; o += K * 81;
+        total = o;
+    }
+};
+
+// pointers to the persistent per-instance state (device memory)
+struct DevState {
+    // sensor latch
+    double *imu_t, *accel, *gyro, *p_foot, *J, *qdot, *contact, *quat;
+    int* vo_flag;
+    double *vo_tpre, *vo_tnow, *vo_dp;
+    int* ekf_vo_flag;
+    double *ekf_vo_t, *ekf_vo_q;
+    // EKF
+    double *ekf_q, *ekf_P, *ekf_hist;
+    // MHE
+    double *st_time, *st_R;
+    int* st_dtime;
+    double *rec, *Mp, *np_;
+    double *wp, *wpt;
+    int* wp_count;
+    double* p_vo;
+    int *vo_ins_idx, *vo_ins_dtime;
+    double* gws;
+    // KF
+    double *kf_x, *kf_C;
+    // outputs
+    double *x_mhe, *v_b;
+    int *status, *iters, *rho_updates;
+    double *pri_res, *dua_res;
+};
+
+}  // namespace dekf

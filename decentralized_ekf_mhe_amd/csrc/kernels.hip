@@ -1,0 +1,90 @@
+// kernels.hip — gfx950 kernel entry points of the estimator hot path.
+//   k_ekf_tick        one lane per instance              (ekf_core.h)
+//   k_mhe_initialize  one wavefront per instance         (mhe_assemble_core.h)
+//   k_mhe_assemble    one wavefront per instance         (mhe_assemble_core.h)
+//   k_mhe_solve       persistent one-wave workgroups, grid-stride over instances; each
+//                     workgroup owns one scratch slab in HBM, so a slab is only ever touched
+//                     from one XCD (its L2 is the only one that caches it)  (mhe_solve_core.h)
+//   k_kf_*            KF alternative                      (kf_core.h)
+//   k_latch_vo        masked VO latch (robotSub::vo_callback for a batch)
+#include <hip/hip_runtime.h>
+
+#include "cfg.h"
+#include "ekf_core.h"
+#include "kf_core.h"
+#include "mhe_assemble_core.h"
+#include "mhe_solve_core.h"
+
+using namespace dekf;
+
+extern "C" {
+
+__global__ void __launch_bounds__(64) k_ekf_tick(DevCfg c, DevState s, int count) {
+    int b = blockIdx.x * 64 + threadIdx.x;
+    if (b < c.B) ekf_tick(c, s, b, count);
+}
+
+__global__ void __launch_bounds__(64) k_mhe_initialize(DevCfg c, DevState s) {
+    extern __shared__ double lds[];
+    assemble_initialize(c, s, blockIdx.x, lds);
+    if (threadIdx.x == 0) { s.status[blockIdx.x] = DEKF_SOLVE_NONE; s.iters[blockIdx.x] = 0; }
+}
+
+__global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T, int pushes) {
+    extern __shared__ double lds[];
+    assemble_update(c, s, blockIdx.x, T, pushes, lds);
+}
+
+__global__ void __launch_bounds__(64) k_mhe_solve(DevCfg c, DevState s, int kstart, int K, int gws_len) {
+    extern __shared__ double lds[];
+    double* gws = s.gws + (size_t)blockIdx.x * gws_len;
+    for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window(c, s, b, kstart, K, lds, gws);
+}
+
+__global__ void __launch_bounds__(64) k_kf_initialize(DevCfg c, DevState s) {
+    extern __shared__ double lds[];
+    kf_initialize(c, s, blockIdx.x, lds);
+}
+
+__global__ void __launch_bounds__(64) k_kf_update(DevCfg c, DevState s, int pushes) {
+    extern __shared__ double lds[];
+    kf_update(c, s, blockIdx.x, pushes, lds);
+}
+
+__global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* t_pre, const double* t_now,
+                           const double* dp, const double* t_pose, const double* q_vo) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= c.B || !mask[b]) return;
+    s.vo_flag[b] = 1;
+    s.vo_tpre[b] = t_pre[b];
+    s.vo_tnow[b] = t_now[b];
+    for (int i = 0; i < 3; ++i) s.vo_dp[3 * (size_t)b + i] = dp[3 * (size_t)b + i];
+    if (q_vo) {
+        s.ekf_vo_flag[b] = 1;
+        s.ekf_vo_t[b] = t_pose[b];
+        for (int i = 0; i < 4; ++i) s.ekf_vo_q[4 * (size_t)b + i] = q_vo[4 * (size_t)b + i];
+    }
+}
+
+__global__ void k_reset_state(DevCfg c, DevState s) {
+    int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= c.B) return;
+    size_t B = (size_t)c.B;
+    for (int i = 0; i < 4; ++i) { s.ekf_q[i * B + b] = c.ekf_q0[i]; s.quat[4 * (size_t)b + i] = c.ekf_q0[i]; }
+    for (int i = 0; i < 16; ++i) s.ekf_P[i * B + b] = (i % 5 == 0) ? c.ekf_P0[i / 5] : 0.0;
+    s.vo_flag[b] = 0;
+    s.ekf_vo_flag[b] = 0;
+    s.wp_count[b] = 0;
+    for (int i = 0; i < 3; ++i) s.p_vo[3 * (size_t)b + i] = 0.0;
+    for (int i = 0; i < 9; ++i) s.x_mhe[9 * (size_t)b + i] = 0.0;
+    for (int i = 0; i < 3; ++i) s.v_b[3 * (size_t)b + i] = 0.0;
+    s.status[b] = DEKF_SOLVE_NONE;
+    s.iters[b] = 0;
+    s.rho_updates[b] = 0;
+    s.pri_res[b] = 0.0;
+    s.dua_res[b] = 0.0;
+    s.vo_ins_idx[b] = 0;
+    s.vo_ins_dtime[b] = 0;
+}
+
+}  // extern "C"

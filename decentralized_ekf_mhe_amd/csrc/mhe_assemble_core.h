@@ -1,0 +1,385 @@
+// mhe_assemble_core.h — per-instance (one wavefront) construction of everything
+// DecentralizedEstimation::update(T) does BEFORE the QP solve:
+//   UpdateMHE(T)            dynamics / camera terms of step T-1, measurement terms of step T
+//                           (src/decentral_legged_est/src/DecentralEst.cpp:353-585)
+//   GetMeasurement(T)       sample intake, VO synchronisation, Bezier interpolation  (:864-985,
+//                           src/Spline/Bezier_simple.cpp:12-82)
+//   UpdateVOConstraints(T)  equality bounds on the VO rows                            (:987-1009)
+//   marginalizeQP(T-N)      Schur arrival cost                      (src/MheSrb.cpp:475-713)
+// Instead of the reference's string-keyed registries and growing sparse H/A, every window
+// step owns one fixed record (cfg.h: Rec) in HBM; H, g, A, l, u are never materialised.
+#pragma once
+#include "cfg.h"
+#include "smallmat.h"
+
+namespace dekf {
+
+struct AsmScratch {
+    // LDS doubles needed by assemble_instance for (L): see assemble_scratch_len()
+    DEKF_FN static int len(int L) {
+        int dim = 12 + 3 * L;
+        return 81 /*Minv*/ + 12 * 9 /*Am*/ + 12 * 9 /*AmMinv*/ + dim * dim /*S*/ + dim * dim + dim /*winverse*/ +
+               dim /*u*/ + dim /*Yu*/ + 81 /*tmp9*/ + 16;
+    }
+};
+
+// A_dyn,k[r][j] for R (row-major) and dt (DecentralEst.cpp:395-398)
+DEKF_FN double adyn_entry(const double* R, double dt, int r, int j) {
+    if (r == j) return 1.0;
+    if (r < 3) {
+        if (j == r + 3) return dt;
+        if (j >= 6) return -0.5 * dt * dt * R[3 * r + (j - 6)];
+        return 0.0;
+    }
+    if (r < 6 && j >= 6) return -dt * R[3 * (r - 3) + (j - 6)];
+    return 0.0;
+}
+
+// gains that depend only on R_sb of a step: Q_dyn's 6x6 block and Q_cam (one lane)
+DEKF_FN void step_gains(const DevCfg& c, const double* R, double* qd21, double* qc6) {
+    double dt = c.dt;
+    double RCp[9], RCa[9];  // R C R'
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double sp = 0, sa = 0;
+            for (int t = 0; t < 3; ++t) { sp += R[3 * i + t] * c.C_p[t] * R[3 * j + t]; sa += R[3 * i + t] * c.C_accel[t] * R[3 * j + t]; }
+            RCp[3 * i + j] = sp; RCa[3 * i + j] = sa;
+        }
+    double G[36];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            G[6 * i + j] = dt * dt * RCp[3 * i + j] + 0.25 * dt * dt * dt * dt * RCa[3 * i + j];
+            G[6 * i + 3 + j] = 0.5 * dt * dt * dt * RCa[3 * i + j];
+            G[6 * (3 + i) + j] = 0.5 * dt * dt * dt * RCa[3 * j + i];
+            G[6 * (3 + i) + 3 + j] = dt * dt * RCa[3 * i + j];
+        }
+    inv_small<6>(G, 6);
+    int p = 0;
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) qd21[p++] = G[6 * i + j];
+    p = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int j = i; j < 3; ++j) {
+            double s = 0;
+            for (int t = 0; t < 3; ++t) s += R[3 * i + t] * c.Q_vo[t] * R[3 * j + t];
+            qc6[p++] = s;
+        }
+}
+
+// b_meas and the 3x3 gain (as_gain) or covariance of leg `leg` at the latched sample (one lane)
+// (DecentralEst.cpp:513-547 / :807-837)
+DEKF_FN void leg_terms(const DevCfg& c, const double* R, const double* gyro, const double* p_foot, const double* J,
+                       const double* qdot, double contact, bool as_gain, double* bm3, double* w6) {
+    int nj = c.nj;
+    double Jq[3] = {0, 0, 0};
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < nj; ++j) Jq[i] += J[i * nj + j] * qdot[j];
+    double wxp[3], t1[3], t2[3];
+    cross3(gyro, p_foot, wxp);
+    mv3(R, Jq, t1);
+    mv3(R, wxp, t2);
+    for (int i = 0; i < 3; ++i) bm3[i] = -t1[i] - t2[i];
+    if (contact == 0.0) {
+        const double* d = as_gain ? c.Q_swing : c.C_swing;
+        w6[0] = d[0]; w6[1] = 0; w6[2] = 0; w6[3] = d[1]; w6[4] = 0; w6[5] = d[2];
+        return;
+    }
+    // G C G' with G = [-J, -w^x J, p^x], C = diag(C_enc_vel, C_enc_pos, C_gyro)
+    double WJ[3 * DEKF_MAX_JOINTS];
+    for (int j = 0; j < nj; ++j) {
+        double col[3] = {J[0 * nj + j], J[1 * nj + j], J[2 * nj + j]}, o[3];
+        cross3(gyro, col, o);
+        WJ[0 * nj + j] = o[0]; WJ[1 * nj + j] = o[1]; WJ[2 * nj + j] = o[2];
+    }
+    double Px[9] = {0, -p_foot[2], p_foot[1], p_foot[2], 0, -p_foot[0], -p_foot[1], p_foot[0], 0};
+    double Cb[9];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+            double s = 0;
+            for (int j = 0; j < nj; ++j) s += J[i * nj + j] * c.C_enc_vel[j] * J[k * nj + j] + WJ[i * nj + j] * c.C_enc_pos[j] * WJ[k * nj + j];
+            for (int t = 0; t < 3; ++t) s += Px[3 * i + t] * c.C_gyro[t] * Px[3 * k + t];
+            Cb[3 * i + k] = s;
+        }
+    double RC[9], Cw[9];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+            double s = 0;
+            for (int t = 0; t < 3; ++t) s += R[3 * i + t] * Cb[3 * t + k];
+            RC[3 * i + k] = s;
+        }
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+            double s = 0;
+            for (int t = 0; t < 3; ++t) s += RC[3 * i + t] * R[3 * k + t];
+            Cw[3 * i + k] = s;
+        }
+    if (as_gain) inv_small<3>(Cw, 3);
+    w6[0] = Cw[0]; w6[1] = Cw[1]; w6[2] = Cw[2]; w6[3] = Cw[4]; w6[4] = Cw[5]; w6[5] = Cw[8];
+}
+
+// GetMeasurement(T): returns through LDS/HBM; `pushes` = samples already on the stack.
+// sm: LDS scratch (>= 16 doubles used here)
+DEKF_FN void get_measurement(const DevCfg& c, const DevState& s, int b, int T, int pushes, double* sm) {
+    const int ring = c.ring;
+    double* st_time = s.st_time + (size_t)b * ring;
+    double* st_R = s.st_R + (size_t)b * ring * 9;
+    double* rec_base = s.rec + (size_t)b * c.wcap * c.rec;
+    const double* quat = s.quat + 4 * (size_t)b;
+    double R[9];
+    quat_to_rot(quat, R);
+    const double* accel = s.accel + 3 * (size_t)b;
+    int size = pushes < ring ? pushes : ring;  // entries held before this push
+    int base = pushes - size;                  // logical index of the oldest one
+    int flag = s.vo_flag[b];
+    DEKF_SYNC();
+    if (flag && size > 0) {  // wave-uniform
+        double t_pre = s.vo_tpre[b], t_now = s.vo_tnow[b];
+        // upper_bound on a sorted stack == count of entries <= t
+        double cnt_pre = wred_sum(size, [&](int i) { return st_time[(base + i) % ring] <= t_pre ? 1.0 : 0.0; });
+        double cnt_now = wred_sum(size, [&](int i) { return st_time[(base + i) % ring] <= t_now ? 1.0 : 0.0; });
+        if (cnt_pre > 0.5) {
+            int idx_pre = base + (int)(cnt_pre + 0.5) - 1;
+            int idx_now = base + (int)(cnt_now + 0.5) - 1;
+            const double* Rp = st_R + (size_t)(idx_pre % ring) * 9;
+            const double* dp = s.vo_dp + 3 * (size_t)b;
+            double* pv = s.p_vo + 3 * (size_t)b;
+            double* wp = s.wp + 12 * (size_t)b;
+            double* wpt = s.wpt + 4 * (size_t)b;
+            int wcnt = s.wp_count[b];
+            double acc[3];
+            for (int i = 0; i < 3; ++i) acc[i] = pv[i] + Rp[3 * i] * dp[0] + Rp[3 * i + 1] * dp[1] + Rp[3 * i + 2] * dp[2];
+            int win_start = pushes - (c.N < T ? c.N : T);
+            int interp_start = win_start > idx_pre ? win_start : idx_pre;
+            double t_interp = st_time[interp_start % ring];
+            // Bezier::add_way_point: keep the last four
+            double P[4][3], tw[4];
+            int nw = wcnt < 4 ? wcnt + 1 : 4;
+            int shift = wcnt < 4 ? 0 : 1;
+            for (int i = 0; i < nw - 1; ++i) {
+                for (int a = 0; a < 3; ++a) P[i][a] = wp[3 * (i + shift) + a];
+                tw[i] = wpt[i + shift];
+            }
+            for (int a = 0; a < 3; ++a) P[nw - 1][a] = acc[a];
+            tw[nw - 1] = t_now;
+            DEKF_SYNC();
+            if (DEKF_LANE() == 0) {
+                for (int i = 0; i < nw; ++i) {
+                    for (int a = 0; a < 3; ++a) wp[3 * i + a] = P[i][a];
+                    wpt[i] = tw[i];
+                }
+                s.wp_count[b] = nw;
+                for (int a = 0; a < 3; ++a) pv[a] = acc[a];
+            }
+            if (idx_now > win_start && nw >= 4) {
+                double t_interval = tw[3] - tw[0];
+                double u0 = (t_interp - tw[0]) / t_interval;
+                double uinc = c.dt / t_interval;
+                int num = idx_now - interp_start + 1;
+                // node_i, i = 0..num-1; bound of step interp_start+i is -(node_{i+1} - node_i)
+                wfor(num - 1, [&](int i) {
+                    double nd[2][3];
+                    for (int q = 0; q < 2; ++q) {
+                        double u = u0 + uinc * (double)(i + q);
+                        for (int a = 0; a < 3; ++a) {
+                            double v = u * u * u * ((-1) * P[0][a] + 3 * P[1][a] - 3 * P[2][a] + P[3][a]);
+                            v += u * u * (3 * P[0][a] - 6 * P[1][a] + 3 * P[2][a]);
+                            v += u * ((-3) * P[0][a] + 3 * P[1][a]);
+                            v += P[0][a];
+                            nd[q][a] = v;
+                        }
+                    }
+                    double* r = rec_base + (size_t)((interp_start + i) % c.wcap) * c.rec;
+                    r[Rec::VOF] = 1.0;
+                    for (int a = 0; a < 3; ++a) r[Rec::VOB + a] = -(nd[1][a] - nd[0][a]);
+                });
+                if (DEKF_LANE() == 0) { s.vo_ins_idx[b] = interp_start - win_start; s.vo_ins_dtime[b] = interp_start; }
+            }
+        }
+        if (DEKF_LANE() == 0) s.vo_flag[b] = 0;
+    }
+    // push
+    if (DEKF_LANE() == 0) {
+        st_time[pushes % ring] = s.imu_t[b];
+        s.st_dtime[(size_t)b * ring + pushes % ring] = T;
+        for (int i = 0; i < 9; ++i) st_R[(size_t)(pushes % ring) * 9 + i] = R[i];
+    }
+    (void)sm;
+    DEKF_SYNC();
+}
+
+// measurement-side part of the record of step T from the latched sample (after get_measurement);
+// as_gain = false stores covariances instead of gains (KF mode)
+DEKF_FN void write_measurement_record(const DevCfg& c, const DevState& s, int b, int T, bool as_gain = true) {
+    double* r = s.rec + ((size_t)b * c.wcap + (T % c.wcap)) * c.rec;
+    const double* quat = s.quat + 4 * (size_t)b;
+    const double* accel = s.accel + 3 * (size_t)b;
+    const double* gyro = s.gyro + 3 * (size_t)b;
+    double R[9];
+    quat_to_rot(quat, R);
+    int L = c.L, nj = c.nj;
+    wfor(L + 1, [&](int i) {
+        if (i < L) {
+            double bm[3], w6[6];
+            leg_terms(c, R, gyro, s.p_foot + ((size_t)b * L + i) * 3, s.J + ((size_t)b * L + i) * 3 * nj,
+                      s.qdot + ((size_t)b * L + i) * nj, s.contact[(size_t)b * L + i], as_gain, bm, w6);
+            for (int a = 0; a < 3; ++a) r[Rec::BM + 3 * i + a] = bm[a];
+            for (int a = 0; a < 6; ++a) r[Rec::qm(c.nm) + 6 * i + a] = w6[a];
+        } else {
+            double as[3];
+            mv3(R, accel, as);
+            for (int a = 0; a < 9; ++a) r[Rec::R + a] = R[a];
+            r[Rec::AS + 0] = as[0]; r[Rec::AS + 1] = as[1]; r[Rec::AS + 2] = as[2] - 9.81;
+            for (int a = 0; a < 3; ++a) r[Rec::GY + a] = gyro[a];
+            r[Rec::VOF] = 0.0;
+            r[Rec::VOB] = r[Rec::VOB + 1] = r[Rec::VOB + 2] = 0.0;
+        }
+    });
+}
+
+// marginalizeQP(step): fold window step `step` into (Mp, np)   (MheSrb.cpp:475-713)
+DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int step, double* sm) {
+    const double* r = s.rec + ((size_t)b * c.wcap + (step % c.wcap)) * c.rec;
+    double* Mp = s.Mp + 81 * (size_t)b;
+    double* np = s.np_ + 9 * (size_t)b;
+    const int nm = c.nm, L = c.L;
+    const bool vo = r[Rec::VOF] != 0.0;
+    const int na = vo ? 12 : 9;
+    const int dim = na + nm;
+    double* Minv = sm;                 // 81
+    double* Am = Minv + 81;            // na x 9
+    double* AmMi = Am + 108;           // na x 9
+    double* S = AmMi + 108;            // dim x dim
+    double* wsc = S + dim * dim;       // dim*dim + dim
+    double* u = wsc + dim * dim + dim; // dim
+    double* Yu = u + dim;              // dim
+    double* Min = Yu + dim;            // 9: M^-1 n
+    const double* R = r + Rec::R;
+    const double dt = c.dt;
+    wfor(81 + na * 9, [&](int e) {
+        if (e < 81) Minv[e] = Mp[e];
+        else {
+            int q = e - 81, i = q / 9, j = q - 9 * i;
+            Am[q] = i < 9 ? adyn_entry(R, dt, i, j) : ((i - 9) == j ? 1.0 : 0.0);
+        }
+    });
+    bool ok = winverse(Minv, 9, wsc, false);
+    wmatmul<false, false>(AmMi, 9, Am, 9, Minv, 9, na, 9, 9);
+    wfor(dim * dim + 9, [&](int e) {
+        if (e >= dim * dim) {
+            int i = e - dim * dim;
+            double sacc = 0;
+            for (int t = 0; t < 9; ++t) sacc += Minv[9 * i + t] * np[t];
+            Min[i] = sacc;
+            return;
+        }
+        int i = e / dim, j = e - i * dim;
+        double v;
+        if (i < na && j < na) {
+            double sacc = 0;
+            for (int t = 0; t < 9; ++t) sacc += AmMi[9 * i + t] * Am[9 * j + t];
+            v = -sacc;
+        } else if (i >= na && j >= na) {
+            v = -Minv[9 * (3 + (i - na) % 3) + 3 + (j - na) % 3];
+        } else {
+            int a = i < na ? i : j, q = i < na ? j : i;
+            v = -AmMi[9 * a + 3 + (q - na) % 3];
+        }
+        S[e] = v;
+    });
+    // minus the inverse gains on the diagonal blocks: one lane per block
+    wfor(L + 2, [&](int blk) {
+        if (blk < L) {
+            const double* q6 = r + Rec::qm(nm) + 6 * blk;
+            double Q[9] = {q6[0], q6[1], q6[2], q6[1], q6[3], q6[4], q6[2], q6[4], q6[5]};
+            inv_small<3>(Q, 3);
+            for (int a = 0; a < 3; ++a)
+                for (int d = 0; d < 3; ++d) S[(na + 3 * blk + a) * dim + na + 3 * blk + d] -= Q[3 * a + d];
+        } else if (blk == L) {
+            double Q[36];
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) Q[6 * i + j] = symget(r + Rec::QD, i, j, 6);
+            inv_small<6>(Q, 6);
+            for (int i = 0; i < 6; ++i)
+                for (int j = 0; j < 6; ++j) S[i * dim + j] -= Q[6 * i + j];
+            for (int i = 0; i < 3; ++i) S[(6 + i) * dim + 6 + i] -= 1.0 / c.Q_bias_dt2[i];
+        } else if (vo) {
+            const double* q6 = r + Rec::QC;
+            double Q[9] = {q6[0], q6[1], q6[2], q6[1], q6[3], q6[4], q6[2], q6[4], q6[5]};
+            inv_small<3>(Q, 3);
+            for (int a = 0; a < 3; ++a)
+                for (int d = 0; d < 3; ++d) S[(9 + a) * dim + 9 + d] -= Q[3 * a + d];
+        }
+    });
+    // u = [ b_dyn ; vo bound ] + Am M^-1 n   |   b_meas + H M^-1 n
+    wfor(dim, [&](int i) {
+        double v;
+        if (i < na) {
+            double sacc = 0;
+            for (int t = 0; t < 9; ++t) sacc += Am[9 * i + t] * Min[t];
+            double rhs;
+            if (i < 3) rhs = -0.5 * dt * dt * r[Rec::AS + i];
+            else if (i < 6) rhs = -dt * r[Rec::AS + i - 3];
+            else if (i < 9) rhs = 0.0;
+            else rhs = r[Rec::VOB + i - 9];
+            v = rhs + sacc;
+        } else {
+            v = r[Rec::BM + i - na] + Min[3 + (i - na) % 3];
+        }
+        u[i] = v;
+    });
+    ok = winverse(S, dim, wsc, true) && ok;
+    wfor(dim, [&](int i) {
+        double sacc = 0;
+        for (int t = 0; t < dim; ++t) sacc += S[i * dim + t] * u[t];
+        Yu[i] = sacc;
+    });
+    // M+ = -B' S^-1 B, n+ = B' S^-1 u with B = [-I9; -[I3 0] (VO); 0]
+    wfor(90, [&](int e) {
+        if (e < 81) {
+            int i = e / 9, j = e - 9 * i;
+            double v = S[i * dim + j];
+            if (vo) {
+                if (i < 3) v += S[(9 + i) * dim + j];
+                if (j < 3) v += S[i * dim + 9 + j];
+                if (i < 3 && j < 3) v += S[(9 + i) * dim + 9 + j];
+            }
+            Mp[e] = -v;
+        } else {
+            int i = e - 81;
+            double v = Yu[i];
+            if (vo && i < 3) v += Yu[9 + i];
+            np[i] = -v;
+        }
+    });
+    return ok;
+}
+
+// everything update(T) does before initQP/solveQP; T >= 1
+DEKF_FN void assemble_update(const DevCfg& c, const DevState& s, int b, int T, int pushes, double* sm) {
+    // UpdateMHE part 1: gains of step T-1 from stack.back()
+    double* rprev = s.rec + ((size_t)b * c.wcap + ((T - 1) % c.wcap)) * c.rec;
+    if (DEKF_LANE() == 0) {
+        double qd[21], qc[6];
+        step_gains(c, rprev + Rec::R, qd, qc);
+        for (int i = 0; i < 21; ++i) rprev[Rec::QD + i] = qd[i];
+        for (int i = 0; i < 6; ++i) rprev[Rec::QC + i] = qc[i];
+    }
+    DEKF_SYNC();
+    get_measurement(c, s, b, T, pushes, sm);
+    write_measurement_record(c, s, b, T);
+    if (T >= c.N) marginalize_step(c, s, b, T - c.N, sm);
+}
+
+// InitializeMHE (DecentralEst.cpp:200-351): first sample, prior as arrival cost
+DEKF_FN void assemble_initialize(const DevCfg& c, const DevState& s, int b, double* sm) {
+    get_measurement(c, s, b, 0, 0, sm);
+    write_measurement_record(c, s, b, 0);
+    double* Mp = s.Mp + 81 * (size_t)b;
+    double* np = s.np_ + 9 * (size_t)b;
+    wfor(90, [&](int e) {
+        if (e < 81) Mp[e] = (e / 9 == e % 9) ? c.Q_prior[e / 9] : 0.0;
+        else np[e - 81] = 0.0;
+    });
+}
+
+}  // namespace dekf

@@ -1,0 +1,663 @@
+// mhe_solve_core.h — per-instance (one wavefront) OSQP-style ADMM solve of the MHE window QP.
+//
+// Replaces  MHEproblem::initQP + solveQP + getsolution  (src/decentral_legged_est/src/MheSrb.cpp:
+// 272-349, 715-723), i.e. osqp_setup + osqp_solve on
+//     min 1/2 x'Hx + g'x   s.t.  l <= Ax <= u
+// with H, g, A, l, u as MHEproblem::updateQP / marginalizeQP leave them (:351-447, :475-713),
+// and the tail of DecentralizedEstimation::update (DecentralEst.cpp:179-185).
+//
+// Same algorithm as OSQP (Ruiz equilibration, per-row rho, sigma/alpha-relaxed ADMM,
+// termination every check_termination iterations on unscaled residuals, adaptive rho with
+// refactorisation, cold start), different linear algebra: the QP is never assembled.
+// Per window step k the variables are [x_k(9) v_k(3L) w_k(9) c_k(3)] and the rows
+// [Meas_k(3L) Dyn_k(9) VO_k(3)], every slack v/w/c appears in exactly
+// one row with coefficient -1, and H is block diagonal.  The ADMM linear system
+//     (P + sigma I + A' diag(rho) A) xt = sigma x - q + A'(diag(rho) z - y),   zt = A xt
+// (OSQP's KKT system with nu eliminated) therefore reduces, after eliminating the slack blocks
+// (3x3 per leg, 6x6+3 for w, 3x3 for c), to a block-tridiagonal SPD system in the x_k with
+// 9x9 blocks — a fixed-interval smoother — solved by block LDL': S_k^-1 and W_k = C_k S_k^-1
+// are the "banded KKT factor", refreshed whenever rho changes.
+//
+// Memory: ADMM iterates + right-hand sides live in LDS; scaling vectors, bounds, slack-block
+// inverses and the tridiagonal factor are streamed from a per-workgroup HBM scratch (L2 / MALL
+// resident); window records are read where they lie in HBM.
+#pragma once
+#include "cfg.h"
+#include "mhe_assemble_core.h"
+#include "smallmat.h"
+
+namespace dekf {
+
+struct SolveLds {
+    double *x, *z, *y, *xt, *zt, *at, *tmp;  // tmp: 192 doubles
+    DEKF_FN static int len(int N, int L) {
+        int nm = 3 * L;
+        int n_pad = N * (9 + nm + 12), m_pad = N * (nm + 12);
+        return 2 * n_pad + 4 * m_pad + 192;
+    }
+    DEKF_FN void carve(double* base, int N, int L) {
+        int nm = 3 * L;
+        int n_pad = N * (9 + nm + 12), m_pad = N * (nm + 12);
+        x = base; xt = x + n_pad; z = xt + n_pad; y = z + m_pad; zt = y + m_pad; at = zt + m_pad; tmp = at + m_pad;
+    }
+};
+
+struct SolveCtx {
+    const DevCfg& c;
+    const DevState& s;
+    int b, K, kstart, n, m;
+    Idx ix;
+    SolveLds l;
+    double *D, *E, *lo, *hi, *rho, *Sv, *Sw, *Sc, *Wm, *Wd, *Wc, *PA, *Sinv, *Wk;
+    const double *Mp, *np;
+    double cc;  // cost scaling c
+
+    DEKF_FN const double* rec(int k) const {
+        return s.rec + ((size_t)b * c.wcap + ((kstart + k) % c.wcap)) * c.rec;
+    }
+    // unscaled bound of row (k, kind, o): kind 0 Meas, 1 Dyn, 2 VO
+    DEKF_FN void bounds(int k, int kind, int o, double& lb, double& ub) const {
+        const double* r = rec(k);
+        if (kind == 0) lb = ub = r[Rec::BM + o];
+        else if (kind == 1) lb = ub = (o < 3 ? -0.5 * c.dt * c.dt * r[Rec::AS + o] : (o < 6 ? -c.dt * r[Rec::AS + o - 3] : 0.0));
+        else if (r[Rec::VOF] != 0.0) lb = ub = r[Rec::VOB + o];
+        else { lb = -OSQP_INFTY; ub = OSQP_INFTY; }
+    }
+    DEKF_FN void dec_var(int i, int& k, int& kind, int& o) const {
+        k = i / ix.SV;
+        int q = i - k * ix.SV;
+        if (q < 9) { kind = 0; o = q; }
+        else if (q < 9 + ix.nm) { kind = 1; o = q - 9; }
+        else if (q < 18 + ix.nm) { kind = 2; o = q - 9 - ix.nm; }
+        else { kind = 3; o = q - 18 - ix.nm; }
+    }
+    DEKF_FN void dec_row(int r, int& k, int& kind, int& o) const {
+        k = r / ix.SC;
+        int q = r - k * ix.SC;
+        if (q < ix.nm) { kind = 0; o = q; }
+        else if (q < ix.nm + 9) { kind = 1; o = q - ix.nm; }
+        else { kind = 2; o = q - ix.nm - 9; }
+    }
+    // row that slack variable (k, kind 1..3, o) lives in, and vice versa
+    DEKF_FN int slack_row(int k, int kind, int o) const { return kind == 1 ? ix.rm(k, o) : (kind == 2 ? ix.rd(k, o) : ix.rv(k, o)); }
+    DEKF_FN int row_slack(int k, int kind, int o) const { return kind == 0 ? ix.v(k, o) : (kind == 1 ? ix.w(k, o) : ix.c(k, o)); }
+
+    // (scaled A restricted to the x blocks)' * vec, component x_k[j]
+    DEKF_FN double gather_x(int k, int j, const double* vec) const {
+        double dj = D[ix.x(k, j)];
+        double acc = 0.0;
+        if (j >= 3 && j < 6)
+            for (int leg = 0; leg < c.L; ++leg) { int r = ix.rm(k, 3 * leg + j - 3); acc += E[r] * vec[r]; }
+        if (k < K - 1) {
+            const double* R = rec(k) + Rec::R;
+            for (int rr = 0; rr < 9; ++rr) {
+                double a = adyn_entry(R, c.dt, rr, j);
+                if (a != 0.0) { int r = ix.rd(k, rr); acc += E[r] * a * vec[r]; }
+            }
+            if (j < 3) { int r = ix.rv(k, j); acc += E[r] * vec[r]; }
+        }
+        if (k > 0) {
+            int r = ix.rd(k - 1, j);
+            acc -= E[r] * vec[r];
+            if (j < 3) { int r2 = ix.rv(k - 1, j); acc -= E[r2] * vec[r2]; }
+        }
+        return acc * dj;
+    }
+    // (scaled A restricted to the x blocks) * xv, row (k, kind, o)
+    DEKF_FN double row_dot_x(int k, int kind, int o, const double* xv) const {
+        double acc;
+        if (kind == 0) {
+            int i = ix.x(k, 3 + o % 3);
+            acc = D[i] * xv[i];
+        } else if (kind == 1) {
+            const double* R = rec(k) + Rec::R;
+            acc = 0.0;
+            for (int j = 0; j < 9; ++j) {
+                double a = adyn_entry(R, c.dt, o, j);
+                if (a != 0.0) { int i = ix.x(k, j); acc += a * D[i] * xv[i]; }
+            }
+            int i2 = ix.x(k + 1, o);
+            acc -= D[i2] * xv[i2];
+        } else {
+            int i = ix.x(k, o), i2 = ix.x(k + 1, o);
+            acc = D[i] * xv[i] - D[i2] * xv[i2];
+        }
+        int r = kind == 0 ? ix.rm(k, o) : (kind == 1 ? ix.rd(k, o) : ix.rv(k, o));
+        return E[r] * acc;
+    }
+    // unscaled P entry helpers -------------------------------------------------------
+    // (P_scaled x)_i for variable i, and the inf-norm of column i of P_scaled
+    DEKF_FN double p_apply(int i, const double* xv, bool norm_only) const {
+        int k, kind, o;
+        dec_var(i, k, kind, o);
+        double di = D[i];
+        double acc = 0.0;
+        auto term = [&](double pij, int i2) {
+            double v = cc * di * pij * D[i2];
+            if (norm_only) acc = dmax(acc, fabs(v));
+            else acc += v * xv[i2];
+        };
+        if (kind == 0) {
+            if (k == 0 && kstart >= 0)
+                for (int t = 0; t < 9; ++t) term(o <= t ? Mp[9 * o + t] : Mp[9 * t + o], ix.x(0, t));
+        } else if (kind == 1) {
+            int leg = o / 3, a = o - 3 * leg;
+            const double* q6 = rec(k) + Rec::qm(ix.nm) + 6 * leg;
+            for (int t = 0; t < 3; ++t) term(symget(q6, a, t, 3), ix.v(k, 3 * leg + t));
+        } else if (kind == 2) {
+            if (o < 6) {
+                const double* q21 = rec(k) + Rec::QD;
+                for (int t = 0; t < 6; ++t) term(symget(q21, o, t, 6), ix.w(k, t));
+            } else term(c.Q_bias_dt2[o - 6], i);
+        } else {
+            const double* q6 = rec(k) + Rec::QC;
+            for (int t = 0; t < 3; ++t) term(symget(q6, o, t, 3), ix.c(k, t));
+        }
+        return acc;
+    }
+    // inf-norm of column i of the scaled A
+    DEKF_FN double a_colnorm(int i) const {
+        int k, kind, o;
+        dec_var(i, k, kind, o);
+        double di = D[i];
+        if (kind != 0) return E[slack_row(k, kind, o)] * di;
+        double acc = 0.0;
+        if (o >= 3 && o < 6)
+            for (int leg = 0; leg < c.L; ++leg) acc = dmax(acc, E[ix.rm(k, 3 * leg + o - 3)]);
+        if (k < K - 1) {
+            const double* R = rec(k) + Rec::R;
+            for (int rr = 0; rr < 9; ++rr) acc = dmax(acc, E[ix.rd(k, rr)] * fabs(adyn_entry(R, c.dt, rr, o)));
+            if (o < 3) acc = dmax(acc, E[ix.rv(k, o)]);
+        }
+        if (k > 0) {
+            acc = dmax(acc, E[ix.rd(k - 1, o)]);
+            if (o < 3) acc = dmax(acc, E[ix.rv(k - 1, o)]);
+        }
+        return acc * di;
+    }
+    // inf-norm of row r of the scaled A
+    DEKF_FN double a_rownorm(int r) const {
+        int k, kind, o;
+        dec_row(r, k, kind, o);
+        double acc = D[row_slack(k, kind, o)];
+        if (kind == 0) acc = dmax(acc, D[ix.x(k, 3 + o % 3)]);
+        else if (kind == 1) {
+            const double* R = rec(k) + Rec::R;
+            for (int j = 0; j < 9; ++j) acc = dmax(acc, fabs(adyn_entry(R, c.dt, o, j)) * D[ix.x(k, j)]);
+            acc = dmax(acc, D[ix.x(k + 1, o)]);
+        } else {
+            acc = dmax(acc, dmax(D[ix.x(k, o)], D[ix.x(k + 1, o)]));
+        }
+        return acc * E[r];
+    }
+};
+
+DEKF_FN double limit_scaling(double v) {
+    v = v < MIN_SCALING ? 1.0 : v;
+    v = v > MAX_SCALING ? MAX_SCALING : v;
+    return v;
+}
+
+// Ruiz equilibration + cost scaling (OSQP scale_data), on the structured QP
+DEKF_FN void solve_scale(SolveCtx& q) {
+    const int n = q.n, m = q.m;
+    wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; });
+    q.cc = 1.0;
+    const double* g = q.np;
+    for (int it = 0; it < q.c.scaling; ++it) {
+        wfor(n + m, [&](int e) {
+            if (e < n) {
+                double v = dmax(q.p_apply(e, nullptr, true), q.a_colnorm(e));
+                q.l.xt[e] = 1.0 / sqrt(limit_scaling(v));
+            } else {
+                q.l.zt[e - n] = 1.0 / sqrt(limit_scaling(q.a_rownorm(e - n)));
+            }
+        });
+        wfor(n + m, [&](int e) { if (e < n) q.D[e] *= q.l.xt[e]; else q.E[e - n] *= q.l.zt[e - n]; });
+        double psum = wred_sum(n, [&](int i) { return q.p_apply(i, nullptr, true); });
+        double qn = 0.0;
+        for (int j = 0; j < 9; ++j) qn = dmax(qn, fabs(q.cc * q.D[q.ix.x(0, j)] * g[j]));
+        double ct = 1.0 / limit_scaling(dmax(psum / (double)n, limit_scaling(qn)));
+        q.cc *= ct;
+        DEKF_SYNC();
+    }
+}
+
+// scaled bounds and per-row rho (OSQP set_rho_vec / osqp_update_rho)
+DEKF_FN void solve_bounds_rho(SolveCtx& q, double rho, bool bounds_too) {
+    wfor(q.m, [&](int r) {
+        int k, kind, o;
+        q.dec_row(r, k, kind, o);
+        double lb, ub;
+        if (bounds_too) {
+            q.bounds(k, kind, o, lb, ub);
+            lb *= q.E[r]; ub *= q.E[r];
+            q.lo[r] = lb; q.hi[r] = ub;
+        } else { lb = q.lo[r]; ub = q.hi[r]; }
+        double rv;
+        if (lb < -OSQP_INFTY * MIN_SCALING && ub > OSQP_INFTY * MIN_SCALING) rv = RHO_MIN;
+        else if (ub - lb < RHO_TOL) rv = RHO_EQ_OVER_RHO_INEQ * rho;
+        else rv = rho;
+        q.rho[r] = rv;
+    });
+}
+
+// numeric factorisation for the current rho: slack-block inverses, effective row weights,
+// block-tridiagonal LDL' (S_k^-1, W_k)
+DEKF_FN bool solve_factor(SolveCtx& q) {
+    const DevCfg& c = q.c;
+    const int K = q.K, L = c.L, nm = c.nm;
+    const Idx& ix = q.ix;
+    const double sigma = c.sigma, cc = q.cc;
+    // 3a. slack blocks: one lane per block
+    wfor(K * (L + 2), [&](int e) {
+        int k = e / (L + 2), blk = e - k * (L + 2);
+        const double* r = q.rec(k);
+        if (blk < L) {
+            const double* q6 = r + Rec::qm(nm) + 6 * blk;
+            double gv[3], rr[3], S6[6], Si[6];
+            for (int a = 0; a < 3; ++a) {
+                int row = ix.rm(k, 3 * blk + a);
+                double beta = q.E[row] * q.D[ix.v(k, 3 * blk + a)];
+                rr[a] = q.rho[row];
+                gv[a] = rr[a] * beta;
+                S6[symidx(a, a, 3)] = 0.0;
+            }
+            for (int a = 0; a < 3; ++a)
+                for (int d = a; d < 3; ++d)
+                    S6[symidx(a, d, 3)] = cc * q.D[ix.v(k, 3 * blk + a)] * q6[symidx(a, d, 3)] * q.D[ix.v(k, 3 * blk + d)];
+            for (int a = 0; a < 3; ++a) S6[symidx(a, a, 3)] += sigma + gv[a] * q.E[ix.rm(k, 3 * blk + a)] * q.D[ix.v(k, 3 * blk + a)];
+            inv3_sym(S6, Si);
+            for (int t = 0; t < 6; ++t) q.Sv[(k * L + blk) * 6 + t] = Si[t];
+            for (int a = 0; a < 3; ++a)
+                for (int d = a; d < 3; ++d)
+                    q.Wm[(k * L + blk) * 6 + symidx(a, d, 3)] = (a == d ? rr[a] : 0.0) - gv[a] * Si[symidx(a, d, 3)] * gv[d];
+        } else if (k < K - 1 && blk == L) {
+            const double* q21 = r + Rec::QD;
+            double S[36], gv[9], rr[9];
+            for (int a = 0; a < 9; ++a) {
+                int row = ix.rd(k, a);
+                double beta = q.E[row] * q.D[ix.w(k, a)];
+                rr[a] = q.rho[row];
+                gv[a] = rr[a] * beta;
+            }
+            for (int a = 0; a < 6; ++a)
+                for (int d = 0; d < 6; ++d)
+                    S[6 * a + d] = cc * q.D[ix.w(k, a)] * symget(q21, a, d, 6) * q.D[ix.w(k, d)] +
+                                   (a == d ? sigma + gv[a] * q.E[ix.rd(k, a)] * q.D[ix.w(k, a)] : 0.0);
+            inv_small<6>(S, 6);
+            double* sw = q.Sw + k * 24;
+            double* wd = q.Wd + k * 24;
+            for (int a = 0; a < 6; ++a)
+                for (int d = a; d < 6; ++d) {
+                    double si = 0.5 * (S[6 * a + d] + S[6 * d + a]);
+                    sw[symidx(a, d, 6)] = si;
+                    wd[symidx(a, d, 6)] = (a == d ? rr[a] : 0.0) - gv[a] * si * gv[d];
+                }
+            for (int a = 6; a < 9; ++a) {
+                double dw = q.D[ix.w(k, a)];
+                double sdiag = cc * dw * c.Q_bias_dt2[a - 6] * dw + sigma + gv[a] * q.E[ix.rd(k, a)] * dw;
+                sw[21 + a - 6] = 1.0 / sdiag;
+                wd[21 + a - 6] = rr[a] - gv[a] * gv[a] / sdiag;
+            }
+        } else if (k < K - 1 && blk == L + 1) {
+            const double* q6 = r + Rec::QC;
+            double gv[3], rr[3], S6[6], Si[6];
+            for (int a = 0; a < 3; ++a) {
+                int row = ix.rv(k, a);
+                rr[a] = q.rho[row];
+                gv[a] = rr[a] * q.E[row] * q.D[ix.c(k, a)];
+            }
+            for (int a = 0; a < 3; ++a)
+                for (int d = a; d < 3; ++d)
+                    S6[symidx(a, d, 3)] = cc * q.D[ix.c(k, a)] * q6[symidx(a, d, 3)] * q.D[ix.c(k, d)];
+            for (int a = 0; a < 3; ++a) S6[symidx(a, a, 3)] += sigma + gv[a] * q.E[ix.rv(k, a)] * q.D[ix.c(k, a)];
+            inv3_sym(S6, Si);
+            for (int t = 0; t < 6; ++t) q.Sc[k * 6 + t] = Si[t];
+            for (int a = 0; a < 3; ++a)
+                for (int d = a; d < 3; ++d)
+                    q.Wc[k * 6 + symidx(a, d, 3)] = (a == d ? rr[a] : 0.0) - gv[a] * Si[symidx(a, d, 3)] * gv[d];
+        }
+    });
+    // effective dyn-row weight as a 9x9 accessor
+    auto wd_at = [&](int k, int a, int d) -> double {
+        const double* wd = q.Wd + k * 24;
+        if (a < 6 && d < 6) return symget(wd, a, d, 6);
+        return (a == d) ? wd[21 + a - 6] : 0.0;
+    };
+    // 3b. PA_k = Wd_k * (E_D A_dyn D_x)
+    wfor((K - 1) * 81, [&](int e) {
+        int k = e / 81, p = e - 81 * k, i = p / 9, j = p - 9 * i;
+        const double* R = q.rec(k) + Rec::R;
+        double acc = 0.0;
+        for (int t = 0; t < 9; ++t) {
+            double w = wd_at(k, i, t);
+            if (w != 0.0) acc += w * q.E[ix.rd(k, t)] * adyn_entry(R, c.dt, t, j);
+        }
+        q.PA[e] = acc * q.D[ix.x(k, j)];
+    });
+    // 3c. T_kk -> Sinv[k], C_k -> Wk[k]
+    wfor(K * 81 + (K - 1) * 81, [&](int e) {
+        if (e < K * 81) {
+            int k = e / 81, p = e - 81 * k, i = p / 9, j = p - 9 * i;
+            double di = q.D[ix.x(k, i)], dj = q.D[ix.x(k, j)];
+            double acc = (i == j) ? sigma : 0.0;
+            if (k == 0) acc += cc * di * (i <= j ? q.Mp[9 * i + j] : q.Mp[9 * j + i]) * dj;
+            if (i >= 3 && i < 6 && j >= 3 && j < 6)
+                for (int leg = 0; leg < L; ++leg)
+                    acc += q.E[ix.rm(k, 3 * leg + i - 3)] * di * symget(q.Wm + (k * L + leg) * 6, i - 3, j - 3, 3) *
+                           q.E[ix.rm(k, 3 * leg + j - 3)] * dj;
+            if (k < K - 1) {
+                if (i < 3 && j < 3) acc += q.E[ix.rv(k, i)] * di * symget(q.Wc + k * 6, i, j, 3) * q.E[ix.rv(k, j)] * dj;
+                const double* R = q.rec(k) + Rec::R;
+                for (int t = 0; t < 9; ++t) {
+                    double a = adyn_entry(R, c.dt, t, i);
+                    if (a != 0.0) acc += q.E[ix.rd(k, t)] * a * di * q.PA[k * 81 + 9 * t + j];
+                }
+            }
+            if (k > 0) {
+                acc += q.E[ix.rd(k - 1, i)] * di * wd_at(k - 1, i, j) * q.E[ix.rd(k - 1, j)] * dj;
+                if (i < 3 && j < 3)
+                    acc += q.E[ix.rv(k - 1, i)] * di * symget(q.Wc + (k - 1) * 6, i, j, 3) * q.E[ix.rv(k - 1, j)] * dj;
+            }
+            q.Sinv[e] = acc;
+        } else {
+            int e2 = e - K * 81;
+            int k = e2 / 81, p = e2 - 81 * k, i = p / 9, j = p - 9 * i;
+            double d1 = q.D[ix.x(k + 1, i)];
+            double acc = -q.E[ix.rd(k, i)] * d1 * q.PA[k * 81 + p];
+            if (i < 3 && j < 3)
+                acc -= q.E[ix.rv(k, i)] * d1 * symget(q.Wc + k * 6, i, j, 3) * q.E[ix.rv(k, j)] * q.D[ix.x(k, j)];
+            q.Wk[e2] = acc;
+        }
+    });
+    // C_k moves to PA[k]; W_k will be written to Wk[k]
+    wfor((K - 1) * 81, [&](int e) { q.PA[e] = q.Wk[e]; });
+    // 3d. block LDL'
+    bool ok = true;
+    double* scratch = q.l.tmp;  // 90 doubles
+    for (int k = 0; k < K; ++k) {
+        double* Sk = q.Sinv + k * 81;
+        if (k > 0) {
+            const double* Wp = q.Wk + (k - 1) * 81;
+            const double* Cp = q.PA + (k - 1) * 81;
+            wfor(81, [&](int p) {
+                int i = p / 9, j = p - 9 * i;
+                double acc = 0.0;
+                for (int t = 0; t < 9; ++t) acc += Wp[9 * i + t] * Cp[9 * j + t];
+                Sk[p] -= acc;
+            });
+        }
+        // symmetrise (round-off) then invert in place
+        wfor(81, [&](int p) {
+            int i = p / 9, j = p - 9 * i;
+            if (i < j) { double v = 0.5 * (Sk[9 * i + j] + Sk[9 * j + i]); scratch[100 + p] = v; }
+        });
+        wfor(81, [&](int p) {
+            int i = p / 9, j = p - 9 * i;
+            if (i < j) { Sk[9 * i + j] = scratch[100 + p]; Sk[9 * j + i] = scratch[100 + p]; }
+        });
+        ok = winverse(Sk, 9, scratch, false) && ok;
+        if (k < K - 1) {
+            const double* Ck = q.PA + k * 81;
+            double* Wk = q.Wk + k * 81;
+            wfor(81, [&](int p) {
+                int i = p / 9, j = p - 9 * i;
+                double acc = 0.0;
+                for (int t = 0; t < 9; ++t) acc += Ck[9 * i + t] * Sk[9 * t + j];
+                Wk[p] = acc;
+            });
+        }
+    }
+    return ok;
+}
+
+// apply a slack-block inverse: out[row of slack] = sum_s' Sinv_block[s][s'] * in(s')
+template <class InF>
+DEKF_FN double slack_inv_apply(const SolveCtx& q, int k, int kind, int o, InF in) {
+    const Idx& ix = q.ix;
+    if (kind == 1) {
+        int leg = o / 3, a = o - 3 * leg;
+        const double* si = q.Sv + (k * q.c.L + leg) * 6;
+        double acc = 0.0;
+        for (int t = 0; t < 3; ++t) acc += symget(si, a, t, 3) * in(ix.v(k, 3 * leg + t), ix.rm(k, 3 * leg + t));
+        return acc;
+    } else if (kind == 2) {
+        const double* sw = q.Sw + k * 24;
+        if (o >= 6) return sw[21 + o - 6] * in(ix.w(k, o), ix.rd(k, o));
+        double acc = 0.0;
+        for (int t = 0; t < 6; ++t) acc += symget(sw, o, t, 6) * in(ix.w(k, t), ix.rd(k, t));
+        return acc;
+    } else {
+        const double* si = q.Sc + k * 6;
+        double acc = 0.0;
+        for (int t = 0; t < 3; ++t) acc += symget(si, o, t, 3) * in(ix.c(k, t), ix.rv(k, t));
+        return acc;
+    }
+}
+
+// one linear solve: l.xt holds the right-hand side (n) on entry and xt on exit; l.at gets zt = A xt
+DEKF_FN void solve_linear(SolveCtx& q) {
+    const int n = q.n, m = q.m, K = q.K;
+    const Idx& ix = q.ix;
+    double *xt = q.l.xt, *zt = q.l.zt, *at = q.l.at, *tmp = q.l.tmp;
+    // t = S^-1 rhs_s (stored at the slack's row), h = rho*beta*t
+    wfor(m, [&](int r) {
+        int k, kind, o;
+        q.dec_row(r, k, kind, o);
+        zt[r] = slack_inv_apply(q, k, kind + 1, o, [&](int var, int) { return xt[var]; });
+    });
+    wfor(m, [&](int r) {
+        int k, kind, o;
+        q.dec_row(r, k, kind, o);
+        at[r] = q.rho[r] * q.E[r] * q.D[q.row_slack(k, kind, o)] * zt[r];
+    });
+    wfor(K * 9, [&](int e) {
+        int k = e / 9, j = e - 9 * k;
+        xt[ix.x(k, j)] += q.gather_x(k, j, at);
+    });
+    // block-tridiagonal solve
+    for (int k = 1; k < K; ++k) {
+        const double* W = q.Wk + (k - 1) * 81;
+        wfor(9, [&](int i) {
+            double acc = 0.0;
+            for (int t = 0; t < 9; ++t) acc += W[9 * i + t] * xt[ix.x(k - 1, t)];
+            xt[ix.x(k, i)] -= acc;
+        });
+    }
+    for (int k = K - 1; k >= 0; --k) {
+        const double* Si = q.Sinv + k * 81;
+        const double* W = q.Wk + k * 81;
+        wfor(9, [&](int i) {
+            double acc = 0.0;
+            for (int t = 0; t < 9; ++t) acc += Si[9 * i + t] * xt[ix.x(k, t)];
+            if (k < K - 1)
+                for (int t = 0; t < 9; ++t) acc -= W[9 * t + i] * xt[ix.x(k + 1, t)];
+            tmp[i] = acc;
+        });
+        wfor(9, [&](int i) { xt[ix.x(k, i)] = tmp[i]; });
+    }
+    // a = A_x xt_x ; slack back-substitution ; zt = a - beta * s
+    wfor(m, [&](int r) {
+        int k, kind, o;
+        q.dec_row(r, k, kind, o);
+        at[r] = q.row_dot_x(k, kind, o, xt);
+    });
+    wfor(m, [&](int r) {
+        int k, kind, o;
+        q.dec_row(r, k, kind, o);
+        double corr = slack_inv_apply(q, k, kind + 1, o, [&](int var, int row) { return q.rho[row] * q.E[row] * q.D[var] * at[row]; });
+        xt[q.row_slack(k, kind, o)] = zt[r] + corr;
+    });
+    wfor(m, [&](int r) {
+        int k, kind, o;
+        q.dec_row(r, k, kind, o);
+        int sv = q.row_slack(k, kind, o);
+        at[r] -= q.E[r] * q.D[sv] * xt[sv];
+    });
+    (void)n;
+}
+
+struct SolveInfo {
+    int iters, status, rho_updates;
+    double pri_res, dua_res, rho;
+};
+
+// osqp_setup + osqp_solve + extraction.  window = steps kstart .. kstart+K-1 (newest = T)
+DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, double* lds, double* gws) {
+    Gws g;
+    g.init(c.N, c.L);
+    SolveCtx q{c, s, b, K, kstart, 0, 0, Idx{c.nm, c.SV, c.SC}, SolveLds{}, nullptr, nullptr, nullptr, nullptr, nullptr,
+               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0};
+    q.l.carve(lds, c.N, c.L);
+    q.n = (K - 1) * c.SV + 9 + c.nm;
+    q.m = (K - 1) * c.SC + c.nm;
+    q.D = gws + g.D; q.E = gws + g.E; q.lo = gws + g.lo; q.hi = gws + g.hi; q.rho = gws + g.rho;
+    q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc; q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
+    q.PA = gws + g.PA; q.Sinv = gws + g.Sinv; q.Wk = gws + g.Wk;
+    q.Mp = s.Mp + 81 * (size_t)b;
+    q.np = s.np_ + 9 * (size_t)b;
+    const int n = q.n, m = q.m;
+    const Idx& ix = q.ix;
+    SolveInfo info{0, DEKF_SOLVE_MAX_ITER, 0, 0.0, 0.0, c.rho0};
+
+    if (c.scaling > 0) solve_scale(q);
+    else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); q.cc = 1.0; }
+    double rho = dmin(dmax(c.rho0, RHO_MIN), RHO_MAX);
+    solve_bounds_rho(q, rho, true);
+    bool ok = solve_factor(q);
+    double qs[9];  // scaled linear cost on x_0
+    for (int j = 0; j < 9; ++j) qs[j] = q.cc * q.D[ix.x(0, j)] * q.np[j];
+    double *x = q.l.x, *z = q.l.z, *y = q.l.y, *xt = q.l.xt, *zt = q.l.zt, *at = q.l.at;
+    wfor(n + 2 * m, [&](int e) {
+        if (e < n) x[e] = 0.0;
+        else if (e < n + m) z[e - n] = 0.0;
+        else y[e - n - m] = 0.0;
+    });
+    const double sigma = c.sigma, alpha = c.alpha;
+    const double cinv = 1.0 / q.cc;
+    int iter = 0;
+    bool done = false;
+    while (ok && !done && iter < c.max_iter) {
+        ++iter;
+        // right-hand side: sigma x - q + A'(rho z - y)
+        wfor(m, [&](int r) { zt[r] = q.rho[r] * z[r] - y[r]; });
+        wfor(n, [&](int i) {
+            int k, kind, o;
+            q.dec_var(i, k, kind, o);
+            double v = sigma * x[i];
+            if (kind == 0) {
+                if (k == 0) v -= qs[o];
+                v += q.gather_x(k, o, zt);
+            } else {
+                int r = q.slack_row(k, kind, o);
+                v -= q.E[r] * q.D[i] * zt[r];
+            }
+            xt[i] = v;
+        });
+        solve_linear(q);
+        // x, z, y updates (alpha relaxation, projection onto [lo, hi])
+        wfor(n + m, [&](int e) {
+            if (e < n) x[e] = alpha * xt[e] + (1.0 - alpha) * x[e];
+            else {
+                int r = e - n;
+                double rv = q.rho[r];
+                double zh = alpha * at[r] + (1.0 - alpha) * z[r];
+                double zn = dmin(dmax(zh + y[r] / rv, q.lo[r]), q.hi[r]);
+                y[r] += rv * (zh - zn);
+                z[r] = zn;
+            }
+        });
+        bool can_check = c.check_termination > 0 && (iter % c.check_termination == 0);
+        bool adapt_now = c.adaptive_rho && c.adaptive_rho_interval > 0 && (iter % c.adaptive_rho_interval == 0);
+        if (can_check || adapt_now || iter == c.max_iter) {
+            // residuals: rows
+            double ra[6], va[8];
+            wred_maxn<6>(m, ra, [&](int r, double* acc) {
+                int k, kind, o;
+                q.dec_row(r, k, kind, o);
+                int sv = q.row_slack(k, kind, o);
+                double Ax = q.row_dot_x(k, kind, o, x) - q.E[r] * q.D[sv] * x[sv];
+                double pr = Ax - z[r];
+                double ei = 1.0 / q.E[r];
+                acc[0] = dmax(acc[0], fabs(pr) * ei);
+                acc[1] = dmax(acc[1], fabs(z[r]) * ei);
+                acc[2] = dmax(acc[2], fabs(Ax) * ei);
+                acc[3] = dmax(acc[3], fabs(pr));
+                acc[4] = dmax(acc[4], fabs(z[r]));
+                acc[5] = dmax(acc[5], fabs(Ax));
+            });
+            wred_maxn<8>(n, va, [&](int i, double* acc) {
+                int k, kind, o;
+                q.dec_var(i, k, kind, o);
+                double Px = q.p_apply(i, x, false);
+                double Aty, qv = 0.0;
+                if (kind == 0) {
+                    Aty = q.gather_x(k, o, y);
+                    if (k == 0) qv = qs[o];
+                } else {
+                    int r = q.slack_row(k, kind, o);
+                    Aty = -q.E[r] * q.D[i] * y[r];
+                }
+                double dr = qv + Px + Aty;
+                double di = 1.0 / q.D[i];
+                acc[0] = dmax(acc[0], fabs(dr) * di);
+                acc[1] = dmax(acc[1], fabs(qv) * di);
+                acc[2] = dmax(acc[2], fabs(Aty) * di);
+                acc[3] = dmax(acc[3], fabs(Px) * di);
+                acc[4] = dmax(acc[4], fabs(dr));
+                acc[5] = dmax(acc[5], fabs(qv));
+                acc[6] = dmax(acc[6], fabs(Aty));
+                acc[7] = dmax(acc[7], fabs(Px));
+            });
+            info.pri_res = ra[0];
+            info.dua_res = cinv * va[0];
+            if (can_check || iter == c.max_iter) {
+                double eps_pri = c.eps_abs + c.eps_rel * dmax(ra[1], ra[2]);
+                double eps_dua = c.eps_abs + c.eps_rel * cinv * dmax(va[1], dmax(va[2], va[3]));
+                if (info.pri_res < eps_pri && info.dua_res < eps_dua) { info.status = DEKF_SOLVE_OK; done = true; }
+            }
+            if (!done && adapt_now) {
+                double pr = ra[3] / (dmax(ra[4], ra[5]) + 1e-10);
+                double du = va[4] / (dmax(va[5], dmax(va[6], va[7])) + 1e-10);
+                double rho_new = dmin(dmax(rho * sqrt(pr / (du + 1e-10)), RHO_MIN), RHO_MAX);
+                if (rho_new > rho * c.adaptive_rho_tolerance || rho_new < rho / c.adaptive_rho_tolerance) {
+                    rho = rho_new;
+                    info.rho_updates++;
+                    DEKF_SYNC();
+                    solve_bounds_rho(q, rho, false);
+                    ok = solve_factor(q);
+                }
+            }
+        }
+    }
+    info.iters = iter;
+    info.rho = rho;
+    // store_solution + update() tail: x_T = D x ; v_b = R (x_T[3:6] + gyro x p_imu_2_opti)
+    const double* rT = q.rec(K - 1);
+    double xT[9];
+    bool finite = ok;
+    for (int j = 0; j < 9; ++j) {
+        xT[j] = q.D[ix.x(K - 1, j)] * x[ix.x(K - 1, j)];
+        if (!(fabs(xT[j]) <= 1e300)) finite = false;
+    }
+    if (!finite) info.status = DEKF_SOLVE_NUMERIC;
+    if (DEKF_LANE() == 0) {
+        const double p_opti[3] = {0.016041, 0.089061, 0.0579875};
+        double wxp[3], t[3], vb[3];
+        cross3(rT + Rec::GY, p_opti, wxp);
+        for (int a = 0; a < 3; ++a) t[a] = xT[3 + a] + wxp[a];
+        mv3(rT + Rec::R, t, vb);
+        for (int j = 0; j < 9; ++j) s.x_mhe[9 * (size_t)b + j] = xT[j];
+        for (int a = 0; a < 3; ++a) s.v_b[3 * (size_t)b + a] = vb[a];
+        s.status[b] = info.status;
+        s.iters[b] = info.iters;
+        s.rho_updates[b] = info.rho_updates;
+        s.pri_res[b] = info.pri_res;
+        s.dua_res[b] = info.dua_res;
+    }
+    DEKF_SYNC();
+    return info;
+}
+
+}  // namespace dekf

@@ -1,0 +1,108 @@
+"""ctypes access to tests/hostsim/libhostsim.so — the lane-sequential CPU build of the device
+cores.  TEST INFRASTRUCTURE ONLY (see tests/hostsim/hostsim.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from decentralized_ekf_mhe_amd.params import DekfParams
+
+HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hostsim")
+LIB = os.path.join(HERE, "libhostsim.so")
+CSRC = os.path.join(os.path.dirname(HERE), "..", "decentralized_ekf_mhe_amd", "csrc")
+_dp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+
+
+def build(force=False, sanitize=False):
+    srcs = [os.path.join(HERE, "hostsim.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    out = LIB if not sanitize else LIB.replace(".so", "_asan.so")
+    stale = (not os.path.exists(out)) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs)
+    if force or stale:
+        flags = ["-O2"] if not sanitize else ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"]
+        subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared", "-DDEKF_HOSTSIM", "-w"] + flags +
+                              ["-o", out, os.path.join(HERE, "hostsim.cpp")])
+    return out
+
+
+def _p(a):
+    if a is None:
+        return None
+    assert a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(_dp if a.dtype == np.float64 else _ip)
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        L = C.CDLL(build())
+        L.hs_create.restype = C.c_void_p
+        L.hs_create.argtypes = [C.POINTER(DekfParams), C.c_int]
+        vp = C.c_void_p
+        L.hs_destroy.argtypes = [vp]
+        L.hs_push_imu.argtypes = [vp, _dp, _dp, _dp]
+        L.hs_push_leg.argtypes = [vp, _dp, _dp, _dp, _dp]
+        L.hs_push_vo.argtypes = [vp, _ip, _dp, _dp, _dp, _dp, _dp]
+        L.hs_push_quat.argtypes = [vp, _dp]
+        L.hs_ekf_step.argtypes = [vp]
+        L.hs_initialize.argtypes = [vp]
+        L.hs_update.argtypes = [vp, C.c_int]
+        L.hs_get.argtypes = [vp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
+        L.hs_get_ekf_cov.argtypes = [vp, _dp]
+        L.hs_get_arrival.argtypes = [vp, _dp, _dp]
+        L.hs_get_scaling.argtypes = [vp, C.c_int, C.c_int, _dp, _dp]
+        _lib = L
+    return _lib
+
+
+class HostSim:
+    def __init__(self, params, batch):
+        self.p, self.B = params, batch
+        self.h = lib().hs_create(C.byref(params), batch)
+        assert self.h, "hs_create rejected the parameters"
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().hs_destroy(self.h)
+            self.h = None
+
+    def feed(self, s, k):
+        L = lib()
+        L.hs_push_imu(self.h, _p(s["imu_t"][k]), _p(s["accel"][k]), _p(s["gyro"][k]))
+        L.hs_push_leg(self.h, _p(s["p_foot"][k]), _p(s["J"][k]), _p(s["qdot"][k]), _p(s["contact"][k]))
+        if s["vo_mask"][k].any():
+            L.hs_push_vo(self.h, _p(s["vo_mask"][k]), _p(s["vo_t_pre"][k]), _p(s["vo_t_now"][k]), _p(s["vo_dp"][k]),
+                         _p(s["vo_t_pose"][k]), _p(s["vo_q"][k]))
+
+    def step(self, T):
+        L = lib()
+        L.hs_ekf_step(self.h)
+        if T == 0:
+            L.hs_initialize(self.h)
+        else:
+            L.hs_update(self.h, T)
+
+    def get(self):
+        B = self.B
+        x, vb, q, pv = np.zeros((B, 9)), np.zeros((B, 3)), np.zeros((B, 4)), np.zeros((B, 3))
+        st, it, ru = (np.zeros(B, np.int32) for _ in range(3))
+        lib().hs_get(self.h, _p(x), _p(vb), _p(q), _p(pv), _p(st), _p(it), _p(ru))
+        return dict(x=x, v_b=vb, quat=q, p_vo=pv, status=st, iters=it, rho_updates=ru)
+
+    def ekf_cov(self):
+        P = np.zeros((self.B, 4, 4))
+        lib().hs_get_ekf_cov(self.h, _p(P))
+        return P
+
+    def arrival(self):
+        M, n = np.zeros((self.B, 9, 9)), np.zeros((self.B, 9))
+        lib().hs_get_arrival(self.h, _p(M), _p(n))
+        return M, n
+
+    def scaling(self, n, m):
+        D, E = np.zeros(n), np.zeros(m)
+        lib().hs_get_scaling(self.h, n, m, _p(D), _p(E))
+        return D, E
