@@ -1,0 +1,161 @@
+#!/usr/bin/env python3
+"""bench.py — estimator-steps/s of the EKF + 20-step-MHE hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one estimator-step for every robot instance of the batch: one EKF timer tick
+(predict + accel-correct, VO rewind when a pose is due) + one full MHE update(T) (term
+construction, VO bounds, marginalisation, Ruiz scaling, factorisation, OSQP-style ADMM to
+eps 1e-6, extraction) — SURVEY.md §8(d).  Workload at N=1: BASELINE.json configs[1]
+"Go1, batch=4096 synthetic IMU+encoder+vision streams, 20-step MHE, 1xMI355X".  Instances are
+independent, so N GPUs run N shards of 4096 (weak scaling) and exchange only the fused
+base-velocity estimates (one RCCL all-gather per step).  Sensor logs are synthetic
+(decentralized_ekf_mhe_amd/streams.py) and resident in HBM before the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+# SURVEY.md §8(d) contract figure: algorithmic bytes per estimator-step, Go1, N = 20
+B_ALG_GO1 = 5736
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def cpu_baseline(params, steps, seed_first):
+    """the oracle (CPU restatement of the reference algorithm) timed on this host's cores"""
+    import oracle_lib
+    from decentralized_ekf_mhe_amd.streams import make_streams
+    cores = os.cpu_count() or 1
+    inst = 2 * cores
+    s = make_streams(params, inst, steps, first_instance=seed_first)
+    _, _, _, secs1 = oracle_lib.run_streams(params, {k: (np.ascontiguousarray(v[:, :2]) if isinstance(v, np.ndarray) else v)
+                                                     for k, v in s.items()}, nthreads=1)
+    _, _, _, secs = oracle_lib.run_streams(params, s, nthreads=cores)
+    return {"value": inst * steps / secs, "unit": "estimator-steps/s", "cores": cores, "kind": "port",
+            "single_thread_value": 2 * steps / secs1,
+            "sample": f"{inst} Go1 instances x {steps} steps (T=0..{steps - 1}, window fill included) of the same synthetic "
+                      f"logs, oracle/liboracle.so (fp64 restatement of Eigen+OSQP path), {cores} threads; "
+                      f"single_thread_value = 2 instances on 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-allgather", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from decentralized_ekf_mhe_amd import go1_params
+    from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, new_unique_id, streams_to_device
+    from decentralized_ekf_mhe_amd.streams import make_streams
+
+    p = go1_params()
+    p.ekf_rate = p.rate  # one EKF tick per estimator-step, so its dt is the step
+    B, W, K = args.batch, args.warmup, args.steps
+    assert W >= p.N + 1, "warm-up must fill the window (steady state starts at T = N)"
+
+    t_gen = time.time()
+    s = make_streams(p, B, W + K, first_instance=rank * B)
+    sd = streams_to_device(s, device=f"cuda:{local_rank}")
+    t_gen = time.time() - t_gen
+
+    est = BatchedEstimator(p, B, device=local_rank)
+    vb_all = None
+    if world > 1 and not args.no_allgather:
+        ids = [new_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        est.comm_init(world, rank, ids[0])
+        vb_all = torch.empty((world, B, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
+
+    def run(k0, k1):
+        for k in range(k0, k1):
+            est.push_stream_step(sd, k)
+            est.step(k)
+            if vb_all is not None:
+                est.allgather_vb(vb_all)
+
+    run(0, W)
+    est.sync()
+    est.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(W, W + K)
+    est.sync()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tim = est.timing_read()
+    est.timing_enable(False)
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    out = est.get()
+    info = est.solver_info()
+    solved = float((out["status"] == 1).mean())
+    v_err = float(np.abs(out["x"][:, 3:6] - s["gt_v_s"][W + K - 1]).max())
+
+    if rank == 0:
+        value = world * B * K / elapsed
+        solve_ms, solve_n = tim["solve"]
+        avg_solve_s = solve_ms / max(solve_n, 1) * 1e-3
+        achieved = B_ALG_GO1 * B / avg_solve_s / 1e9
+        line = {
+            "metric": "estimator-steps/sec (EKF+MHE, 20-step window)",
+            "value": value, "unit": "estimator-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Go1, batch=4096 per GPU synthetic IMU+encoder+vision streams, 20-step MHE "
+                                   "(BASELINE.json configs[1])",
+                       "robot": "go1", "legs": 4, "N": int(p.N), "batch_per_gpu": B, "global_batch": world * B,
+                       "eps": 1e-6, "parallelism": f"instances sharded x{world}, RCCL all-gather of v_b per step"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "k_mhe_solve", "avg_launch_ms": avg_solve_s * 1e3, "launches": solve_n,
+                         "alg_bytes_per_step": B_ALG_GO1, "units_per_launch": B},
+            "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items()},
+            "solver": {"mean_iters": float(info["iters"].mean()), "max_iters": int(info["iters"].max()),
+                       "solved_frac": solved, "max_abs_v_err_vs_truth": v_err},
+            "stream_gen_s": t_gen,
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(p, min(W + K, 150), seed_first=0)
+        print(json.dumps(line))
+    est.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,8 +49,8 @@ struct Rec {
     // R_sb (9) | a_s (3) | gyro (3) | Qd 6x6 sym packed (21) | Qc 3x3 sym packed (6) |
     // vo flag (1) | vo bound (3) | bm (nm) | Qm L x sym packed (6L)
     static constexpr int R = 0, AS = 9, GY = 12, QD = 15, QC = 36, VOF = 42, VOB = 43, BM = 46;
-    DEKF_FN static int qm(int nm) { return BM + nm; }
-    DEKF_FN static int len(int L) { return BM + 3 * L + 6 * L; }
+    DEKF_HD static int qm(int nm) { return BM + nm; }
+    DEKF_HD static int len(int L) { return BM + 3 * L + 6 * L; }
 };
 
 // packed symmetric index, i <= j, n x n
@@ -76,7 +76,7 @@ struct Gws {
     // Wm (K*6L) | Wd (K*24) | Wc (K*6) | PA (K*81) | Sinv (K*81) | Wk (K*81)
     int n_pad, m_pad, K;
     int D, E, lo, hi, rho, Sv, Sw, Sc, Wm, Wd, Wc, PA, Sinv, Wk, total;
-    DEKF_FN void init(int N, int L) {
+    DEKF_HD void init(int N, int L) {
         K = N;
         int nm = 3 * L;
         n_pad = N * (9 + nm + 12);

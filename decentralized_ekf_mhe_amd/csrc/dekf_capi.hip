@@ -1,0 +1,454 @@
+// dekf_capi.hip — implementation of the C ABI in include/dekf.h on top of the gfx950 kernels.
+// No CPU fallback: without a usable HIP device dekf_create fails with DEKF_ERR_NO_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/dekf.h"
+#include "cfg.h"
+#include "host_common.h"
+#include "kf_core.h"
+#include "mhe_assemble_core.h"
+#include "mhe_solve_core.h"
+
+using namespace dekf;
+
+extern "C" {
+__global__ void k_ekf_tick(DevCfg c, DevState s, int count);
+__global__ void k_mhe_initialize(DevCfg c, DevState s);
+__global__ void k_mhe_assemble(DevCfg c, DevState s, int T, int pushes);
+__global__ void k_mhe_solve(DevCfg c, DevState s, int kstart, int K, int gws_len);
+__global__ void k_kf_initialize(DevCfg c, DevState s);
+__global__ void k_kf_update(DevCfg c, DevState s, int pushes);
+__global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* t_pre, const double* t_now,
+                           const double* dp, const double* t_pose, const double* q_vo);
+__global__ void k_reset_state(DevCfg c, DevState s);
+__global__ void k_go1_leg_odometry(DevCfg c, DevState s, const double* jp, const double* jv, const double* force,
+                                   double thr, double pibx, double piby, double pibz);
+}
+
+namespace {
+thread_local std::string g_err;
+
+struct RcclApi;  // rccl_dyn.h
+}  // namespace
+#include "rccl_dyn.h"
+
+struct dekf_handle_s {
+    dekf_params prm;
+    DevCfg c;
+    DevState s;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<void*> blocks;
+    // staging for host-side pushes / gets
+    void* stage = nullptr;
+    size_t stage_bytes = 0;
+    int solve_grid = 0, gws_len = 0;
+    size_t lds_solve = 0, lds_asm = 0, lds_kf = 0;
+    int ekf_count = 0, pushes = 0, next_T = 0;
+    bool initialized = false;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DEKF_TIMING_CLASSES];
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    // RCCL
+    void* comm = nullptr;
+    int world = 1, rank = 0;
+};
+
+namespace {
+
+#define HIPCHK(expr)                                                                                       \
+    do {                                                                                                   \
+        hipError_t e_ = (expr);                                                                            \
+        if (e_ != hipSuccess) {                                                                            \
+            g_err = std::string(#expr) + ": " + hipGetErrorString(e_);                                     \
+            return DEKF_ERR_HIP;                                                                           \
+        }                                                                                                  \
+    } while (0)
+
+dekf_status fail(dekf_status st, const char* msg) {
+    g_err = msg;
+    return st;
+}
+
+dekf_status ensure_stage(dekf_handle h, size_t bytes) {
+    if (bytes <= h->stage_bytes) return DEKF_OK;
+    if (h->stage) HIPCHK(hipFree(h->stage));
+    h->stage = nullptr;
+    h->stage_bytes = 0;
+    HIPCHK(hipMalloc(&h->stage, bytes));
+    h->stage_bytes = bytes;
+    return DEKF_OK;
+}
+
+// dst (device) <- src (host or device), n bytes, on the handle's stream
+dekf_status put(dekf_handle h, void* dst, const void* src, size_t n, dekf_mem where) {
+    if (!src) return fail(DEKF_ERR_INVALID, "null input pointer");
+    HIPCHK(hipMemcpyAsync(dst, src, n, where == DEKF_HOST ? hipMemcpyHostToDevice : hipMemcpyDeviceToDevice, h->stream));
+    return DEKF_OK;
+}
+dekf_status fetch(dekf_handle h, void* dst, const void* src, size_t n, dekf_mem where) {
+    if (!dst) return DEKF_OK;
+    HIPCHK(hipMemcpyAsync(dst, src, n, where == DEKF_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice, h->stream));
+    return DEKF_OK;
+}
+
+struct Timed {  // brackets one launch with events when timing is on
+    dekf_handle h;
+    int cls;
+    hipEvent_t a = nullptr, b = nullptr;
+    Timed(dekf_handle h_, int cls_) : h(h_), cls(cls_) {
+        if (!h->timing) return;
+        if (!h->ev_pool.empty()) { a = h->ev_pool.back().first; b = h->ev_pool.back().second; h->ev_pool.pop_back(); }
+        else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        hipEventRecord(a, h->stream);
+    }
+    ~Timed() {
+        if (!a) return;
+        hipEventRecord(b, h->stream);
+        h->ev[cls].push_back({a, b});
+    }
+};
+
+}  // namespace
+
+extern "C" {
+
+void dekf_default_params(dekf_params* p) { default_params(p); }
+int dekf_abi_version(void) { return DEKF_ABI_VERSION; }
+const char* dekf_last_error(void) { return g_err.c_str(); }
+
+dekf_status dekf_create(const dekf_params* p, int batch, int device, void* stream, dekf_handle* out) {
+    if (!p || !out) return fail(DEKF_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+        return fail(DEKF_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (device < 0 || device >= ndev) return fail(DEKF_ERR_INVALID, "device ordinal out of range");
+    DevCfg c;
+    if (const char* msg = fill_cfg(*p, batch, c)) return fail(DEKF_ERR_INVALID, msg);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        g_err = std::string("device is ") + prop.gcnArchName + ", this build targets gfx950 only";
+        return DEKF_ERR_NO_DEVICE;
+    }
+    dekf_handle h = new dekf_handle_s();
+    h->prm = *p;
+    h->c = c;
+    h->device = device;
+    if (stream) h->stream = (hipStream_t)stream;
+    else {
+        if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete h;
+            return fail(DEKF_ERR_HIP, "hipStreamCreate failed");
+        }
+        h->own_stream = true;
+    }
+    h->lds_solve = (size_t)SolveLds::len(c.N, c.L) * sizeof(double);
+    h->lds_asm = (size_t)AsmScratch::len(c.L) * sizeof(double);
+    h->lds_kf = (size_t)KfScratch::len(c.L) * sizeof(double);
+    if (h->lds_solve > 160 * 1024) {
+        delete h;
+        return fail(DEKF_ERR_INVALID, "window too large: ADMM iterates exceed the 160 KiB LDS of one CU");
+    }
+    if (h->lds_solve > 64 * 1024)
+        hipFuncSetAttribute((const void*)k_mhe_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
+    int per_cu = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_mhe_solve, 64, h->lds_solve) != hipSuccess || per_cu < 1)
+        per_cu = 1;
+    long slots = (long)per_cu * prop.multiProcessorCount;
+    h->solve_grid = (int)(slots < batch ? slots : batch);
+    Gws g;
+    g.init(c.N, c.L);
+    h->gws_len = g.total;
+    bool ok = true;
+    alloc_state(h->c, h->s, h->solve_grid, [&](size_t bytes) -> void* {
+        void* q = nullptr;
+        if (!ok) return nullptr;
+        if (hipMalloc(&q, bytes ? bytes : 8) != hipSuccess) { ok = false; return nullptr; }
+        if (hipMemsetAsync(q, 0, bytes ? bytes : 8, h->stream) != hipSuccess) ok = false;
+        h->blocks.push_back(q);
+        return q;
+    });
+    if (!ok) {
+        dekf_destroy(h);
+        return fail(DEKF_ERR_HIP, "hipMalloc failed while allocating the estimator state");
+    }
+    *out = h;
+    return dekf_reset(h);
+}
+
+dekf_status dekf_destroy(dekf_handle h) {
+    if (!h) return DEKF_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    if (h->comm) rccl_destroy(h->comm);
+    for (auto& v : h->ev) for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : h->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (void* q : h->blocks) hipFree(q);
+    if (h->stage) hipFree(h->stage);
+    if (h->own_stream) hipStreamDestroy(h->stream);
+    delete h;
+    return DEKF_OK;
+}
+
+dekf_status dekf_reset(dekf_handle h) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    HIPCHK(hipSetDevice(h->device));
+    k_reset_state<<<(h->c.B + 255) / 256, 256, 0, h->stream>>>(h->c, h->s);
+    HIPCHK(hipGetLastError());
+    h->ekf_count = 0;
+    h->pushes = 0;
+    h->next_T = 0;
+    h->initialized = false;
+    return DEKF_OK;
+}
+
+dekf_status dekf_sync(dekf_handle h) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DEKF_OK;
+}
+int dekf_batch(dekf_handle h) { return h ? h->c.B : 0; }
+void* dekf_stream(dekf_handle h) { return h ? (void*)h->stream : nullptr; }
+
+dekf_status dekf_push_imu(dekf_handle h, const double* imu_time, const double* accel_b, const double* gyro_b, dekf_mem where) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    size_t B = h->c.B;
+    dekf_status st;
+    if ((st = put(h, h->s.imu_t, imu_time, B * 8, where))) return st;
+    if ((st = put(h, h->s.accel, accel_b, 3 * B * 8, where))) return st;
+    return put(h, h->s.gyro, gyro_b, 3 * B * 8, where);
+}
+
+dekf_status dekf_push_leg(dekf_handle h, const double* p_imu_2_foot, const double* J_imu_2_foot, const double* joint_velocity,
+                          const double* contact, dekf_mem where) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    size_t B = h->c.B, L = h->c.L, nj = h->c.nj;
+    dekf_status st;
+    if ((st = put(h, h->s.p_foot, p_imu_2_foot, 3 * L * B * 8, where))) return st;
+    if ((st = put(h, h->s.J, J_imu_2_foot, 3 * L * nj * B * 8, where))) return st;
+    if ((st = put(h, h->s.qdot, joint_velocity, L * nj * B * 8, where))) return st;
+    return put(h, h->s.contact, contact, L * B * 8, where);
+}
+
+dekf_status dekf_push_go1_joints(dekf_handle h, const double* joint_position, const double* joint_velocity,
+                                 const double* foot_force, dekf_mem where) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    if (h->c.L != 4 || h->c.nj != 3) return fail(DEKF_ERR_INVALID, "dekf_push_go1_joints needs num_legs 4, joints_per_leg 3");
+    size_t B = h->c.B;
+    const double *jp = joint_position, *jv = joint_velocity, *ff = foot_force;
+    if (!jp || !jv || !ff) return fail(DEKF_ERR_INVALID, "null input pointer");
+    if (where == DEKF_HOST) {
+        dekf_status st = ensure_stage(h, 28 * B * 8);
+        if (st) return st;
+        double* d = (double*)h->stage;
+        HIPCHK(hipMemcpyAsync(d, jp, 12 * B * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d + 12 * B, jv, 12 * B * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d + 24 * B, ff, 4 * B * 8, hipMemcpyHostToDevice, h->stream));
+        jp = d; jv = d + 12 * B; ff = d + 24 * B;
+    }
+    k_go1_leg_odometry<<<(h->c.B + 63) / 64, 64, 0, h->stream>>>(h->c, h->s, jp, jv, ff, h->prm.contact_effort_threshold,
+                                                               h->prm.p_ib[0], h->prm.p_ib[1], h->prm.p_ib[2]);
+    HIPCHK(hipGetLastError());
+    return DEKF_OK;
+}
+
+dekf_status dekf_push_vo(dekf_handle h, const int* mask, const double* t_pre, const double* t_now, const double* dp_body,
+                         const double* t_pose, const double* q_vo, dekf_mem where) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    if (!mask || !t_pre || !t_now || !dp_body) return fail(DEKF_ERR_INVALID, "null input pointer");
+    if ((q_vo == nullptr) != (t_pose == nullptr)) return fail(DEKF_ERR_INVALID, "t_pose and q_vo must be given together");
+    size_t B = h->c.B;
+    if (where == DEKF_HOST) {
+        // mask(int) t_pre t_now dp(3) t_pose q(4): 10 doubles + 1 int per instance
+        dekf_status st = ensure_stage(h, (10 * 8 + 8) * B);
+        if (st) return st;
+        double* d = (double*)h->stage;
+        int* dm = (int*)(d + 10 * B);
+        HIPCHK(hipMemcpyAsync(dm, mask, B * 4, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d, t_pre, B * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d + B, t_now, B * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipMemcpyAsync(d + 2 * B, dp_body, 3 * B * 8, hipMemcpyHostToDevice, h->stream));
+        if (q_vo) {
+            HIPCHK(hipMemcpyAsync(d + 5 * B, t_pose, B * 8, hipMemcpyHostToDevice, h->stream));
+            HIPCHK(hipMemcpyAsync(d + 6 * B, q_vo, 4 * B * 8, hipMemcpyHostToDevice, h->stream));
+        }
+        mask = dm; t_pre = d; t_now = d + B; dp_body = d + 2 * B;
+        if (q_vo) { t_pose = d + 5 * B; q_vo = d + 6 * B; }
+    }
+    k_latch_vo<<<(h->c.B + 255) / 256, 256, 0, h->stream>>>(h->c, h->s, mask, t_pre, t_now, dp_body, t_pose, q_vo);
+    HIPCHK(hipGetLastError());
+    return DEKF_OK;
+}
+
+dekf_status dekf_push_quaternion(dekf_handle h, const double* quat, dekf_mem where) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    return put(h, h->s.quat, quat, 4 * (size_t)h->c.B * 8, where);
+}
+
+dekf_status dekf_ekf_step(dekf_handle h) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    {
+        Timed t(h, 0);
+        k_ekf_tick<<<(h->c.B + 63) / 64, 64, 0, h->stream>>>(h->c, h->s, h->ekf_count);
+    }
+    HIPCHK(hipGetLastError());
+    h->ekf_count++;
+    return DEKF_OK;
+}
+
+dekf_status dekf_initialize(dekf_handle h) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    if (h->initialized) return fail(DEKF_ERR_ORDER, "dekf_initialize called twice without dekf_reset");
+    if (h->c.est_type == 0) {
+        k_mhe_initialize<<<h->c.B, 64, h->lds_asm, h->stream>>>(h->c, h->s);
+        h->pushes = 1;
+    } else {
+        k_kf_initialize<<<h->c.B, 64, h->lds_kf, h->stream>>>(h->c, h->s);
+        h->pushes = 2;
+    }
+    HIPCHK(hipGetLastError());
+    h->initialized = true;
+    h->next_T = 1;
+    return DEKF_OK;
+}
+
+dekf_status dekf_update(dekf_handle h, int T) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    if (!h->initialized) return fail(DEKF_ERR_ORDER, "dekf_update before dekf_initialize");
+    if (T != h->next_T) return fail(DEKF_ERR_ORDER, "update(T) must be called with T = 1, 2, 3, ... (EstSub.cpp:58-75)");
+    if (h->c.est_type == 0) {
+        {
+            Timed t(h, 1);
+            k_mhe_assemble<<<h->c.B, 64, h->lds_asm, h->stream>>>(h->c, h->s, T, h->pushes);
+        }
+        HIPCHK(hipGetLastError());
+        int kstart = T - h->c.N + 1 > 0 ? T - h->c.N + 1 : 0;
+        {
+            Timed t(h, 2);
+            k_mhe_solve<<<h->solve_grid, 64, h->lds_solve, h->stream>>>(h->c, h->s, kstart, T - kstart + 1, h->gws_len);
+        }
+    } else {
+        Timed t(h, 1);
+        k_kf_update<<<h->c.B, 64, h->lds_kf, h->stream>>>(h->c, h->s, h->pushes);
+    }
+    HIPCHK(hipGetLastError());
+    h->pushes++;
+    h->next_T++;
+    return DEKF_OK;
+}
+
+dekf_status dekf_step(dekf_handle h, int T) {
+    dekf_status st = dekf_ekf_step(h);
+    if (st) return st;
+    return T == 0 ? dekf_initialize(h) : dekf_update(h, T);
+}
+
+dekf_status dekf_get(dekf_handle h, double* x_mhe, double* v_b, double* quat, double* p_vo, int* status, dekf_mem where) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    size_t B = h->c.B;
+    dekf_status st;
+    if ((st = fetch(h, x_mhe, h->s.x_mhe, 9 * B * 8, where))) return st;
+    if ((st = fetch(h, v_b, h->s.v_b, 3 * B * 8, where))) return st;
+    if ((st = fetch(h, quat, h->s.quat, 4 * B * 8, where))) return st;
+    if ((st = fetch(h, p_vo, h->s.p_vo, 3 * B * 8, where))) return st;
+    if ((st = fetch(h, status, h->s.status, B * 4, where))) return st;
+    if (where == DEKF_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+    return DEKF_OK;
+}
+
+dekf_status dekf_get_ekf_cov(dekf_handle h, double* cov, dekf_mem where) {
+    if (!h || !cov) return fail(DEKF_ERR_INVALID, "null argument");
+    // device layout is [16][B]; hand out [B][4][4]
+    size_t B = h->c.B;
+    std::vector<double> tmp(16 * B);
+    HIPCHK(hipMemcpyAsync(tmp.data(), h->s.ekf_P, 16 * B * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    std::vector<double> outv(16 * B);
+    for (size_t b = 0; b < B; ++b)
+        for (int i = 0; i < 16; ++i) outv[16 * b + i] = tmp[(size_t)i * B + b];
+    if (where == DEKF_HOST) std::memcpy(cov, outv.data(), 16 * B * 8);
+    else {
+        HIPCHK(hipMemcpyAsync(cov, outv.data(), 16 * B * 8, hipMemcpyHostToDevice, h->stream));
+        HIPCHK(hipStreamSynchronize(h->stream));
+    }
+    return DEKF_OK;
+}
+
+dekf_status dekf_get_solver_info(dekf_handle h, int* iters, int* rho_updates, double* pri_res, double* dua_res, dekf_mem where) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    size_t B = h->c.B;
+    dekf_status st;
+    if ((st = fetch(h, iters, h->s.iters, B * 4, where))) return st;
+    if ((st = fetch(h, rho_updates, h->s.rho_updates, B * 4, where))) return st;
+    if ((st = fetch(h, pri_res, h->s.pri_res, B * 8, where))) return st;
+    if ((st = fetch(h, dua_res, h->s.dua_res, B * 8, where))) return st;
+    if (where == DEKF_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+    return DEKF_OK;
+}
+
+dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where) {
+    if (!h || !cov) return fail(DEKF_ERR_INVALID, "null argument");
+    dekf_status st = fetch(h, cov, h->s.kf_C, 81 * (size_t)h->c.B * 8, where);
+    if (st) return st;
+    if (where == DEKF_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+    return DEKF_OK;
+}
+
+dekf_status dekf_timing_enable(dekf_handle h, int on) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    h->timing = on != 0;
+    return DEKF_OK;
+}
+dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches) {
+    if (!h || !ms_sum || !launches) return fail(DEKF_ERR_INVALID, "null argument");
+    HIPCHK(hipStreamSynchronize(h->stream));
+    for (int c = 0; c < DEKF_TIMING_CLASSES; ++c) {
+        double sum = 0.0;
+        for (auto& pr : h->ev[c]) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, pr.first, pr.second));
+            sum += ms;
+            h->ev_pool.push_back(pr);
+        }
+        ms_sum[c] = sum;
+        launches[c] = (int)h->ev[c].size();
+        h->ev[c].clear();
+    }
+    return DEKF_OK;
+}
+
+// ---------------------------------------------------------------- RCCL all-gather
+dekf_status dekf_comm_unique_id(void* id_out) {
+    if (!id_out) return fail(DEKF_ERR_INVALID, "null argument");
+    const char* e = rccl_unique_id(id_out);
+    if (e) return fail(DEKF_ERR_COMM, e);
+    return DEKF_OK;
+}
+dekf_status dekf_comm_init(dekf_handle h, int world, int rank, const void* id) {
+    if (!h || !id || world < 1 || rank < 0 || rank >= world) return fail(DEKF_ERR_INVALID, "bad communicator arguments");
+    HIPCHK(hipSetDevice(h->device));
+    const char* e = rccl_init_rank(&h->comm, world, rank, id);
+    if (e) return fail(DEKF_ERR_COMM, e);
+    h->world = world;
+    h->rank = rank;
+    return DEKF_OK;
+}
+dekf_status dekf_allgather_vb(dekf_handle h, double* v_b_all_dev) {
+    if (!h || !v_b_all_dev) return fail(DEKF_ERR_INVALID, "null argument");
+    if (!h->comm) return fail(DEKF_ERR_ORDER, "dekf_comm_init has not been called");
+    const char* e = rccl_allgather_f64(h->comm, h->s.v_b, v_b_all_dev, 3 * (size_t)h->c.B, h->stream);
+    if (e) return fail(DEKF_ERR_COMM, e);
+    return DEKF_OK;
+}
+
+}  // extern "C"

@@ -11,6 +11,7 @@
 
 #include "cfg.h"
 #include "ekf_core.h"
+#include "go1_kin.h"
 #include "kf_core.h"
 #include "mhe_assemble_core.h"
 #include "mhe_solve_core.h"
@@ -64,6 +65,15 @@ __global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* 
         s.ekf_vo_t[b] = t_pose[b];
         for (int i = 0; i < 4; ++i) s.ekf_vo_q[4 * (size_t)b + i] = q_vo[4 * (size_t)b + i];
     }
+}
+
+__global__ void __launch_bounds__(64) k_go1_leg_odometry(DevCfg c, DevState s, const double* jp, const double* jv,
+                                                         const double* force, double thr, double pibx, double piby,
+                                                         double pibz) {
+    int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= c.B) return;
+    const double p_ib[3] = {pibx, piby, pibz};
+    go1_leg_odometry(s, b, jp, jv, force, thr, p_ib);
 }
 
 __global__ void k_reset_state(DevCfg c, DevState s) {

@@ -10,7 +10,7 @@
 namespace dekf {
 
 struct KfScratch {
-    DEKF_FN static int len(int L) {
+    DEKF_HD static int len(int L) {
         int nm = 3 * L;
         return 81 * 3 + nm * nm * 2 + nm + 9 * nm * 2 + 32;
     }
@@ -95,7 +95,8 @@ DEKF_FN void kf_correct(const DevCfg& c, const DevState& s, int b, const double*
     wfor(90, [&](int e) { if (e < 81) C[e] = Cn[e]; else x[e - 81] = xn[e - 81]; });
 }
 
-DEKF_FN void kf_output(const DevCfg& c, const DevState& s, int b, const double* r) {
+// v_KF_b_ is only written by update(), not by initialize() (DecentralEst.cpp:189-196)
+DEKF_FN void kf_output(const DevCfg& c, const DevState& s, int b, const double* r, bool write_vb) {
     if (DEKF_LANE() == 0) {
         const double* x = s.kf_x + 9 * (size_t)b;
         const double p_opti[3] = {0.016041, 0.089061, 0.0579875};
@@ -104,21 +105,22 @@ DEKF_FN void kf_output(const DevCfg& c, const DevState& s, int b, const double* 
         for (int a = 0; a < 3; ++a) t[a] = x[3 + a] + wxp[a];
         mv3(r + Rec::R, t, vb);
         for (int j = 0; j < 9; ++j) s.x_mhe[9 * (size_t)b + j] = x[j];
-        for (int a = 0; a < 3; ++a) s.v_b[3 * (size_t)b + a] = vb[a];
+        if (write_vb)
+            for (int a = 0; a < 3; ++a) s.v_b[3 * (size_t)b + a] = vb[a];
         s.status[b] = DEKF_SOLVE_NONE;
     }
     DEKF_SYNC();
 }
 
 // UpdateKF: predict with stack.back(), GetMeasurement(0), correct.  `pushes` samples so far.
-DEKF_FN void kf_update(const DevCfg& c, const DevState& s, int b, int pushes, double* sm) {
+DEKF_FN void kf_update(const DevCfg& c, const DevState& s, int b, int pushes, double* sm, bool write_vb = true) {
     const double* rprev = s.rec + ((size_t)b * c.wcap + ((pushes - 1) % c.wcap)) * c.rec;
     kf_predict(c, s, b, rprev, sm);
     get_measurement(c, s, b, 0, pushes, sm);
     write_measurement_record(c, s, b, pushes, false);
     const double* r = s.rec + ((size_t)b * c.wcap + (pushes % c.wcap)) * c.rec;
     kf_correct(c, s, b, r, sm);
-    kf_output(c, s, b, r);
+    kf_output(c, s, b, r, write_vb);
 }
 
 // InitializeKF + UpdateKF, as DecentralizedEstimation::initialize does for est_type 1
@@ -133,7 +135,7 @@ DEKF_FN void kf_initialize(const DevCfg& c, const DevState& s, int b, double* sm
     });
     const double* r0 = s.rec + ((size_t)b * c.wcap + 0) * c.rec;
     kf_correct(c, s, b, r0, sm);
-    kf_update(c, s, b, 1, sm);
+    kf_update(c, s, b, 1, sm, false);
 }
 
 }  // namespace dekf

@@ -16,7 +16,7 @@ namespace dekf {
 
 struct AsmScratch {
     // LDS doubles needed by assemble_instance for (L): see assemble_scratch_len()
-    DEKF_FN static int len(int L) {
+    DEKF_HD static int len(int L) {
         int dim = 12 + 3 * L;
         return 81 /*Minv*/ + 12 * 9 /*Am*/ + 12 * 9 /*AmMinv*/ + dim * dim /*S*/ + dim * dim + dim /*winverse*/ +
                dim /*u*/ + dim /*Yu*/ + 81 /*tmp9*/ + 16;

@@ -30,7 +30,7 @@ namespace dekf {
 
 struct SolveLds {
     double *x, *z, *y, *xt, *zt, *at, *tmp;  // tmp: 192 doubles
-    DEKF_FN static int len(int N, int L) {
+    DEKF_HD static int len(int N, int L) {
         int nm = 3 * L;
         int n_pad = N * (9 + nm + 12), m_pad = N * (nm + 12);
         return 2 * n_pad + 4 * m_pad + 192;

@@ -19,12 +19,14 @@
 #include <hip/hip_runtime.h>
 #define DEKF_DEVICE_BUILD 1
 #define DEKF_FN __device__ __forceinline__
+#define DEKF_HD __host__ __device__ __forceinline__
 #define DEKF_LANE() ((int)(threadIdx.x & 63))
 // block == one wavefront, so the workgroup barrier is a wave barrier + LDS/VMEM drain
 #define DEKF_SYNC() __syncthreads()
 #else
 #define DEKF_DEVICE_BUILD 0
 #define DEKF_FN inline
+#define DEKF_HD inline
 #define DEKF_LANE() 0
 #define DEKF_SYNC() ((void)0)
 #endif

@@ -188,6 +188,15 @@ dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where);
 #define DEKF_SOLVE_MAX_ITER 2   /* OSQP_MAX_ITER_REACHED; iterate still returned, as osqp-eigen does */
 #define DEKF_SOLVE_NUMERIC -1   /* non-finite value or zero pivot */
 
+/* ---- measurement (the reference's tic/toc helpers, DecentralEst.cpp:1031-1044) ------- */
+/* When enabled, every kernel launch of the hot path is bracketed by HIP events on the
+ * handle's stream.  dekf_timing_read synchronises and returns, per kernel class
+ * (0 ekf tick, 1 MHE assemble/marginalise [or KF update], 2 MHE ADMM solve), the summed
+ * device milliseconds and the number of launches since the last read. */
+#define DEKF_TIMING_CLASSES 3
+dekf_status dekf_timing_enable(dekf_handle h, int on);
+dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches);
+
 /* ---- multi-GPU (new: the reference is single-robot) ------------------------------ */
 /* All-gather of the fused base velocity over RCCL: every rank contributes its
  * v_b[B][3] and receives v_b_all[world][B][3] (device pointer). The communicator is
