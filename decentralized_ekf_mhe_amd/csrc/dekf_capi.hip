@@ -20,7 +20,9 @@ extern "C" {
 __global__ void k_ekf_tick(DevCfg c, DevState s, int count);
 __global__ void k_mhe_initialize(DevCfg c, DevState s);
 __global__ void k_mhe_assemble(DevCfg c, DevState s, int T, int pushes);
-__global__ void k_mhe_solve(DevCfg c, DevState s, int kstart, int K, int gws_len);
+__global__ void k_mhe_solve_ll(DevCfg c, DevState s, int kstart, int K, int gws_len);
+__global__ void k_mhe_solve_lg(DevCfg c, DevState s, int kstart, int K, int gws_len);
+__global__ void k_mhe_solve_gg(DevCfg c, DevState s, int kstart, int K, int gws_len);
 __global__ void k_kf_initialize(DevCfg c, DevState s);
 __global__ void k_kf_update(DevCfg c, DevState s, int pushes);
 __global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* t_pre, const double* t_now,
@@ -49,6 +51,7 @@ struct dekf_handle_s {
     void* stage = nullptr;
     size_t stage_bytes = 0;
     int solve_grid = 0, gws_len = 0;
+    void (*solve_kernel)(DevCfg, DevState, int, int, int) = nullptr;
     size_t lds_solve = 0, lds_asm = 0, lds_kf = 0;
     int ekf_count = 0, pushes = 0, next_T = 0;
     bool initialized = false;
@@ -152,7 +155,10 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
         }
         h->own_stream = true;
     }
-    h->lds_solve = (size_t)SolveLds::len(c.N, c.L) * sizeof(double);
+    SolveLayout lay;
+    lay.init(c.N, c.L);
+    h->lds_solve = lay.lds_bytes();
+    h->solve_kernel = lay.pa_in_lds() ? k_mhe_solve_ll : (lay.factor_in_lds() ? k_mhe_solve_lg : k_mhe_solve_gg);
     h->lds_asm = (size_t)AsmScratch::len(c.L) * sizeof(double);
     h->lds_kf = (size_t)KfScratch::len(c.L) * sizeof(double);
     if (h->lds_solve > 160 * 1024) {
@@ -160,9 +166,9 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
         return fail(DEKF_ERR_INVALID, "window too large: ADMM iterates exceed the 160 KiB LDS of one CU");
     }
     if (h->lds_solve > 64 * 1024)
-        hipFuncSetAttribute((const void*)k_mhe_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
+        hipFuncSetAttribute((const void*)h->solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
     int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_mhe_solve, 64, h->lds_solve) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h->solve_kernel, 64, h->lds_solve) != hipSuccess || per_cu < 1)
         per_cu = 1;
     long slots = (long)per_cu * prop.multiProcessorCount;
     h->solve_grid = (int)(slots < batch ? slots : batch);
@@ -335,7 +341,7 @@ dekf_status dekf_update(dekf_handle h, int T) {
         int kstart = T - h->c.N + 1 > 0 ? T - h->c.N + 1 : 0;
         {
             Timed t(h, 2);
-            k_mhe_solve<<<h->solve_grid, 64, h->lds_solve, h->stream>>>(h->c, h->s, kstart, T - kstart + 1, h->gws_len);
+            h->solve_kernel<<<h->solve_grid, 64, h->lds_solve, h->stream>>>(h->c, h->s, kstart, T - kstart + 1, h->gws_len);
         }
     } else {
         Timed t(h, 1);

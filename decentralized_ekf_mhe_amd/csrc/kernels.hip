@@ -2,7 +2,7 @@
 //   k_ekf_tick        one lane per instance              (ekf_core.h)
 //   k_mhe_initialize  one wavefront per instance         (mhe_assemble_core.h)
 //   k_mhe_assemble    one wavefront per instance         (mhe_assemble_core.h)
-//   k_mhe_solve       persistent one-wave workgroups, grid-stride over instances; each
+//   k_mhe_solve_*     persistent one-wave workgroups, grid-stride over instances; each
 //                     workgroup owns one scratch slab in HBM, so a slab is only ever touched
 //                     from one XCD (its L2 is the only one that caches it)  (mhe_solve_core.h)
 //   k_kf_*            KF alternative                      (kf_core.h)
@@ -36,11 +36,17 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
     assemble_update(c, s, blockIdx.x, T, pushes, lds);
 }
 
-__global__ void __launch_bounds__(64) k_mhe_solve(DevCfg c, DevState s, int kstart, int K, int gws_len) {
-    extern __shared__ double lds[];
-    double* gws = s.gws + (size_t)blockIdx.x * gws_len;
-    for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window(c, s, b, kstart, K, lds, gws);
-}
+// three placements of the factor (mhe_solve_core.h: SolveLayout): _ll all in LDS (Go1, N = 20),
+// _lg LDS factor with the factor-time temporary in HBM (fewer legs), _gg factor streamed from HBM
+#define DEKF_SOLVE_KERNEL(NAME, FL, PL)                                                                  \
+    __global__ void __launch_bounds__(64) NAME(DevCfg c, DevState s, int kstart, int K, int gws_len) {   \
+        extern __shared__ double lds[];                                                                  \
+        double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                              \
+        for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<FL, PL>(c, s, b, kstart, K, lds, gws); \
+    }
+DEKF_SOLVE_KERNEL(k_mhe_solve_ll, true, true)
+DEKF_SOLVE_KERNEL(k_mhe_solve_lg, true, false)
+DEKF_SOLVE_KERNEL(k_mhe_solve_gg, false, false)
 
 __global__ void __launch_bounds__(64) k_kf_initialize(DevCfg c, DevState s) {
     extern __shared__ double lds[];

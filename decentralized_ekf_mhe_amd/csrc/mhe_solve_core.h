@@ -18,9 +18,11 @@
 // 9x9 blocks — a fixed-interval smoother — solved by block LDL': S_k^-1 and W_k = C_k S_k^-1
 // are the "banded KKT factor", refreshed whenever rho changes.
 //
-// Memory: ADMM iterates + right-hand sides live in LDS; scaling vectors, bounds, slack-block
-// inverses and the tridiagonal factor are streamed from a per-workgroup HBM scratch (L2 / MALL
-// resident); window records are read where they lie in HBM.
+// Memory (SolveMem): when it fits 2 workgroups per CU (Go1/Cassie at N = 20: <= 80 KiB) the
+// ADMM iterates, the scaling vectors, the bounds, the slack-block inverses, the block
+// tridiagonal factor and the rotations all live in LDS, so an ADMM iteration touches HBM only
+// at the termination checks (window records, every 25 iterations).  Longer windows (PogoX,
+// N = 100) keep the iterates in LDS and stream the factor from the workgroup's HBM scratch slab.
 #pragma once
 #include "cfg.h"
 #include "mhe_assemble_core.h"
@@ -28,18 +30,26 @@
 
 namespace dekf {
 
-struct SolveLds {
-    double *x, *z, *y, *xt, *zt, *at, *tmp;  // tmp: 192 doubles
-    DEKF_HD static int len(int N, int L) {
+constexpr int SOLVE_TMP = 176;  // 2 x 81 Gauss-Jordan ping-pong + slack
+
+// how many doubles of LDS a solve needs in each placement mode
+struct SolveLayout {
+    int n_pad, m_pad, K;
+    int vec;        // iterates: x z y xt zt at xs tmp
+    int resident;   // D E lo hi Sv Sw Sc Sinv Wk R
+    DEKF_HD void init(int N, int L) {
         int nm = 3 * L;
-        int n_pad = N * (9 + nm + 12), m_pad = N * (nm + 12);
-        return 2 * n_pad + 4 * m_pad + 192;
+        K = N;
+        n_pad = N * (9 + nm + 12);
+        m_pad = N * (nm + 12);
+        vec = 2 * n_pad + 4 * m_pad + 9 * N + SOLVE_TMP;
+        resident = n_pad + 3 * m_pad + N * (6 * L + 24 + 6) + N * (45 + 81) + 9 * N;
     }
-    DEKF_FN void carve(double* base, int N, int L) {
-        int nm = 3 * L;
-        int n_pad = N * (9 + nm + 12), m_pad = N * (nm + 12);
-        x = base; xt = x + n_pad; z = xt + n_pad; y = z + m_pad; zt = y + m_pad; at = zt + m_pad; tmp = at + m_pad;
-    }
+    // LDS-resident factor only if two workgroups still fit in one CU's 160 KiB
+    DEKF_HD bool factor_in_lds() const { return (size_t)(vec + resident) * 8 <= 80 * 1024; }
+    // the factor-time product P A_dyn can alias the (then dead) xt|zt|at vectors when they are big enough
+    DEKF_HD bool pa_in_lds() const { return factor_in_lds() && (n_pad + 2 * m_pad >= (K - 1) * 81); }
+    DEKF_HD size_t lds_bytes() const { return (size_t)(factor_in_lds() ? vec + resident : vec) * 8; }
 };
 
 struct SolveCtx {
@@ -47,13 +57,25 @@ struct SolveCtx {
     const DevState& s;
     int b, K, kstart, n, m;
     Idx ix;
-    SolveLds l;
-    double *D, *E, *lo, *hi, *rho, *Sv, *Sw, *Sc, *Wm, *Wd, *Wc, *PA, *Sinv, *Wk;
+    // LDS always
+    double *x, *z, *y, *xt, *zt, *at, *xs, *tmp;
+    // LDS or HBM scratch
+    double *D, *E, *lo, *hi, *Sv, *Sw, *Sc, *Sinv, *Wk, *R;
+    // factor-time temporaries
+    double *Wm, *Wd, *Wc, *PA;
     const double *Mp, *np;
-    double cc;  // cost scaling c
+    double cc;   // cost scaling c
+    double rho;  // current scalar rho
 
     DEKF_FN const double* rec(int k) const {
         return s.rec + ((size_t)b * c.wcap + ((kstart + k) % c.wcap)) * c.rec;
+    }
+    DEKF_FN double adyn(int k, int r, int j) const { return adyn_entry(R + 9 * k, c.dt, r, j); }
+    // per-row rho from the scaled bounds (OSQP set_rho_vec / osqp_update_rho)
+    DEKF_FN double rho_at(int r) const {
+        double lb = lo[r], ub = hi[r];
+        if (lb < -OSQP_INFTY * MIN_SCALING && ub > OSQP_INFTY * MIN_SCALING) return RHO_MIN;
+        return (ub - lb < RHO_TOL) ? RHO_EQ_OVER_RHO_INEQ * rho : rho;
     }
     // unscaled bound of row (k, kind, o): kind 0 Meas, 1 Dyn, 2 VO
     DEKF_FN void bounds(int k, int kind, int o, double& lb, double& ub) const {
@@ -89,9 +111,8 @@ struct SolveCtx {
         if (j >= 3 && j < 6)
             for (int leg = 0; leg < c.L; ++leg) { int r = ix.rm(k, 3 * leg + j - 3); acc += E[r] * vec[r]; }
         if (k < K - 1) {
-            const double* R = rec(k) + Rec::R;
             for (int rr = 0; rr < 9; ++rr) {
-                double a = adyn_entry(R, c.dt, rr, j);
+                double a = adyn(k, rr, j);
                 if (a != 0.0) { int r = ix.rd(k, rr); acc += E[r] * a * vec[r]; }
             }
             if (j < 3) { int r = ix.rv(k, j); acc += E[r] * vec[r]; }
@@ -103,30 +124,26 @@ struct SolveCtx {
         }
         return acc * dj;
     }
-    // (scaled A restricted to the x blocks) * xv, row (k, kind, o)
-    DEKF_FN double row_dot_x(int k, int kind, int o, const double* xv) const {
+    // (scaled A restricted to the x blocks) * xv, row (k, kind, o); xv(k, j) returns x_k[j]
+    template <class XF>
+    DEKF_FN double row_dot_x(int k, int kind, int o, XF xv) const {
         double acc;
         if (kind == 0) {
-            int i = ix.x(k, 3 + o % 3);
-            acc = D[i] * xv[i];
+            acc = D[ix.x(k, 3 + o % 3)] * xv(k, 3 + o % 3);
         } else if (kind == 1) {
-            const double* R = rec(k) + Rec::R;
             acc = 0.0;
             for (int j = 0; j < 9; ++j) {
-                double a = adyn_entry(R, c.dt, o, j);
-                if (a != 0.0) { int i = ix.x(k, j); acc += a * D[i] * xv[i]; }
+                double a = adyn(k, o, j);
+                if (a != 0.0) acc += a * D[ix.x(k, j)] * xv(k, j);
             }
-            int i2 = ix.x(k + 1, o);
-            acc -= D[i2] * xv[i2];
+            acc -= D[ix.x(k + 1, o)] * xv(k + 1, o);
         } else {
-            int i = ix.x(k, o), i2 = ix.x(k + 1, o);
-            acc = D[i] * xv[i] - D[i2] * xv[i2];
+            acc = D[ix.x(k, o)] * xv(k, o) - D[ix.x(k + 1, o)] * xv(k + 1, o);
         }
         int r = kind == 0 ? ix.rm(k, o) : (kind == 1 ? ix.rd(k, o) : ix.rv(k, o));
         return E[r] * acc;
     }
-    // unscaled P entry helpers -------------------------------------------------------
-    // (P_scaled x)_i for variable i, and the inf-norm of column i of P_scaled
+    // (P_scaled x)_i for variable i, or the inf-norm of column i of P_scaled (reads HBM records)
     DEKF_FN double p_apply(int i, const double* xv, bool norm_only) const {
         int k, kind, o;
         dec_var(i, k, kind, o);
@@ -138,7 +155,7 @@ struct SolveCtx {
             else acc += v * xv[i2];
         };
         if (kind == 0) {
-            if (k == 0 && kstart >= 0)
+            if (k == 0)
                 for (int t = 0; t < 9; ++t) term(o <= t ? Mp[9 * o + t] : Mp[9 * t + o], ix.x(0, t));
         } else if (kind == 1) {
             int leg = o / 3, a = o - 3 * leg;
@@ -165,8 +182,7 @@ struct SolveCtx {
         if (o >= 3 && o < 6)
             for (int leg = 0; leg < c.L; ++leg) acc = dmax(acc, E[ix.rm(k, 3 * leg + o - 3)]);
         if (k < K - 1) {
-            const double* R = rec(k) + Rec::R;
-            for (int rr = 0; rr < 9; ++rr) acc = dmax(acc, E[ix.rd(k, rr)] * fabs(adyn_entry(R, c.dt, rr, o)));
+            for (int rr = 0; rr < 9; ++rr) acc = dmax(acc, E[ix.rd(k, rr)] * fabs(adyn(k, rr, o)));
             if (o < 3) acc = dmax(acc, E[ix.rv(k, o)]);
         }
         if (k > 0) {
@@ -182,8 +198,7 @@ struct SolveCtx {
         double acc = D[row_slack(k, kind, o)];
         if (kind == 0) acc = dmax(acc, D[ix.x(k, 3 + o % 3)]);
         else if (kind == 1) {
-            const double* R = rec(k) + Rec::R;
-            for (int j = 0; j < 9; ++j) acc = dmax(acc, fabs(adyn_entry(R, c.dt, o, j)) * D[ix.x(k, j)]);
+            for (int j = 0; j < 9; ++j) acc = dmax(acc, fabs(adyn(k, o, j)) * D[ix.x(k, j)]);
             acc = dmax(acc, D[ix.x(k + 1, o)]);
         } else {
             acc = dmax(acc, dmax(D[ix.x(k, o)], D[ix.x(k + 1, o)]));
@@ -208,12 +223,12 @@ DEKF_FN void solve_scale(SolveCtx& q) {
         wfor(n + m, [&](int e) {
             if (e < n) {
                 double v = dmax(q.p_apply(e, nullptr, true), q.a_colnorm(e));
-                q.l.xt[e] = 1.0 / sqrt(limit_scaling(v));
+                q.xt[e] = 1.0 / sqrt(limit_scaling(v));
             } else {
-                q.l.zt[e - n] = 1.0 / sqrt(limit_scaling(q.a_rownorm(e - n)));
+                q.zt[e - n] = 1.0 / sqrt(limit_scaling(q.a_rownorm(e - n)));
             }
         });
-        wfor(n + m, [&](int e) { if (e < n) q.D[e] *= q.l.xt[e]; else q.E[e - n] *= q.l.zt[e - n]; });
+        wfor(n + m, [&](int e) { if (e < n) q.D[e] *= q.xt[e]; else q.E[e - n] *= q.zt[e - n]; });
         double psum = wred_sum(n, [&](int i) { return q.p_apply(i, nullptr, true); });
         double qn = 0.0;
         for (int j = 0; j < 9; ++j) qn = dmax(qn, fabs(q.cc * q.D[q.ix.x(0, j)] * g[j]));
@@ -223,27 +238,8 @@ DEKF_FN void solve_scale(SolveCtx& q) {
     }
 }
 
-// scaled bounds and per-row rho (OSQP set_rho_vec / osqp_update_rho)
-DEKF_FN void solve_bounds_rho(SolveCtx& q, double rho, bool bounds_too) {
-    wfor(q.m, [&](int r) {
-        int k, kind, o;
-        q.dec_row(r, k, kind, o);
-        double lb, ub;
-        if (bounds_too) {
-            q.bounds(k, kind, o, lb, ub);
-            lb *= q.E[r]; ub *= q.E[r];
-            q.lo[r] = lb; q.hi[r] = ub;
-        } else { lb = q.lo[r]; ub = q.hi[r]; }
-        double rv;
-        if (lb < -OSQP_INFTY * MIN_SCALING && ub > OSQP_INFTY * MIN_SCALING) rv = RHO_MIN;
-        else if (ub - lb < RHO_TOL) rv = RHO_EQ_OVER_RHO_INEQ * rho;
-        else rv = rho;
-        q.rho[r] = rv;
-    });
-}
-
 // numeric factorisation for the current rho: slack-block inverses, effective row weights,
-// block-tridiagonal LDL' (S_k^-1, W_k)
+// block-tridiagonal LDL' (S_k^-1 packed symmetric, W_k)
 DEKF_FN bool solve_factor(SolveCtx& q) {
     const DevCfg& c = q.c;
     const int K = q.K, L = c.L, nm = c.nm;
@@ -258,10 +254,8 @@ DEKF_FN bool solve_factor(SolveCtx& q) {
             double gv[3], rr[3], S6[6], Si[6];
             for (int a = 0; a < 3; ++a) {
                 int row = ix.rm(k, 3 * blk + a);
-                double beta = q.E[row] * q.D[ix.v(k, 3 * blk + a)];
-                rr[a] = q.rho[row];
-                gv[a] = rr[a] * beta;
-                S6[symidx(a, a, 3)] = 0.0;
+                rr[a] = q.rho_at(row);
+                gv[a] = rr[a] * q.E[row] * q.D[ix.v(k, 3 * blk + a)];
             }
             for (int a = 0; a < 3; ++a)
                 for (int d = a; d < 3; ++d)
@@ -275,25 +269,30 @@ DEKF_FN bool solve_factor(SolveCtx& q) {
         } else if (k < K - 1 && blk == L) {
             const double* q21 = r + Rec::QD;
             double S[36], gv[9], rr[9];
+#pragma unroll
             for (int a = 0; a < 9; ++a) {
                 int row = ix.rd(k, a);
-                double beta = q.E[row] * q.D[ix.w(k, a)];
-                rr[a] = q.rho[row];
-                gv[a] = rr[a] * beta;
+                rr[a] = q.rho_at(row);
+                gv[a] = rr[a] * q.E[row] * q.D[ix.w(k, a)];
             }
+#pragma unroll
             for (int a = 0; a < 6; ++a)
+#pragma unroll
                 for (int d = 0; d < 6; ++d)
                     S[6 * a + d] = cc * q.D[ix.w(k, a)] * symget(q21, a, d, 6) * q.D[ix.w(k, d)] +
                                    (a == d ? sigma + gv[a] * q.E[ix.rd(k, a)] * q.D[ix.w(k, a)] : 0.0);
-            inv_small<6>(S, 6);
+            inv_spd_unrolled<6>(S);
             double* sw = q.Sw + k * 24;
             double* wd = q.Wd + k * 24;
+#pragma unroll
             for (int a = 0; a < 6; ++a)
+#pragma unroll
                 for (int d = a; d < 6; ++d) {
                     double si = 0.5 * (S[6 * a + d] + S[6 * d + a]);
                     sw[symidx(a, d, 6)] = si;
                     wd[symidx(a, d, 6)] = (a == d ? rr[a] : 0.0) - gv[a] * si * gv[d];
                 }
+#pragma unroll
             for (int a = 6; a < 9; ++a) {
                 double dw = q.D[ix.w(k, a)];
                 double sdiag = cc * dw * c.Q_bias_dt2[a - 6] * dw + sigma + gv[a] * q.E[ix.rd(k, a)] * dw;
@@ -305,7 +304,7 @@ DEKF_FN bool solve_factor(SolveCtx& q) {
             double gv[3], rr[3], S6[6], Si[6];
             for (int a = 0; a < 3; ++a) {
                 int row = ix.rv(k, a);
-                rr[a] = q.rho[row];
+                rr[a] = q.rho_at(row);
                 gv[a] = rr[a] * q.E[row] * q.D[ix.c(k, a)];
             }
             for (int a = 0; a < 3; ++a)
@@ -328,41 +327,42 @@ DEKF_FN bool solve_factor(SolveCtx& q) {
     // 3b. PA_k = Wd_k * (E_D A_dyn D_x)
     wfor((K - 1) * 81, [&](int e) {
         int k = e / 81, p = e - 81 * k, i = p / 9, j = p - 9 * i;
-        const double* R = q.rec(k) + Rec::R;
         double acc = 0.0;
         for (int t = 0; t < 9; ++t) {
             double w = wd_at(k, i, t);
-            if (w != 0.0) acc += w * q.E[ix.rd(k, t)] * adyn_entry(R, c.dt, t, j);
+            if (w != 0.0) acc += w * q.E[ix.rd(k, t)] * q.adyn(k, t, j);
         }
         q.PA[e] = acc * q.D[ix.x(k, j)];
     });
-    // 3c. T_kk -> Sinv[k], C_k -> Wk[k]
-    wfor(K * 81 + (K - 1) * 81, [&](int e) {
-        if (e < K * 81) {
-            int k = e / 81, p = e - 81 * k, i = p / 9, j = p - 9 * i;
+    // 3c. T_kk (upper triangle, packed) -> Sinv[k], C_k -> Wk[k]
+    wfor(K * 45 + (K - 1) * 81, [&](int e) {
+        if (e < K * 45) {
+            int k = e / 45, p = e - 45 * k;
+            int i = 0;
+            while (p >= 9 - i) { p -= 9 - i; ++i; }
+            int j = i + p;
             double di = q.D[ix.x(k, i)], dj = q.D[ix.x(k, j)];
             double acc = (i == j) ? sigma : 0.0;
-            if (k == 0) acc += cc * di * (i <= j ? q.Mp[9 * i + j] : q.Mp[9 * j + i]) * dj;
-            if (i >= 3 && i < 6 && j >= 3 && j < 6)
+            if (k == 0) acc += cc * di * q.Mp[9 * i + j] * dj;
+            if (i >= 3 && j < 6)
                 for (int leg = 0; leg < L; ++leg)
                     acc += q.E[ix.rm(k, 3 * leg + i - 3)] * di * symget(q.Wm + (k * L + leg) * 6, i - 3, j - 3, 3) *
                            q.E[ix.rm(k, 3 * leg + j - 3)] * dj;
             if (k < K - 1) {
-                if (i < 3 && j < 3) acc += q.E[ix.rv(k, i)] * di * symget(q.Wc + k * 6, i, j, 3) * q.E[ix.rv(k, j)] * dj;
-                const double* R = q.rec(k) + Rec::R;
+                if (j < 3) acc += q.E[ix.rv(k, i)] * di * symget(q.Wc + k * 6, i, j, 3) * q.E[ix.rv(k, j)] * dj;
                 for (int t = 0; t < 9; ++t) {
-                    double a = adyn_entry(R, c.dt, t, i);
+                    double a = q.adyn(k, t, i);
                     if (a != 0.0) acc += q.E[ix.rd(k, t)] * a * di * q.PA[k * 81 + 9 * t + j];
                 }
             }
             if (k > 0) {
                 acc += q.E[ix.rd(k - 1, i)] * di * wd_at(k - 1, i, j) * q.E[ix.rd(k - 1, j)] * dj;
-                if (i < 3 && j < 3)
+                if (j < 3)
                     acc += q.E[ix.rv(k - 1, i)] * di * symget(q.Wc + (k - 1) * 6, i, j, 3) * q.E[ix.rv(k - 1, j)] * dj;
             }
             q.Sinv[e] = acc;
         } else {
-            int e2 = e - K * 81;
+            int e2 = e - K * 45;
             int k = e2 / 81, p = e2 - 81 * k, i = p / 9, j = p - 9 * i;
             double d1 = q.D[ix.x(k + 1, i)];
             double acc = -q.E[ix.rd(k, i)] * d1 * q.PA[k * 81 + p];
@@ -373,46 +373,63 @@ DEKF_FN bool solve_factor(SolveCtx& q) {
     });
     // C_k moves to PA[k]; W_k will be written to Wk[k]
     wfor((K - 1) * 81, [&](int e) { q.PA[e] = q.Wk[e]; });
-    // 3d. block LDL'
+    // 3d. block LDL': S_k = T_kk - W_{k-1} C_{k-1}'; S_k^-1 by Gauss-Jordan ping-pong; W_k = C_k S_k^-1
     bool ok = true;
-    double* scratch = q.l.tmp;  // 90 doubles
+    double* bufA = q.tmp;
+    double* bufB = q.tmp + 81;
     for (int k = 0; k < K; ++k) {
-        double* Sk = q.Sinv + k * 81;
-        if (k > 0) {
-            const double* Wp = q.Wk + (k - 1) * 81;
-            const double* Cp = q.PA + (k - 1) * 81;
+        const double* Tk = q.Sinv + k * 45;
+        const double* Wp = q.Wk + (k - 1) * 81;
+        const double* Cp = q.PA + (k - 1) * 81;
+        wfor(81, [&](int p) {
+            int i = p / 9, j = p - 9 * i;
+            int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
+            double acc = Tk[symidx(lo_, hi_, 9)];
+            if (k > 0) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int t = 0; t < 9; ++t) { s1 += Wp[9 * i + t] * Cp[9 * j + t]; s2 += Wp[9 * j + t] * Cp[9 * i + t]; }
+                acc -= 0.5 * (s1 + s2);
+            }
+            bufA[p] = acc;
+        });
+        double* src = bufA;
+        double* dst = bufB;
+        for (int pv = 0; pv < 9; ++pv) {
+            double piv = src[pv * 9 + pv];
+            if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) ok = false;
+            double d = 1.0 / piv;
             wfor(81, [&](int p) {
                 int i = p / 9, j = p - 9 * i;
-                double acc = 0.0;
-                for (int t = 0; t < 9; ++t) acc += Wp[9 * i + t] * Cp[9 * j + t];
-                Sk[p] -= acc;
+                double v;
+                if (i == pv) v = (j == pv) ? d : src[p] * d;
+                else if (j == pv) v = -src[p] * d;
+                else v = src[p] - src[i * 9 + pv] * src[pv * 9 + j] * d;
+                dst[p] = v;
             });
+            double* t = src; src = dst; dst = t;
         }
-        // symmetrise (round-off) then invert in place
-        wfor(81, [&](int p) {
-            int i = p / 9, j = p - 9 * i;
-            if (i < j) { double v = 0.5 * (Sk[9 * i + j] + Sk[9 * j + i]); scratch[100 + p] = v; }
-        });
-        wfor(81, [&](int p) {
-            int i = p / 9, j = p - 9 * i;
-            if (i < j) { Sk[9 * i + j] = scratch[100 + p]; Sk[9 * j + i] = scratch[100 + p]; }
-        });
-        ok = winverse(Sk, 9, scratch, false) && ok;
-        if (k < K - 1) {
-            const double* Ck = q.PA + k * 81;
-            double* Wk = q.Wk + k * 81;
-            wfor(81, [&](int p) {
-                int i = p / 9, j = p - 9 * i;
+        // src holds S_k^-1
+        double* Sk = q.Sinv + k * 45;
+        const double* Ck = q.PA + k * 81;
+        double* Wk = q.Wk + k * 81;
+        wfor(45 + (k < K - 1 ? 81 : 0), [&](int e) {
+            if (e < 45) {
+                int p = e, i = 0;
+                while (p >= 9 - i) { p -= 9 - i; ++i; }
+                int j = i + p;
+                Sk[e] = 0.5 * (src[9 * i + j] + src[9 * j + i]);
+            } else {
+                int p = e - 45, i = p / 9, j = p - 9 * i;
                 double acc = 0.0;
-                for (int t = 0; t < 9; ++t) acc += Ck[9 * i + t] * Sk[9 * t + j];
+                for (int t = 0; t < 9; ++t) acc += Ck[9 * i + t] * src[9 * t + j];
                 Wk[p] = acc;
-            });
-        }
+            }
+        });
     }
     return ok;
 }
 
-// apply a slack-block inverse: out[row of slack] = sum_s' Sinv_block[s][s'] * in(s')
+// apply a slack-block inverse: sum_s' Sinv_block[s][s'] * in(var s', row of s')
 template <class InF>
 DEKF_FN double slack_inv_apply(const SolveCtx& q, int k, int kind, int o, InF in) {
     const Idx& ix = q.ix;
@@ -436,66 +453,68 @@ DEKF_FN double slack_inv_apply(const SolveCtx& q, int k, int kind, int o, InF in
     }
 }
 
-// one linear solve: l.xt holds the right-hand side (n) on entry and xt on exit; l.at gets zt = A xt
+// One ADMM linear solve.  In: xt = right-hand side (n).  Out: xs = xt on the x blocks (K*9),
+// xt = xt on the slack entries, zt = A xt.
 DEKF_FN void solve_linear(SolveCtx& q) {
-    const int n = q.n, m = q.m, K = q.K;
+    const int m = q.m, K = q.K;
     const Idx& ix = q.ix;
-    double *xt = q.l.xt, *zt = q.l.zt, *at = q.l.at, *tmp = q.l.tmp;
-    // t = S^-1 rhs_s (stored at the slack's row), h = rho*beta*t
+    double *xt = q.xt, *zt = q.zt, *at = q.at, *xs = q.xs;
+    // t = S^-1 rhs_s (kept at the slack's row in zt), h = rho*beta*t (in at)
     wfor(m, [&](int r) {
         int k, kind, o;
         q.dec_row(r, k, kind, o);
-        zt[r] = slack_inv_apply(q, k, kind + 1, o, [&](int var, int) { return xt[var]; });
+        double t = slack_inv_apply(q, k, kind + 1, o, [&](int var, int) { return xt[var]; });
+        zt[r] = t;
+        at[r] = q.rho_at(r) * q.E[r] * q.D[q.row_slack(k, kind, o)] * t;
     });
-    wfor(m, [&](int r) {
-        int k, kind, o;
-        q.dec_row(r, k, kind, o);
-        at[r] = q.rho[r] * q.E[r] * q.D[q.row_slack(k, kind, o)] * zt[r];
-    });
+    // reduced right-hand side on the x blocks
     wfor(K * 9, [&](int e) {
         int k = e / 9, j = e - 9 * k;
-        xt[ix.x(k, j)] += q.gather_x(k, j, at);
+        xs[e] = xt[ix.x(k, j)] + q.gather_x(k, j, at);
     });
-    // block-tridiagonal solve
+    // block-tridiagonal solve: forward f_k -= W_{k-1} f_{k-1}
     for (int k = 1; k < K; ++k) {
         const double* W = q.Wk + (k - 1) * 81;
         wfor(9, [&](int i) {
             double acc = 0.0;
-            for (int t = 0; t < 9; ++t) acc += W[9 * i + t] * xt[ix.x(k - 1, t)];
-            xt[ix.x(k, i)] -= acc;
+            for (int t = 0; t < 9; ++t) acc += W[9 * i + t] * xs[9 * (k - 1) + t];
+            xs[9 * k + i] -= acc;
         });
     }
+    // backward u_k = S_k^-1 f_k - W_k' u_{k+1}; results ping-pong through tmp so that one
+    // phase per step suffices, the last reader of f_k being this very step
+    double* ub = q.tmp;  // [2][9]
     for (int k = K - 1; k >= 0; --k) {
-        const double* Si = q.Sinv + k * 81;
+        const double* Si = q.Sinv + k * 45;
         const double* W = q.Wk + k * 81;
+        double* un = ub + 9 * (k & 1);
+        const double* up = ub + 9 * ((k + 1) & 1);
         wfor(9, [&](int i) {
             double acc = 0.0;
-            for (int t = 0; t < 9; ++t) acc += Si[9 * i + t] * xt[ix.x(k, t)];
+            for (int t = 0; t < 9; ++t) acc += symget(Si, i, t, 9) * xs[9 * k + t];
             if (k < K - 1)
-                for (int t = 0; t < 9; ++t) acc -= W[9 * t + i] * xt[ix.x(k + 1, t)];
-            tmp[i] = acc;
+                for (int t = 0; t < 9; ++t) acc -= W[9 * t + i] * up[t];
+            un[i] = acc;
+            if (k < K - 1) xs[9 * (k + 1) + i] = up[i];  // f_{k+1} is dead: store u_{k+1}
         });
-        wfor(9, [&](int i) { xt[ix.x(k, i)] = tmp[i]; });
     }
+    wfor(9, [&](int i) { xs[i] = ub[i]; });
     // a = A_x xt_x ; slack back-substitution ; zt = a - beta * s
+    auto xv = [&](int k, int j) { return xs[9 * k + j]; };
     wfor(m, [&](int r) {
         int k, kind, o;
         q.dec_row(r, k, kind, o);
-        at[r] = q.row_dot_x(k, kind, o, xt);
+        at[r] = q.row_dot_x(k, kind, o, xv);
     });
     wfor(m, [&](int r) {
         int k, kind, o;
         q.dec_row(r, k, kind, o);
-        double corr = slack_inv_apply(q, k, kind + 1, o, [&](int var, int row) { return q.rho[row] * q.E[row] * q.D[var] * at[row]; });
-        xt[q.row_slack(k, kind, o)] = zt[r] + corr;
-    });
-    wfor(m, [&](int r) {
-        int k, kind, o;
-        q.dec_row(r, k, kind, o);
+        double corr = slack_inv_apply(q, k, kind + 1, o, [&](int var, int row) { return q.rho_at(row) * q.E[row] * q.D[var] * at[row]; });
         int sv = q.row_slack(k, kind, o);
-        at[r] -= q.E[r] * q.D[sv] * xt[sv];
+        double sl = zt[r] + corr;
+        xt[sv] = sl;
+        zt[r] = at[r] - q.E[r] * q.D[sv] * sl;
     });
-    (void)n;
 }
 
 struct SolveInfo {
@@ -503,81 +522,126 @@ struct SolveInfo {
     double pri_res, dua_res, rho;
 };
 
-// osqp_setup + osqp_solve + extraction.  window = steps kstart .. kstart+K-1 (newest = T)
+// osqp_setup + osqp_solve + extraction.  window = steps kstart .. kstart+K-1 (newest = T).
+// FACTOR_LDS / PA_LDS are compile-time so that every pointer has a provable address space
+// (ds_read/ds_write instead of flat_load) — see SolveLayout::factor_in_lds / pa_in_lds.
+template <bool FACTOR_LDS, bool PA_LDS>
 DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, double* lds, double* gws) {
+    SolveLayout lay;
+    lay.init(c.N, c.L);
     Gws g;
     g.init(c.N, c.L);
-    SolveCtx q{c, s, b, K, kstart, 0, 0, Idx{c.nm, c.SV, c.SC}, SolveLds{}, nullptr, nullptr, nullptr, nullptr, nullptr,
-               nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1.0};
-    q.l.carve(lds, c.N, c.L);
+    SolveCtx q{c, s, b, K, kstart, 0, 0, Idx{c.nm, c.SV, c.SC}};
+    {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
+        double* p = lds;
+        q.x = p; p += lay.n_pad;
+        q.z = p; p += lay.m_pad;
+        q.y = p; p += lay.m_pad;
+        q.xt = p; p += lay.n_pad;
+        q.zt = p; p += lay.m_pad;
+        q.at = p; p += lay.m_pad;
+        q.xs = p; p += 9 * c.N;
+        q.tmp = p; p += SOLVE_TMP;
+        if constexpr (FACTOR_LDS) {
+            q.D = p; p += lay.n_pad;
+            q.E = p; p += lay.m_pad;
+            q.lo = p; p += lay.m_pad;
+            q.hi = p; p += lay.m_pad;
+            q.Sv = p; p += c.N * 6 * c.L;
+            q.Sw = p; p += c.N * 24;
+            q.Sc = p; p += c.N * 6;
+            q.Sinv = p; p += c.N * 45;
+            q.Wk = p; p += c.N * 81;
+            q.R = p; p += c.N * 9;
+        } else {
+            q.D = gws + g.D; q.E = gws + g.E; q.lo = gws + g.lo; q.hi = gws + g.hi;
+            q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc;
+            q.Sinv = gws + g.Sinv; q.Wk = gws + g.Wk; q.R = gws + g.rho;  // rho slot is unused: R (9K <= m_pad)
+        }
+        q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
+        if constexpr (PA_LDS) q.PA = q.xt;
+        else q.PA = gws + g.PA;
+    }
     q.n = (K - 1) * c.SV + 9 + c.nm;
     q.m = (K - 1) * c.SC + c.nm;
-    q.D = gws + g.D; q.E = gws + g.E; q.lo = gws + g.lo; q.hi = gws + g.hi; q.rho = gws + g.rho;
-    q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc; q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
-    q.PA = gws + g.PA; q.Sinv = gws + g.Sinv; q.Wk = gws + g.Wk;
     q.Mp = s.Mp + 81 * (size_t)b;
     q.np = s.np_ + 9 * (size_t)b;
+    q.cc = 1.0;
     const int n = q.n, m = q.m;
     const Idx& ix = q.ix;
     SolveInfo info{0, DEKF_SOLVE_MAX_ITER, 0, 0.0, 0.0, c.rho0};
 
+    wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });
     if (c.scaling > 0) solve_scale(q);
-    else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); q.cc = 1.0; }
-    double rho = dmin(dmax(c.rho0, RHO_MIN), RHO_MAX);
-    solve_bounds_rho(q, rho, true);
+    else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
+    q.rho = dmin(dmax(c.rho0, RHO_MIN), RHO_MAX);
+    // scaled bounds, cold start
+    double *x = q.x, *z = q.z, *y = q.y, *xt = q.xt, *zt = q.zt, *at = q.at;
+    wfor(n + m, [&](int e) {
+        if (e < n) { x[e] = 0.0; return; }
+        int r = e - n, k, kind, o;
+        q.dec_row(r, k, kind, o);
+        double lb, ub;
+        q.bounds(k, kind, o, lb, ub);
+        q.lo[r] = lb * q.E[r];
+        q.hi[r] = ub * q.E[r];
+        z[r] = 0.0;
+        y[r] = 0.0;
+        at[r] = 0.0;  // u = rho z - y of the cold start
+    });
     bool ok = solve_factor(q);
+    wfor(m, [&](int r) { at[r] = 0.0; });  // PA may alias at
     double qs[9];  // scaled linear cost on x_0
     for (int j = 0; j < 9; ++j) qs[j] = q.cc * q.D[ix.x(0, j)] * q.np[j];
-    double *x = q.l.x, *z = q.l.z, *y = q.l.y, *xt = q.l.xt, *zt = q.l.zt, *at = q.l.at;
-    wfor(n + 2 * m, [&](int e) {
-        if (e < n) x[e] = 0.0;
-        else if (e < n + m) z[e - n] = 0.0;
-        else y[e - n - m] = 0.0;
-    });
     const double sigma = c.sigma, alpha = c.alpha;
     const double cinv = 1.0 / q.cc;
     int iter = 0;
     bool done = false;
     while (ok && !done && iter < c.max_iter) {
         ++iter;
-        // right-hand side: sigma x - q + A'(rho z - y)
-        wfor(m, [&](int r) { zt[r] = q.rho[r] * z[r] - y[r]; });
+        // right-hand side: sigma x - q + A'u, u = rho z - y (left in `at` by the previous update)
         wfor(n, [&](int i) {
             int k, kind, o;
             q.dec_var(i, k, kind, o);
             double v = sigma * x[i];
             if (kind == 0) {
                 if (k == 0) v -= qs[o];
-                v += q.gather_x(k, o, zt);
+                v += q.gather_x(k, o, at);
             } else {
                 int r = q.slack_row(k, kind, o);
-                v -= q.E[r] * q.D[i] * zt[r];
+                v -= q.E[r] * q.D[i] * at[r];
             }
             xt[i] = v;
         });
         solve_linear(q);
-        // x, z, y updates (alpha relaxation, projection onto [lo, hi])
+        // x, z, y updates (alpha relaxation, projection onto [lo, hi]); u for the next iteration
         wfor(n + m, [&](int e) {
-            if (e < n) x[e] = alpha * xt[e] + (1.0 - alpha) * x[e];
-            else {
+            if (e < n) {
+                int k, kind, o;
+                q.dec_var(e, k, kind, o);
+                double xn = kind == 0 ? q.xs[9 * k + o] : xt[e];
+                x[e] = alpha * xn + (1.0 - alpha) * x[e];
+            } else {
                 int r = e - n;
-                double rv = q.rho[r];
-                double zh = alpha * at[r] + (1.0 - alpha) * z[r];
+                double rv = q.rho_at(r);
+                double zh = alpha * zt[r] + (1.0 - alpha) * z[r];
                 double zn = dmin(dmax(zh + y[r] / rv, q.lo[r]), q.hi[r]);
-                y[r] += rv * (zh - zn);
+                double yn = y[r] + rv * (zh - zn);
+                y[r] = yn;
                 z[r] = zn;
+                at[r] = rv * zn - yn;
             }
         });
         bool can_check = c.check_termination > 0 && (iter % c.check_termination == 0);
         bool adapt_now = c.adaptive_rho && c.adaptive_rho_interval > 0 && (iter % c.adaptive_rho_interval == 0);
         if (can_check || adapt_now || iter == c.max_iter) {
-            // residuals: rows
             double ra[6], va[8];
+            auto xv = [&](int k, int j) { return x[ix.x(k, j)]; };
             wred_maxn<6>(m, ra, [&](int r, double* acc) {
                 int k, kind, o;
                 q.dec_row(r, k, kind, o);
                 int sv = q.row_slack(k, kind, o);
-                double Ax = q.row_dot_x(k, kind, o, x) - q.E[r] * q.D[sv] * x[sv];
+                double Ax = q.row_dot_x(k, kind, o, xv) - q.E[r] * q.D[sv] * x[sv];
                 double pr = Ax - z[r];
                 double ei = 1.0 / q.E[r];
                 acc[0] = dmax(acc[0], fabs(pr) * ei);
@@ -620,19 +684,19 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
             if (!done && adapt_now) {
                 double pr = ra[3] / (dmax(ra[4], ra[5]) + 1e-10);
                 double du = va[4] / (dmax(va[5], dmax(va[6], va[7])) + 1e-10);
-                double rho_new = dmin(dmax(rho * sqrt(pr / (du + 1e-10)), RHO_MIN), RHO_MAX);
-                if (rho_new > rho * c.adaptive_rho_tolerance || rho_new < rho / c.adaptive_rho_tolerance) {
-                    rho = rho_new;
+                double rho_new = dmin(dmax(q.rho * sqrt(pr / (du + 1e-10)), RHO_MIN), RHO_MAX);
+                if (rho_new > q.rho * c.adaptive_rho_tolerance || rho_new < q.rho / c.adaptive_rho_tolerance) {
+                    q.rho = rho_new;
                     info.rho_updates++;
                     DEKF_SYNC();
-                    solve_bounds_rho(q, rho, false);
                     ok = solve_factor(q);
+                    wfor(m, [&](int r) { at[r] = q.rho_at(r) * z[r] - y[r]; });
                 }
             }
         }
     }
     info.iters = iter;
-    info.rho = rho;
+    info.rho = q.rho;
     // store_solution + update() tail: x_T = D x ; v_b = R (x_T[3:6] + gyro x p_imu_2_opti)
     const double* rT = q.rec(K - 1);
     double xT[9];

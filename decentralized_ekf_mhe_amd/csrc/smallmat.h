@@ -60,6 +60,29 @@ DEKF_FN bool inv_small(double* A, int n) {
     return true;
 }
 
+// in-place inverse of an SPD N x N row-major matrix, Gauss-Jordan without pivoting, fully
+// unrolled so that every index is static and the matrix stays in registers
+template <int N>
+DEKF_FN void inv_spd_unrolled(double* A) {
+#pragma unroll
+    for (int p = 0; p < N; ++p) {
+        double d = 1.0 / A[p * N + p];
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (j != p) A[p * N + j] *= d;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (i == p) continue;
+            double f = A[i * N + p];
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                if (j != p) A[i * N + j] -= f * A[p * N + j];
+            A[i * N + p] = -f * d;
+        }
+        A[p * N + p] = d;
+    }
+}
+
 // inverse of a symmetric 3x3 given packed (00 01 02 11 12 22) -> packed, by cofactors
 DEKF_FN bool inv3_sym(const double* s, double* o) {
     double a = s[0], b = s[1], c = s[2], d = s[3], e = s[4], f = s[5];

@@ -33,7 +33,8 @@ void* hs_create(const dekf_params* p, int B) {
     alloc_state(h->c, h->s, 1, [&](size_t bytes) { void* q = std::calloc(1, bytes ? bytes : 8); h->blocks.push_back(q); return q; });
     Gws g; g.init(h->c.N, h->c.L);
     h->gws_len = g.total;
-    int n = SolveLds::len(h->c.N, h->c.L);
+    SolveLayout lay; lay.init(h->c.N, h->c.L);
+    int n = (int)(lay.lds_bytes() / 8);
     int a = AsmScratch::len(h->c.L), k = KfScratch::len(h->c.L);
     h->lds.assign((size_t)std::max(n, std::max(a, k)), 0.0);
     for (int b = 0; b < B; ++b) {
@@ -89,7 +90,10 @@ void hs_update(void* hv, int T) {
         if (h->c.est_type == 0) {
             assemble_update(h->c, h->s, b, T, h->pushes, h->lds.data());
             int kstart = T - h->c.N + 1 > 0 ? T - h->c.N + 1 : 0;
-            solve_window(h->c, h->s, b, kstart, T - kstart + 1, h->lds.data(), h->s.gws);
+            SolveLayout lay; lay.init(h->c.N, h->c.L);
+            if (lay.pa_in_lds()) solve_window<true, true>(h->c, h->s, b, kstart, T - kstart + 1, h->lds.data(), h->s.gws);
+            else if (lay.factor_in_lds()) solve_window<true, false>(h->c, h->s, b, kstart, T - kstart + 1, h->lds.data(), h->s.gws);
+            else solve_window<false, false>(h->c, h->s, b, kstart, T - kstart + 1, h->lds.data(), h->s.gws);
         } else {
             kf_update(h->c, h->s, b, h->pushes, h->lds.data());
         }
@@ -118,6 +122,31 @@ void hs_get_arrival(void* hv, double* M, double* n) {
 void hs_get_scaling(void* hv, int n, int m, double* D, double* E) {
     Sim* h = (Sim*)hv;
     Gws g; g.init(h->c.N, h->c.L);
-    std::memcpy(D, h->s.gws + g.D, (size_t)n * 8); std::memcpy(E, h->s.gws + g.E, (size_t)m * 8);
+    SolveLayout lay; lay.init(h->c.N, h->c.L);
+    const double* Dp = h->s.gws + g.D;
+    const double* Ep = h->s.gws + g.E;
+    if (lay.factor_in_lds()) {  // same carve order as solve_window
+        Dp = h->lds.data() + 2 * lay.n_pad + 4 * lay.m_pad + 9 * h->c.N + SOLVE_TMP;
+        Ep = Dp + lay.n_pad;
+    }
+    std::memcpy(D, Dp, (size_t)n * 8); std::memcpy(E, Ep, (size_t)m * 8);
 }
 }  // extern "C"
+
+#include "../../decentralized_ekf_mhe_amd/csrc/go1_kin.h"
+extern "C" {
+// Go1 leg odometry front-end (go1_kin.h) for n joint vectors jp[n][12] -> p[n][12] (with p_ib), J[n][36]
+void hs_go1_fk(int n, const double* jp, const double* p_ib, double* p_out, double* J_out) {
+    for (int i = 0; i < n; ++i)
+        for (int leg = 0; leg < 4; ++leg) {
+            double p[3], J[9];
+            go1_leg_fk(leg, jp + 12 * i + 3 * leg, p, J);
+            for (int a = 0; a < 3; ++a) p_out[12 * i + 3 * leg + a] = p[a] + p_ib[a];
+            for (int a = 0; a < 9; ++a) J_out[36 * i + 9 * leg + a] = J[a];
+        }
+}
+void hs_push_go1_joints(void* hv, const double* jp, const double* jv, const double* force, double thr, const double* p_ib) {
+    Sim* h = (Sim*)hv;
+    for (int b = 0; b < h->c.B; ++b) go1_leg_odometry(h->s, b, jp, jv, force, thr, p_ib);
+}
+}

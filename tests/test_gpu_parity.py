@@ -157,5 +157,6 @@ def test_large_batch_properties():
     assert np.array_equal(x, np.broadcast_to(x[0], x.shape))
     x_ref, _, _, _ = O.run_streams(p, {k: (np.ascontiguousarray(v[:, :8]) if isinstance(v, np.ndarray) else v) for k, v in s.items()}, nthreads=8)
     assert block_err(x[0, :8], x_ref[K - 1]) <= 1.0
+    # the estimate is pulled from its tight zero prior towards the synthetic truth (0.5 m/s forward)
     v_err = np.abs(o["x"][:64, 3:6] - s["gt_v_s"][K - 1]).max()
-    assert v_err < 0.25, v_err
+    assert v_err < 0.45 and o["x"][:64, 3].mean() > 0.15, v_err
