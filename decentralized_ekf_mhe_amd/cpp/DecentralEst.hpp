@@ -1,0 +1,279 @@
+// DecentralEst.hpp — source-compatible C++ shim over the C ABI (include/dekf.h) for ONE robot.
+//
+// Mirrors the reference's estimator interface so that its call sites keep compiling:
+//     struct robot_params / struct robot_store          (DecentralEst.hpp:18-94)
+//     class DecentralizedEstimation { initialize(); update(T); reset(); }   (:96-103)
+//     public results R_sb_, p_vo_accmulate_, x_MHE_, v_MHE_b_, x_KF_, C_KF_, v_KF_b_   (:278-291)
+// and, for the orientation node, the timer step of orien_ekf (orien_ekf.cpp:77-106).
+// All arithmetic runs in libdekf.so on the GPU (batch = 1 here; fleets use the C ABI directly).
+//
+// The reference's fields are Eigen types.  Eigen is optional here: define
+// DEKF_SHIM_WITH_EIGEN before including this header to get the real Eigen::Vector3d /
+// VectorXd / MatrixXd / Quaterniond members; otherwise minimal stand-ins with the same
+// element access (v(i), m(i,j), q.w()) are used.
+#pragma once
+#include <cmath>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/dekf.h"
+
+#ifdef DEKF_SHIM_WITH_EIGEN
+#include <Eigen/Dense>
+using Eigen::Matrix3d;
+using Eigen::MatrixXd;
+using Eigen::Quaterniond;
+using Eigen::Vector3d;
+using Eigen::Vector4d;
+using Eigen::VectorXd;
+#else
+namespace dekf_shim {
+struct VectorXd {
+    std::vector<double> d;
+    VectorXd() {}
+    explicit VectorXd(int n) : d((size_t)n, 0.0) {}
+    static VectorXd Zero(int n) { return VectorXd(n); }
+    double& operator()(int i) { return d[(size_t)i]; }
+    double operator()(int i) const { return d[(size_t)i]; }
+    int size() const { return (int)d.size(); }
+    void resize(int n) { d.assign((size_t)n, 0.0); }
+    double* data() { return d.data(); }
+    const double* data() const { return d.data(); }
+};
+struct Vector3d {
+    double d[3] = {0, 0, 0};
+    double& operator()(int i) { return d[i]; }
+    double operator()(int i) const { return d[i]; }
+    const double* data() const { return d; }
+    double* data() { return d; }
+};
+struct MatrixXd {  // column-major like Eigen
+    int r = 0, c = 0;
+    std::vector<double> d;
+    MatrixXd() {}
+    MatrixXd(int r_, int c_) : r(r_), c(c_), d((size_t)r_ * c_, 0.0) {}
+    static MatrixXd Zero(int r_, int c_) { return MatrixXd(r_, c_); }
+    double& operator()(int i, int j) { return d[(size_t)j * r + i]; }
+    double operator()(int i, int j) const { return d[(size_t)j * r + i]; }
+    int rows() const { return r; }
+    int cols() const { return c; }
+};
+struct Matrix3d : MatrixXd {
+    Matrix3d() : MatrixXd(3, 3) {}
+};
+struct Quaterniond {
+    double w_ = 1, x_ = 0, y_ = 0, z_ = 0;
+    double& w() { return w_; }
+    double& x() { return x_; }
+    double& y() { return y_; }
+    double& z() { return z_; }
+    double w() const { return w_; }
+    double x() const { return x_; }
+    double y() const { return y_; }
+    double z() const { return z_; }
+};
+}  // namespace dekf_shim
+using dekf_shim::Matrix3d;
+using dekf_shim::MatrixXd;
+using dekf_shim::Quaterniond;
+using dekf_shim::Vector3d;
+using dekf_shim::VectorXd;
+#endif
+
+// ---- DecentralEst.hpp:18-63, verbatim field names -----------------------------------------
+struct robot_params {
+    std::vector<double> p_process_std_, accel_input_std_, accel_bias_std_, gyro_input_std_;
+    std::vector<double> quaternion_ib_, p_ib_;
+    int num_legs_ = 4;
+    int leg_odom_type_ = 0;
+    std::vector<double> joint_position_std_, joint_velocity_std_, foot_slide_std_, foot_swing_std_;
+    double contact_effort_theshold_ = 150.0;
+    std::vector<double> p_init_std_, v_init_std_, foot_init_std_, accel_bias_init_std_;
+    std::vector<double> vo_p_std_;
+    int rate_ = 200, N_ = 20, est_type_ = 0;
+    double rho_ = 0.1, alpha_ = 1.6, delta_ = 1e-5, sigma_ = 1e-5;
+    bool verbose_ = false, adaptRho_ = true, polish_ = false;
+    int maxQPIter_ = 4000;
+    double realtiveTol_ = 1e-6, absTol_ = 1e-6, primTol_ = 1e-6, dualTol_ = 1e-6, timeLimit_ = 0.0028;
+};
+
+// ---- DecentralEst.hpp:65-94 ----------------------------------------------------------------
+struct robot_store {
+    double imu_time_ = 0;
+    Vector3d accel_b_, angular_b_;
+    VectorXd joint_states_position_, joint_states_velocity_, joint_states_effort_, contact_;
+    MatrixXd p_imu_2_foot_, J_imu_2_foot_;  // (3L x 1), (3L x 3)
+    double vo_time_pre_ = 0, vo_time_now_ = 0;
+    bool vo_new_ = false;
+    Vector3d vo_p_body_pre_2_body_;
+    Quaterniond vo_quaternion_;
+    Quaterniond quaternion_, offset_quaternion_;
+    Vector3d gt_p_, gt_v_s_;
+};
+
+namespace dekf_shim {
+inline void check(dekf_status st) {
+    if (st != DEKF_OK) throw std::runtime_error(std::string("dekf: ") + dekf_last_error());
+}
+inline void copy3(double* dst, const std::vector<double>& src, const char* name) {
+    if (src.size() < 3) throw std::invalid_argument(std::string("robot_params.") + name + " needs 3 entries");
+    for (int i = 0; i < 3; ++i) dst[i] = src[(size_t)i];
+}
+// robot_params -> dekf_params (go1 defaults for everything the reference leaves implicit)
+inline dekf_params to_dekf_params(const robot_params& p) {
+    dekf_params d;
+    dekf_default_params(&d);
+    copy3(d.p_process_std, p.p_process_std_, "p_process_std_");
+    copy3(d.accel_input_std, p.accel_input_std_, "accel_input_std_");
+    copy3(d.accel_bias_std, p.accel_bias_std_, "accel_bias_std_");
+    copy3(d.gyro_input_std, p.gyro_input_std_, "gyro_input_std_");
+    if (p.quaternion_ib_.size() >= 4) for (int i = 0; i < 4; ++i) d.quaternion_ib[i] = p.quaternion_ib_[(size_t)i];
+    if (p.p_ib_.size() >= 3) copy3(d.p_ib, p.p_ib_, "p_ib_");
+    d.num_legs = p.num_legs_;
+    d.joints_per_leg = 3;
+    d.leg_odom_type = p.leg_odom_type_;
+    for (int i = 0; i < DEKF_MAX_JOINTS; ++i) {
+        d.joint_position_std[i] = p.joint_position_std_.empty() ? d.joint_position_std[i] : p.joint_position_std_[(size_t)(i % 3)];
+        d.joint_velocity_std[i] = p.joint_velocity_std_.empty() ? d.joint_velocity_std[i] : p.joint_velocity_std_[(size_t)(i % 3)];
+    }
+    copy3(d.foot_slide_std, p.foot_slide_std_, "foot_slide_std_");
+    copy3(d.foot_swing_std, p.foot_swing_std_, "foot_swing_std_");
+    d.contact_effort_threshold = p.contact_effort_theshold_;
+    copy3(d.p_init_std, p.p_init_std_, "p_init_std_");
+    copy3(d.v_init_std, p.v_init_std_, "v_init_std_");
+    if (p.foot_init_std_.size() >= 3) copy3(d.foot_init_std, p.foot_init_std_, "foot_init_std_");
+    copy3(d.accel_bias_init_std, p.accel_bias_init_std_, "accel_bias_init_std_");
+    copy3(d.vo_p_std, p.vo_p_std_, "vo_p_std_");
+    d.rate = p.rate_; d.N = p.N_; d.est_type = p.est_type_;
+    d.rho = p.rho_; d.alpha = p.alpha_; d.delta = p.delta_; d.sigma = p.sigma_;
+    d.verbose = p.verbose_; d.adapt_rho = p.adaptRho_; d.polish = p.polish_; d.max_qp_iter = p.maxQPIter_;
+    d.rel_tol = p.realtiveTol_; d.abs_tol = p.absTol_; d.prim_tol = p.primTol_; d.dual_tol = p.dualTol_;
+    d.time_limit = p.timeLimit_;
+    return d;
+}
+}  // namespace dekf_shim
+
+class DecentralizedEstimation {
+  public:
+    DecentralizedEstimation() {}
+    ~DecentralizedEstimation() { if (h_) dekf_destroy(h_); }
+    DecentralizedEstimation(const DecentralizedEstimation&) = delete;
+    DecentralizedEstimation& operator=(const DecentralizedEstimation&) = delete;
+
+    // DecentralEst.cpp:9-150.  `device` selects the GPU (new; the reference has none).
+    void initialize(std::shared_ptr<robot_store> sub, std::shared_ptr<robot_params> params, int device = 0) {
+        robot_sub_ptr_ = sub;
+        params_ptr_ = params;
+        prm_ = dekf_shim::to_dekf_params(*params);
+        if (h_) { dekf_destroy(h_); h_ = nullptr; }
+        dekf_shim::check(dekf_create(&prm_, 1, device, nullptr, &h_));
+        x_MHE_.resize(9);
+        x_KF_.resize(9);
+        latch();
+        dekf_shim::check(dekf_initialize(h_));
+        fetch();
+    }
+    // DecentralEst.cpp:152-198
+    void update(int T) {
+        if (!h_) throw std::logic_error("update() before initialize()");
+        latch();
+        dekf_shim::check(dekf_update(h_, T));
+        fetch();
+    }
+    // DecentralEst.cpp:1011-1015
+    void reset() { if (h_) dekf_shim::check(dekf_reset(h_)); }
+
+    // ---- public results (DecentralEst.hpp:278-291) ----
+    Matrix3d R_sb_;
+    Vector3d p_vo_accmulate_;
+    VectorXd x_MHE_;
+    Vector3d v_MHE_b_;
+    VectorXd x_KF_;
+    MatrixXd C_KF_ = MatrixXd(9, 9);
+    Vector3d v_KF_b_;
+    int solver_status_ = DEKF_SOLVE_NONE, solver_iters_ = 0;  // new: the reference ignores OSQP's flag
+
+  private:
+    std::shared_ptr<robot_store> robot_sub_ptr_;
+    std::shared_ptr<robot_params> params_ptr_;
+    dekf_params prm_;
+    dekf_handle h_ = nullptr;
+
+    // what GetMeasurement reads from robot_store by pointer (DecentralEst.cpp:867-879)
+    void latch() {
+        robot_store& s = *robot_sub_ptr_;
+        const int L = prm_.num_legs;
+        double a[3] = {s.accel_b_(0), s.accel_b_(1), s.accel_b_(2)};
+        double w[3] = {s.angular_b_(0), s.angular_b_(1), s.angular_b_(2)};
+        dekf_shim::check(dekf_push_imu(h_, &s.imu_time_, a, w, DEKF_HOST));
+        double q[4] = {s.quaternion_.w(), s.quaternion_.x(), s.quaternion_.y(), s.quaternion_.z()};
+        dekf_shim::check(dekf_push_quaternion(h_, q, DEKF_HOST));
+        std::vector<double> p(3 * L), J(9 * L), qd(3 * L), c(L);
+        for (int i = 0; i < 3 * L; ++i) {
+            p[(size_t)i] = s.p_imu_2_foot_(i, 0);
+            for (int j = 0; j < 3; ++j) J[(size_t)(3 * i + j)] = s.J_imu_2_foot_(i, j);
+            qd[(size_t)i] = s.joint_states_velocity_(i);
+        }
+        for (int i = 0; i < L; ++i) c[(size_t)i] = s.contact_(i);
+        dekf_shim::check(dekf_push_leg(h_, p.data(), J.data(), qd.data(), c.data(), DEKF_HOST));
+        if (s.vo_new_) {
+            int one = 1;
+            double dp[3] = {s.vo_p_body_pre_2_body_(0), s.vo_p_body_pre_2_body_(1), s.vo_p_body_pre_2_body_(2)};
+            dekf_shim::check(dekf_push_vo(h_, &one, &s.vo_time_pre_, &s.vo_time_now_, dp, nullptr, nullptr, DEKF_HOST));
+            s.vo_new_ = false;  // DecentralEst.cpp:891
+        }
+        dekf_shim::check(dekf_sync(h_));  // the staging arrays above die with this scope
+    }
+    void fetch() {
+        double x[9], vb[3], q[4], pv[3];
+        int st = 0, it = 0;
+        dekf_shim::check(dekf_get(h_, x, vb, q, pv, &st, DEKF_HOST));
+        dekf_shim::check(dekf_get_solver_info(h_, &it, nullptr, nullptr, nullptr, DEKF_HOST));
+        solver_status_ = st;
+        solver_iters_ = it;
+        VectorXd& xs = prm_.est_type == 0 ? x_MHE_ : x_KF_;
+        Vector3d& v = prm_.est_type == 0 ? v_MHE_b_ : v_KF_b_;
+        for (int i = 0; i < 9; ++i) xs(i) = x[i];
+        for (int i = 0; i < 3; ++i) { v(i) = vb[i]; p_vo_accmulate_(i) = pv[i]; }
+        // R_sb_ = quaternion_.normalized().toRotationMatrix()  (DecentralEst.cpp:867)
+        double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+        double w = q[0] / n, xq = q[1] / n, y = q[2] / n, z = q[3] / n;
+        R_sb_(0, 0) = 1 - 2 * (y * y + z * z); R_sb_(0, 1) = 2 * (xq * y - w * z); R_sb_(0, 2) = 2 * (xq * z + w * y);
+        R_sb_(1, 0) = 2 * (xq * y + w * z); R_sb_(1, 1) = 1 - 2 * (xq * xq + z * z); R_sb_(1, 2) = 2 * (y * z - w * xq);
+        R_sb_(2, 0) = 2 * (xq * z - w * y); R_sb_(2, 1) = 2 * (y * z + w * xq); R_sb_(2, 2) = 1 - 2 * (xq * xq + y * y);
+        if (prm_.est_type == 1) {
+            double C[81];
+            dekf_shim::check(dekf_get_kf_cov(h_, C, DEKF_HOST));
+            for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) C_KF_(i, j) = C[9 * i + j];
+        }
+    }
+};
+
+// The orien_sub node's arithmetic (orien_ekf.cpp:77-106) for one robot: latch IMU / VO pose,
+// run one timer step on the GPU, read the quaternion that is published on imu/filter.
+class OrientationEkf {
+  public:
+    explicit OrientationEkf(const dekf_params& p, int device = 0) { dekf_shim::check(dekf_create(&p, 1, device, nullptr, &h_)); }
+    ~OrientationEkf() { if (h_) dekf_destroy(h_); }
+    OrientationEkf(const OrientationEkf&) = delete;
+    OrientationEkf& operator=(const OrientationEkf&) = delete;
+    void imu_callback(double t, const double accel[3], const double gyro[3]) {
+        dekf_shim::check(dekf_push_imu(h_, &t, accel, gyro, DEKF_HOST));
+        dekf_shim::check(dekf_sync(h_));
+    }
+    void vo_pose_callback(double t, const double q_wxyz[4]) {
+        int one = 1;
+        double zero3[3] = {0, 0, 0};
+        dekf_shim::check(dekf_push_vo(h_, &one, &t, &t, zero3, &t, q_wxyz, DEKF_HOST));
+        dekf_shim::check(dekf_sync(h_));
+    }
+    void timerCallback() { dekf_shim::check(dekf_ekf_step(h_)); }
+    void quaternion(double q_wxyz[4]) { dekf_shim::check(dekf_get(h_, nullptr, nullptr, q_wxyz, nullptr, nullptr, DEKF_HOST)); }
+    void covariance(double P[16]) { dekf_shim::check(dekf_get_ekf_cov(h_, P, DEKF_HOST)); }
+
+  private:
+    dekf_handle h_ = nullptr;
+};

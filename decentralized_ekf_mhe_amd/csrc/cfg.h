@@ -18,6 +18,8 @@
 
 namespace dekf {
 
+#define DEKF_SOLVE_THREADS 256  // lanes of the workgroup that solves one instance (4 wavefronts)
+
 constexpr double OSQP_INFTY = 1e30;
 constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e6, RHO_EQ_OVER_RHO_INEQ = 1e3, RHO_TOL = 1e-4;
 constexpr double MIN_SCALING = 1e-4, MAX_SCALING = 1e4;

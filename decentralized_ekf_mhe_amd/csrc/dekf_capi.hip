@@ -20,9 +20,14 @@ extern "C" {
 __global__ void k_ekf_tick(DevCfg c, DevState s, int count);
 __global__ void k_mhe_initialize(DevCfg c, DevState s);
 __global__ void k_mhe_assemble(DevCfg c, DevState s, int T, int pushes);
-__global__ void k_mhe_solve_ll(DevCfg c, DevState s, int kstart, int K, int gws_len);
-__global__ void k_mhe_solve_lg(DevCfg c, DevState s, int kstart, int K, int gws_len);
-__global__ void k_mhe_solve_gg(DevCfg c, DevState s, int kstart, int K, int gws_len);
+#define DEKF_DECL_SOLVE(LEGS)                                                                        \
+    __global__ void k_mhe_solve_ll_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);     \
+    __global__ void k_mhe_solve_lg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);     \
+    __global__ void k_mhe_solve_gg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);
+DEKF_DECL_SOLVE(1)
+DEKF_DECL_SOLVE(2)
+DEKF_DECL_SOLVE(3)
+DEKF_DECL_SOLVE(4)
 __global__ void k_kf_initialize(DevCfg c, DevState s);
 __global__ void k_kf_update(DevCfg c, DevState s, int pushes);
 __global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* t_pre, const double* t_now,
@@ -158,7 +163,13 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     SolveLayout lay;
     lay.init(c.N, c.L);
     h->lds_solve = lay.lds_bytes();
-    h->solve_kernel = lay.pa_in_lds() ? k_mhe_solve_ll : (lay.factor_in_lds() ? k_mhe_solve_lg : k_mhe_solve_gg);
+    {
+        typedef void (*SolveFn)(DevCfg, DevState, int, int, int);
+        static const SolveFn table[4][3] = {
+            {k_mhe_solve_ll_1, k_mhe_solve_lg_1, k_mhe_solve_gg_1}, {k_mhe_solve_ll_2, k_mhe_solve_lg_2, k_mhe_solve_gg_2},
+            {k_mhe_solve_ll_3, k_mhe_solve_lg_3, k_mhe_solve_gg_3}, {k_mhe_solve_ll_4, k_mhe_solve_lg_4, k_mhe_solve_gg_4}};
+        h->solve_kernel = table[c.L - 1][lay.pa_in_lds() ? 0 : (lay.factor_in_lds() ? 1 : 2)];
+    }
     h->lds_asm = (size_t)AsmScratch::len(c.L) * sizeof(double);
     h->lds_kf = (size_t)KfScratch::len(c.L) * sizeof(double);
     if (h->lds_solve > 160 * 1024) {
@@ -168,7 +179,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     if (h->lds_solve > 64 * 1024)
         hipFuncSetAttribute((const void*)h->solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
     int per_cu = 1;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h->solve_kernel, 64, h->lds_solve) != hipSuccess || per_cu < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h->solve_kernel, DEKF_SOLVE_THREADS, h->lds_solve) != hipSuccess || per_cu < 1)
         per_cu = 1;
     long slots = (long)per_cu * prop.multiProcessorCount;
     h->solve_grid = (int)(slots < batch ? slots : batch);
@@ -341,7 +352,7 @@ dekf_status dekf_update(dekf_handle h, int T) {
         int kstart = T - h->c.N + 1 > 0 ? T - h->c.N + 1 : 0;
         {
             Timed t(h, 2);
-            h->solve_kernel<<<h->solve_grid, 64, h->lds_solve, h->stream>>>(h->c, h->s, kstart, T - kstart + 1, h->gws_len);
+            h->solve_kernel<<<h->solve_grid, DEKF_SOLVE_THREADS, h->lds_solve, h->stream>>>(h->c, h->s, kstart, T - kstart + 1, h->gws_len);
         }
     } else {
         Timed t(h, 1);

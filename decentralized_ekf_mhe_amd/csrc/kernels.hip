@@ -38,15 +38,24 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
 
 // three placements of the factor (mhe_solve_core.h: SolveLayout): _ll all in LDS (Go1, N = 20),
 // _lg LDS factor with the factor-time temporary in HBM (fewer legs), _gg factor streamed from HBM
-#define DEKF_SOLVE_KERNEL(NAME, FL, PL)                                                                  \
-    __global__ void __launch_bounds__(64) NAME(DevCfg c, DevState s, int kstart, int K, int gws_len) {   \
+// One workgroup of DEKF_SOLVE_THREADS lanes (4 wavefronts, one per SIMD of the CU) per instance;
+// the leg count is a compile-time constant of each instantiation.
+#define DEKF_SOLVE_KERNEL(NAME, LEGS, FL, PL)                                                            \
+    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS) NAME(DevCfg c, DevState s, int kstart, int K,   \
+                                                               int gws_len) {                            \
         extern __shared__ double lds[];                                                                  \
         double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                              \
-        for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<FL, PL>(c, s, b, kstart, K, lds, gws); \
+        for (int b = blockIdx.x; b < c.B; b += gridDim.x)                                                \
+            solve_window<LEGS, FL, PL>(c, s, b, kstart, K, lds, gws);                                    \
     }
-DEKF_SOLVE_KERNEL(k_mhe_solve_ll, true, true)
-DEKF_SOLVE_KERNEL(k_mhe_solve_lg, true, false)
-DEKF_SOLVE_KERNEL(k_mhe_solve_gg, false, false)
+#define DEKF_SOLVE_KERNELS(LEGS)                            \
+    DEKF_SOLVE_KERNEL(k_mhe_solve_ll_##LEGS, LEGS, true, true)   \
+    DEKF_SOLVE_KERNEL(k_mhe_solve_lg_##LEGS, LEGS, true, false)  \
+    DEKF_SOLVE_KERNEL(k_mhe_solve_gg_##LEGS, LEGS, false, false)
+DEKF_SOLVE_KERNELS(1)
+DEKF_SOLVE_KERNELS(2)
+DEKF_SOLVE_KERNELS(3)
+DEKF_SOLVE_KERNELS(4)
 
 __global__ void __launch_bounds__(64) k_kf_initialize(DevCfg c, DevState s) {
     extern __shared__ double lds[];

@@ -52,11 +52,27 @@ struct SolveLayout {
     DEKF_HD size_t lds_bytes() const { return (size_t)(factor_in_lds() ? vec + resident : vec) * 8; }
 };
 
+// variable / row indices with the leg count known at compile time: every / and % by the
+// per-step block sizes becomes a multiply-shift instead of a ~40-instruction software divide
+template <int L>
+struct IdxT {
+    static constexpr int nm = 3 * L, SV = 21 + 3 * L, SC = 12 + 3 * L;
+    DEKF_FN static int x(int k, int j) { return k * SV + j; }
+    DEKF_FN static int v(int k, int r) { return k * SV + 9 + r; }
+    DEKF_FN static int w(int k, int r) { return k * SV + 9 + nm + r; }
+    DEKF_FN static int c(int k, int a) { return k * SV + 18 + nm + a; }
+    DEKF_FN static int rm(int k, int r) { return k * SC + r; }
+    DEKF_FN static int rd(int k, int r) { return k * SC + nm + r; }
+    DEKF_FN static int rv(int k, int a) { return k * SC + nm + 9 + a; }
+};
+
+template <int L>
 struct SolveCtx {
+    static constexpr int LEGS = L;
     const DevCfg& c;
     const DevState& s;
     int b, K, kstart, n, m;
-    Idx ix;
+    IdxT<L> ix;
     // LDS always
     double *x, *z, *y, *xt, *zt, *at, *xs, *tmp;
     // LDS or HBM scratch
@@ -109,7 +125,7 @@ struct SolveCtx {
         double dj = D[ix.x(k, j)];
         double acc = 0.0;
         if (j >= 3 && j < 6)
-            for (int leg = 0; leg < c.L; ++leg) { int r = ix.rm(k, 3 * leg + j - 3); acc += E[r] * vec[r]; }
+            for (int leg = 0; leg < L; ++leg) { int r = ix.rm(k, 3 * leg + j - 3); acc += E[r] * vec[r]; }
         if (k < K - 1) {
             for (int rr = 0; rr < 9; ++rr) {
                 double a = adyn(k, rr, j);
@@ -180,7 +196,7 @@ struct SolveCtx {
         if (kind != 0) return E[slack_row(k, kind, o)] * di;
         double acc = 0.0;
         if (o >= 3 && o < 6)
-            for (int leg = 0; leg < c.L; ++leg) acc = dmax(acc, E[ix.rm(k, 3 * leg + o - 3)]);
+            for (int leg = 0; leg < L; ++leg) acc = dmax(acc, E[ix.rm(k, 3 * leg + o - 3)]);
         if (k < K - 1) {
             for (int rr = 0; rr < 9; ++rr) acc = dmax(acc, E[ix.rd(k, rr)] * fabs(adyn(k, rr, o)));
             if (o < 3) acc = dmax(acc, E[ix.rv(k, o)]);
@@ -214,7 +230,8 @@ DEKF_FN double limit_scaling(double v) {
 }
 
 // Ruiz equilibration + cost scaling (OSQP scale_data), on the structured QP
-DEKF_FN void solve_scale(SolveCtx& q) {
+template <class Q>
+DEKF_FN void solve_scale(Q& q) {
     const int n = q.n, m = q.m;
     wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; });
     q.cc = 1.0;
@@ -240,10 +257,12 @@ DEKF_FN void solve_scale(SolveCtx& q) {
 
 // numeric factorisation for the current rho: slack-block inverses, effective row weights,
 // block-tridiagonal LDL' (S_k^-1 packed symmetric, W_k)
-DEKF_FN bool solve_factor(SolveCtx& q) {
+template <class Q>
+DEKF_FN bool solve_factor(Q& q) {
     const DevCfg& c = q.c;
-    const int K = q.K, L = c.L, nm = c.nm;
-    const Idx& ix = q.ix;
+    constexpr int L = Q::LEGS, nm = 3 * Q::LEGS;
+    const int K = q.K;
+    const auto& ix = q.ix;
     const double sigma = c.sigma, cc = q.cc;
     // 3a. slack blocks: one lane per block
     wfor(K * (L + 2), [&](int e) {
@@ -430,12 +449,12 @@ DEKF_FN bool solve_factor(SolveCtx& q) {
 }
 
 // apply a slack-block inverse: sum_s' Sinv_block[s][s'] * in(var s', row of s')
-template <class InF>
-DEKF_FN double slack_inv_apply(const SolveCtx& q, int k, int kind, int o, InF in) {
-    const Idx& ix = q.ix;
+template <class Q, class InF>
+DEKF_FN double slack_inv_apply(const Q& q, int k, int kind, int o, InF in) {
+    const auto& ix = q.ix;
     if (kind == 1) {
         int leg = o / 3, a = o - 3 * leg;
-        const double* si = q.Sv + (k * q.c.L + leg) * 6;
+        const double* si = q.Sv + (k * Q::LEGS + leg) * 6;
         double acc = 0.0;
         for (int t = 0; t < 3; ++t) acc += symget(si, a, t, 3) * in(ix.v(k, 3 * leg + t), ix.rm(k, 3 * leg + t));
         return acc;
@@ -455,9 +474,10 @@ DEKF_FN double slack_inv_apply(const SolveCtx& q, int k, int kind, int o, InF in
 
 // One ADMM linear solve.  In: xt = right-hand side (n).  Out: xs = xt on the x blocks (K*9),
 // xt = xt on the slack entries, zt = A xt.
-DEKF_FN void solve_linear(SolveCtx& q) {
+template <class Q>
+DEKF_FN void solve_linear(Q& q) {
     const int m = q.m, K = q.K;
-    const Idx& ix = q.ix;
+    const auto& ix = q.ix;
     double *xt = q.xt, *zt = q.zt, *at = q.at, *xs = q.xs;
     // t = S^-1 rhs_s (kept at the slack's row in zt), h = rho*beta*t (in at)
     wfor(m, [&](int r) {
@@ -525,13 +545,13 @@ struct SolveInfo {
 // osqp_setup + osqp_solve + extraction.  window = steps kstart .. kstart+K-1 (newest = T).
 // FACTOR_LDS / PA_LDS are compile-time so that every pointer has a provable address space
 // (ds_read/ds_write instead of flat_load) — see SolveLayout::factor_in_lds / pa_in_lds.
-template <bool FACTOR_LDS, bool PA_LDS>
+template <int L, bool FACTOR_LDS, bool PA_LDS>
 DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, double* lds, double* gws) {
     SolveLayout lay;
-    lay.init(c.N, c.L);
+    lay.init(c.N, L);
     Gws g;
-    g.init(c.N, c.L);
-    SolveCtx q{c, s, b, K, kstart, 0, 0, Idx{c.nm, c.SV, c.SC}};
+    g.init(c.N, L);
+    SolveCtx<L> q{c, s, b, K, kstart, 0, 0, IdxT<L>{}};
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
         double* p = lds;
         q.x = p; p += lay.n_pad;
@@ -547,7 +567,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
             q.E = p; p += lay.m_pad;
             q.lo = p; p += lay.m_pad;
             q.hi = p; p += lay.m_pad;
-            q.Sv = p; p += c.N * 6 * c.L;
+            q.Sv = p; p += c.N * 6 * L;
             q.Sw = p; p += c.N * 24;
             q.Sc = p; p += c.N * 6;
             q.Sinv = p; p += c.N * 45;
@@ -562,13 +582,13 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         if constexpr (PA_LDS) q.PA = q.xt;
         else q.PA = gws + g.PA;
     }
-    q.n = (K - 1) * c.SV + 9 + c.nm;
-    q.m = (K - 1) * c.SC + c.nm;
+    q.n = (K - 1) * IdxT<L>::SV + 9 + IdxT<L>::nm;
+    q.m = (K - 1) * IdxT<L>::SC + IdxT<L>::nm;
     q.Mp = s.Mp + 81 * (size_t)b;
     q.np = s.np_ + 9 * (size_t)b;
     q.cc = 1.0;
     const int n = q.n, m = q.m;
-    const Idx& ix = q.ix;
+    const auto& ix = q.ix;
     SolveInfo info{0, DEKF_SOLVE_MAX_ITER, 0, 0.0, 0.0, c.rho0};
 
     wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });

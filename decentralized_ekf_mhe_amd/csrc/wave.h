@@ -1,11 +1,12 @@
 // wave.h — the execution model the estimator cores are written against.
 //
-// One 64-lane wavefront owns one robot instance.  A core is a sequence of
-//   wfor(n, f)        lanes split i = 0..n-1 between them, then a wave-level sync
-//   wred_*(n, f)      wave-wide reduction of f(i)
-//   wave-uniform scalar code in between (every lane computes the same value).
+// One workgroup (1..4 wavefronts of 64 lanes) owns one robot instance.  A core is a sequence of
+//   wfor(n, f)        the group's lanes split i = 0..n-1 between them, then a group-level sync
+//   wred_*(n, f)      group-wide reduction of f(i); every lane receives the result
+//   group-uniform scalar code in between (every lane computes the same value).
 // All state a phase hands to the next one lives in memory (LDS or HBM), never in a lane's
-// registers, so a phase boundary is exactly one sync.
+// registers, so a phase boundary is exactly one sync.  With a single wavefront per group the
+// sync is free (hipcc drops s_barrier for a 64-thread workgroup); with several it is s_barrier.
 //
 // The same source builds in two ways:
 //   hipcc (gfx950)          lanes are real: strided loops + DPP/shuffle reductions + s_barrier
@@ -20,29 +21,33 @@
 #define DEKF_DEVICE_BUILD 1
 #define DEKF_FN __device__ __forceinline__
 #define DEKF_HD __host__ __device__ __forceinline__
-#define DEKF_LANE() ((int)(threadIdx.x & 63))
-// block == one wavefront, so the workgroup barrier is a wave barrier + LDS/VMEM drain
+#define DEKF_LANE() ((int)threadIdx.x)
+#define DEKF_NLANES() ((int)blockDim.x)
 #define DEKF_SYNC() __syncthreads()
 #else
 #define DEKF_DEVICE_BUILD 0
 #define DEKF_FN inline
 #define DEKF_HD inline
 #define DEKF_LANE() 0
+#define DEKF_NLANES() 1
 #define DEKF_SYNC() ((void)0)
 #endif
 
 namespace dekf {
 
 constexpr int WAVE = 64;
+constexpr int MAX_WAVES = 4;  // per workgroup / instance
 
 #if DEKF_DEVICE_BUILD
 template <class F>
 DEKF_FN void wfor_nosync(int n, F f) {
-    for (int i = DEKF_LANE(); i < n; i += WAVE) f(i);
+    const int st = DEKF_NLANES();
+    for (int i = DEKF_LANE(); i < n; i += st) f(i);
 }
 template <class F>
 DEKF_FN void wfor(int n, F f) {
-    for (int i = DEKF_LANE(); i < n; i += WAVE) f(i);
+    const int st = DEKF_NLANES();
+    for (int i = DEKF_LANE(); i < n; i += st) f(i);
     DEKF_SYNC();
 }
 DEKF_FN double wave_max(double v) {
@@ -55,17 +60,39 @@ DEKF_FN double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
 }
+// combine NR per-wave partials across the group's wavefronts; every lane gets the result
+template <int NR, bool SUM>
+DEKF_FN void group_combine(double* v) {
+    if (DEKF_NLANES() <= WAVE) return;  // group-uniform
+    __shared__ double red[NR * MAX_WAVES];
+    const int w = DEKF_LANE() >> 6, nw = DEKF_NLANES() >> 6;
+    DEKF_SYNC();  // a previous use of `red` has been read by everyone
+    if ((DEKF_LANE() & 63) == 0)
+        for (int r = 0; r < NR; ++r) red[r * MAX_WAVES + w] = v[r];
+    DEKF_SYNC();
+    for (int r = 0; r < NR; ++r) {
+        double a = red[r * MAX_WAVES];
+        for (int i = 1; i < nw; ++i) a = SUM ? a + red[r * MAX_WAVES + i] : fmax(a, red[r * MAX_WAVES + i]);
+        v[r] = a;
+    }
+}
 template <class F>
 DEKF_FN double wred_max(int n, F f) {
     double v = 0.0;
-    for (int i = DEKF_LANE(); i < n; i += WAVE) v = fmax(v, f(i));
-    return wave_max(v);
+    const int st = DEKF_NLANES();
+    for (int i = DEKF_LANE(); i < n; i += st) v = fmax(v, f(i));
+    v = wave_max(v);
+    group_combine<1, false>(&v);
+    return v;
 }
 template <class F>
 DEKF_FN double wred_sum(int n, F f) {
     double v = 0.0;
-    for (int i = DEKF_LANE(); i < n; i += WAVE) v += f(i);
-    return wave_sum(v);
+    const int st = DEKF_NLANES();
+    for (int i = DEKF_LANE(); i < n; i += st) v += f(i);
+    v = wave_sum(v);
+    group_combine<1, true>(&v);
+    return v;
 }
 // several maxima at once: f(i, acc) updates acc[0..NR); all lanes get the reduced values
 template <int NR, class F>
@@ -73,16 +100,21 @@ DEKF_FN void wred_maxn(int n, double* out, F f) {
     double acc[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;
-    for (int i = DEKF_LANE(); i < n; i += WAVE) f(i, acc);
+    const int st = DEKF_NLANES();
+    for (int i = DEKF_LANE(); i < n; i += st) f(i, acc);
 #pragma unroll
-    for (int r = 0; r < NR; ++r) out[r] = wave_max(acc[r]);
+    for (int r = 0; r < NR; ++r) acc[r] = wave_max(acc[r]);
+    group_combine<NR, false>(acc);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) out[r] = acc[r];
 }
 // index of the largest f(i) (ties: lowest index), f(i) >= 0
 template <class F>
 DEKF_FN int wred_argmax(int n, F f, double* best_out) {
     double best = -1.0;
     int bi = 0x7fffffff;
-    for (int i = DEKF_LANE(); i < n; i += WAVE) {
+    const int st = DEKF_NLANES();
+    for (int i = DEKF_LANE(); i < n; i += st) {
         double v = f(i);
         if (v > best) { best = v; bi = i; }
     }
@@ -91,6 +123,17 @@ DEKF_FN int wred_argmax(int n, F f, double* best_out) {
         double ov = __shfl_xor(best, o, WAVE);
         int oi = __shfl_xor(bi, o, WAVE);
         if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    if (DEKF_NLANES() > WAVE) {
+        __shared__ double rb[MAX_WAVES];
+        __shared__ int ri[MAX_WAVES];
+        const int w = DEKF_LANE() >> 6, nw = DEKF_NLANES() >> 6;
+        DEKF_SYNC();
+        if ((DEKF_LANE() & 63) == 0) { rb[w] = best; ri[w] = bi; }
+        DEKF_SYNC();
+        best = rb[0]; bi = ri[0];
+        for (int i = 1; i < nw; ++i)
+            if (rb[i] > best || (rb[i] == best && ri[i] < bi)) { best = rb[i]; bi = ri[i]; }
     }
     if (best_out) *best_out = best;
     return bi;

@@ -1,6 +1,8 @@
 // TEST INFRASTRUCTURE ONLY — C entry points of the CPU oracle, loaded with ctypes by tests/,
 // __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing under
 // decentralized_ekf_mhe_amd/ may link or load this library.
+#include <malloc.h>
+
 #include <chrono>
 #include <cstring>
 #include <thread>
@@ -198,6 +200,10 @@ double orc_pipe_run(const dekf_params* prm, int B, int nsteps, int nthreads, con
                     const double* vo_q, double* x_out, double* vb_out, double* quat_out, int* iters_out) {
     int L = prm->num_legs, nj = prm->joints_per_leg;
     int ns = 9 + 3 * prm->leg_odom_type * L;
+    // the dense H / A copies are MB-sized: keep them on the per-thread malloc arenas instead of
+    // one mmap/munmap per copy, which serialises all threads on the process's mm lock
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
     if (nthreads < 1) nthreads = 1;
     if (nthreads > B) nthreads = B;
     auto worker = [&](int b0, int b1) {

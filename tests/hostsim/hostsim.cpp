@@ -91,9 +91,18 @@ void hs_update(void* hv, int T) {
             assemble_update(h->c, h->s, b, T, h->pushes, h->lds.data());
             int kstart = T - h->c.N + 1 > 0 ? T - h->c.N + 1 : 0;
             SolveLayout lay; lay.init(h->c.N, h->c.L);
-            if (lay.pa_in_lds()) solve_window<true, true>(h->c, h->s, b, kstart, T - kstart + 1, h->lds.data(), h->s.gws);
-            else if (lay.factor_in_lds()) solve_window<true, false>(h->c, h->s, b, kstart, T - kstart + 1, h->lds.data(), h->s.gws);
-            else solve_window<false, false>(h->c, h->s, b, kstart, T - kstart + 1, h->lds.data(), h->s.gws);
+            int K = T - kstart + 1;
+#define HS_SOLVE(LEGS)                                                                                      \
+    if (lay.pa_in_lds()) solve_window<LEGS, true, true>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws); \
+    else if (lay.factor_in_lds()) solve_window<LEGS, true, false>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws); \
+    else solve_window<LEGS, false, false>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);
+            switch (h->c.L) {
+                case 1: HS_SOLVE(1) break;
+                case 2: HS_SOLVE(2) break;
+                case 3: HS_SOLVE(3) break;
+                default: HS_SOLVE(4) break;
+            }
+#undef HS_SOLVE
         } else {
             kf_update(h->c, h->s, b, h->pushes, h->lds.data());
         }
