@@ -57,7 +57,11 @@ struct Rec {
 
 // packed symmetric index, i <= j, n x n
 DEKF_FN int symidx(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
-DEKF_FN double symget(const double* s, int i, int j, int n) { return i <= j ? s[symidx(i, j, n)] : s[symidx(j, i, n)]; }
+// branch-free for either order of (i, j): lo * (2n - 1 - lo) / 2 + hi
+DEKF_FN double symget(const double* s, int i, int j, int n) {
+    int lo = i < j ? i : j, hi = i < j ? j : i;
+    return s[(lo * (2 * n - 1 - lo)) / 2 + hi];
+}
 
 // variable / row indices of the QP in the reference's own order
 // (x_k v_k w_k c_k per step; Meas_k Dyn_k VO_k per step — SURVEY.md Appendix A)

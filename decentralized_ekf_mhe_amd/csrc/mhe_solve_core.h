@@ -30,19 +30,19 @@
 
 namespace dekf {
 
-constexpr int SOLVE_TMP = 176;  // 2 x 81 Gauss-Jordan ping-pong + slack
+constexpr int SOLVE_TMP = 176;  // [0,18) sweep ping-pong, [162,171) scaled q; at factor time [0,162) = 2 x 81 Gauss-Jordan
 
 // how many doubles of LDS a solve needs in each placement mode
 struct SolveLayout {
     int n_pad, m_pad, K;
-    int vec;        // iterates: x z y xt zt at xs tmp
+    int vec;        // iterates: x z y xt zt at xs xd tmp
     int resident;   // D E lo hi Sv Sw Sc Sinv Wk R
     DEKF_HD void init(int N, int L) {
         int nm = 3 * L;
         K = N;
         n_pad = N * (9 + nm + 12);
         m_pad = N * (nm + 12);
-        vec = 2 * n_pad + 4 * m_pad + 9 * N + SOLVE_TMP;
+        vec = 2 * n_pad + 4 * m_pad + 18 * N + SOLVE_TMP;
         resident = n_pad + 3 * m_pad + N * (6 * L + 24 + 6) + N * (45 + 81) + 9 * N;
     }
     // LDS-resident factor only if two workgroups still fit in one CU's 160 KiB
@@ -74,7 +74,7 @@ struct SolveCtx {
     int b, K, kstart, n, m;
     IdxT<L> ix;
     // LDS always
-    double *x, *z, *y, *xt, *zt, *at, *xs, *tmp;
+    double *x, *z, *y, *xt, *zt, *at, *xs, *xd, *tmp;
     // LDS or HBM scratch
     double *D, *E, *lo, *hi, *Sv, *Sw, *Sc, *Sinv, *Wk, *R;
     // factor-time temporaries
@@ -448,92 +448,227 @@ DEKF_FN bool solve_factor(Q& q) {
     return ok;
 }
 
-// apply a slack-block inverse: sum_s' Sinv_block[s][s'] * in(var s', row of s')
-template <class Q, class InF>
-DEKF_FN double slack_inv_apply(const Q& q, int k, int kind, int o, InF in) {
-    const auto& ix = q.ix;
-    if (kind == 1) {
-        int leg = o / 3, a = o - 3 * leg;
-        const double* si = q.Sv + (k * Q::LEGS + leg) * 6;
-        double acc = 0.0;
-        for (int t = 0; t < 3; ++t) acc += symget(si, a, t, 3) * in(ix.v(k, 3 * leg + t), ix.rm(k, 3 * leg + t));
-        return acc;
-    } else if (kind == 2) {
-        const double* sw = q.Sw + k * 24;
-        if (o >= 6) return sw[21 + o - 6] * in(ix.w(k, o), ix.rd(k, o));
-        double acc = 0.0;
-        for (int t = 0; t < 6; ++t) acc += symget(sw, o, t, 6) * in(ix.w(k, t), ix.rd(k, t));
-        return acc;
-    } else {
-        const double* si = q.Sc + k * 6;
-        double acc = 0.0;
-        for (int t = 0; t < 3; ++t) acc += symget(si, o, t, 3) * in(ix.c(k, t), ix.rv(k, t));
-        return acc;
+// ---------------------------------------------------------------- one ADMM linear solve
+// Every loop below runs over ONE kind of row / variable (Meas rows, Dyn p/v rows, Dyn bias rows,
+// VO rows; x position / velocity / bias columns), so the 64 lanes of a wavefront execute the same
+// straight-line code instead of diverging three ways, and all index arithmetic is by constants.
+// Meas and Dyn rows are equalities by construction (l == u), so their rho is rho_eq without a
+// look-up; VO rows go through rho_at() because their bounds switch between +-inf and equality.
+
+// sum over the rows that touch x_k[a] / x_k[3+a] / x_k[6+a] of A(row, col) * w(row), w(row) already
+// carrying the row scaling E[row]
+template <class Q, class WF>
+DEKF_FN double gather_pcol(const Q& q, int k, int a, WF w) {
+    constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
+    double g = 0.0;
+    if (k < q.K - 1) g += w(k * SC + NM + a) + w(k * SC + NM + 9 + a);
+    if (k > 0) g -= w((k - 1) * SC + NM + a) + w((k - 1) * SC + NM + 9 + a);
+    return g;
+}
+template <class Q, class WF>
+DEKF_FN double gather_vcol(const Q& q, int k, int a, WF w) {
+    constexpr int L = Q::LEGS, NM = 3 * L, SC = 12 + NM;
+    double g = 0.0;
+#pragma unroll
+    for (int leg = 0; leg < L; ++leg) g += w(k * SC + 3 * leg + a);
+    if (k < q.K - 1) g += w(k * SC + NM + 3 + a) + q.c.dt * w(k * SC + NM + a);
+    if (k > 0) g -= w((k - 1) * SC + NM + 3 + a);
+    return g;
+}
+template <class Q, class WF>
+DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
+    constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
+    double g = 0.0;
+    if (k < q.K - 1) {
+        const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+        const double* R = q.R + 9 * k;
+        g += w(k * SC + NM + 6 + a);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) g -= R[3 * r + a] * (hdt2 * w(k * SC + NM + r) + dt * w(k * SC + NM + 3 + r));
     }
+    if (k > 0) g -= w((k - 1) * SC + NM + 6 + a);
+    return g;
 }
 
-// One ADMM linear solve.  In: xt = right-hand side (n).  Out: xs = xt on the x blocks (K*9),
-// xt = xt on the slack entries, zt = A xt.
+// In: xt = right-hand side (n), at = u (consumed by the caller).  Out: xs = xt on the x blocks
+// (K*9), at[row] = xt of that row's slack, zt = A xt.
 template <class Q>
-DEKF_FN void solve_linear(Q& q) {
-    const int m = q.m, K = q.K;
-    const auto& ix = q.ix;
-    double *xt = q.xt, *zt = q.zt, *at = q.at, *xs = q.xs;
-    // t = S^-1 rhs_s (kept at the slack's row in zt), h = rho*beta*t (in at)
-    wfor(m, [&](int r) {
-        int k, kind, o;
-        q.dec_row(r, k, kind, o);
-        double t = slack_inv_apply(q, k, kind + 1, o, [&](int var, int) { return xt[var]; });
+DEKF_FN void admm_linear(Q& q) {
+    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM, SC = 12 + NM;
+    const int K = q.K, K1 = q.K - 1;
+    double *xt = q.xt, *zt = q.zt, *at = q.at, *xs = q.xs, *xd = q.xd;
+    const double *D = q.D, *E = q.E;
+    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+
+    // B. slack forward elimination: t = S^-1 rhs_s -> zt[row];  E rho beta t -> at[row]
+    wfor_nosync(K * NM, [&](int e) {  // Meas rows, 3x3 block per leg
+        int k = e / NM, o = e - k * NM, leg = o / 3, a = o - 3 * leg;
+        const double* si = q.Sv + (k * L + leg) * 6;
+        const double* in = xt + k * SV + 9 + 3 * leg;
+        double t = symget(si, a, 0, 3) * in[0] + symget(si, a, 1, 3) * in[1] + symget(si, a, 2, 3) * in[2];
+        int r = k * SC + o;
         zt[r] = t;
-        at[r] = q.rho_at(r) * q.E[r] * q.D[q.row_slack(k, kind, o)] * t;
+        at[r] = rho_eq * E[r] * E[r] * D[k * SV + 9 + o] * t;
     });
-    // reduced right-hand side on the x blocks
+    wfor_nosync(K1 * 6, [&](int e) {  // Dyn rows, position / velocity: 6x6 block
+        int k = e / 6, o = e - 6 * k;
+        const double* sw = q.Sw + k * 24;
+        const double* in = xt + k * SV + 9 + NM;
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) t += symget(sw, o, u, 6) * in[u];
+        int r = k * SC + NM + o;
+        zt[r] = t;
+        at[r] = rho_eq * E[r] * E[r] * D[k * SV + 9 + NM + o] * t;
+    });
+    wfor_nosync(K1 * 3, [&](int e) {  // Dyn rows, bias: diagonal
+        int k = e / 3, a = e - 3 * k;
+        int r = k * SC + NM + 6 + a, sv = k * SV + 9 + NM + 6 + a;
+        double t = q.Sw[k * 24 + 21 + a] * xt[sv];
+        zt[r] = t;
+        at[r] = rho_eq * E[r] * E[r] * D[sv] * t;
+    });
+    wfor(K1 * 3, [&](int e) {  // VO rows, 3x3 block
+        int k = e / 3, a = e - 3 * k;
+        const double* si = q.Sc + k * 6;
+        const double* in = xt + k * SV + 18 + NM;
+        double t = symget(si, a, 0, 3) * in[0] + symget(si, a, 1, 3) * in[1] + symget(si, a, 2, 3) * in[2];
+        int r = k * SC + NM + 9 + a;
+        zt[r] = t;
+        at[r] = q.rho_at(r) * E[r] * E[r] * D[k * SV + 18 + NM + a] * t;
+    });
+    // C. reduced right-hand side on the x blocks
+    auto wh = [&](int r) { return at[r]; };
+    wfor_nosync(K * 3, [&](int e) {
+        int k = e / 3, a = e - 3 * k;
+        xs[9 * k + a] = xt[k * SV + a] + D[k * SV + a] * gather_pcol(q, k, a, wh);
+    });
+    wfor_nosync(K * 3, [&](int e) {
+        int k = e / 3, a = e - 3 * k;
+        xs[9 * k + 3 + a] = xt[k * SV + 3 + a] + D[k * SV + 3 + a] * gather_vcol(q, k, a, wh);
+    });
+    wfor(K * 3, [&](int e) {
+        int k = e / 3, a = e - 3 * k;
+        xs[9 * k + 6 + a] = xt[k * SV + 6 + a] + D[k * SV + 6 + a] * gather_bcol(q, k, a, wh);
+    });
+    // D. block-tridiagonal solve, run by the first wavefront alone (no workgroup barriers):
+    //    forward f_k -= W_{k-1} f_{k-1};  backward u_k = S_k^-1 f_k - W_k' u_{k+1}.  The backward
+    //    results ping-pong through tmp so one step is one phase (f_{k+1} is dead when u_{k+1} lands).
+    if (DEKF_IN_WAVE0()) {
+        for (int k = 1; k < K; ++k) {
+            const double* W = q.Wk + (k - 1) * 81;
+            w0for(9, [&](int i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc += W[9 * i + t] * xs[9 * (k - 1) + t];
+                xs[9 * k + i] -= acc;
+            });
+        }
+        double* ub = q.tmp;  // [2][9]
+        for (int k = K - 1; k >= 0; --k) {
+            const double* Si = q.Sinv + k * 45;
+            const double* W = q.Wk + k * 81;
+            double* un = ub + 9 * (k & 1);
+            const double* up = ub + 9 * ((k + 1) & 1);
+            w0for(9, [&](int i) {
+                double acc = 0.0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) acc += symget(Si, i, t, 9) * xs[9 * k + t];
+                if (k < K - 1) {
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) acc -= W[9 * t + i] * up[t];
+                    xs[9 * (k + 1) + i] = up[i];
+                }
+                un[i] = acc;
+            });
+        }
+        w0for(9, [&](int i) { xs[i] = ub[i]; });
+    }
+    DEKF_SYNC();
+    // E. column-scaled x part
     wfor(K * 9, [&](int e) {
         int k = e / 9, j = e - 9 * k;
-        xs[e] = xt[ix.x(k, j)] + q.gather_x(k, j, at);
+        xd[e] = D[k * SV + j] * xs[e];
     });
-    // block-tridiagonal solve: forward f_k -= W_{k-1} f_{k-1}
-    for (int k = 1; k < K; ++k) {
-        const double* W = q.Wk + (k - 1) * 81;
-        wfor(9, [&](int i) {
-            double acc = 0.0;
-            for (int t = 0; t < 9; ++t) acc += W[9 * i + t] * xs[9 * (k - 1) + t];
-            xs[9 * k + i] -= acc;
-        });
-    }
-    // backward u_k = S_k^-1 f_k - W_k' u_{k+1}; results ping-pong through tmp so that one
-    // phase per step suffices, the last reader of f_k being this very step
-    double* ub = q.tmp;  // [2][9]
-    for (int k = K - 1; k >= 0; --k) {
-        const double* Si = q.Sinv + k * 45;
-        const double* W = q.Wk + k * 81;
-        double* un = ub + 9 * (k & 1);
-        const double* up = ub + 9 * ((k + 1) & 1);
-        wfor(9, [&](int i) {
-            double acc = 0.0;
-            for (int t = 0; t < 9; ++t) acc += symget(Si, i, t, 9) * xs[9 * k + t];
-            if (k < K - 1)
-                for (int t = 0; t < 9; ++t) acc -= W[9 * t + i] * up[t];
-            un[i] = acc;
-            if (k < K - 1) xs[9 * (k + 1) + i] = up[i];  // f_{k+1} is dead: store u_{k+1}
-        });
-    }
-    wfor(9, [&](int i) { xs[i] = ub[i]; });
-    // a = A_x xt_x ; slack back-substitution ; zt = a - beta * s
-    auto xv = [&](int k, int j) { return xs[9 * k + j]; };
-    wfor(m, [&](int r) {
-        int k, kind, o;
-        q.dec_row(r, k, kind, o);
-        at[r] = q.row_dot_x(k, kind, o, xv);
+    // F. a = A_x xt_x -> at[row];  rho beta a -> xt[slack of the row]
+    wfor_nosync(K * NM, [&](int e) {  // Meas
+        int k = e / NM, o = e - k * NM, a = o % 3;
+        int r = k * SC + o, sv = k * SV + 9 + o;
+        double ar = E[r] * xd[9 * k + 3 + a];
+        at[r] = ar;
+        xt[sv] = rho_eq * E[r] * D[sv] * ar;
     });
-    wfor(m, [&](int r) {
-        int k, kind, o;
-        q.dec_row(r, k, kind, o);
-        double corr = slack_inv_apply(q, k, kind + 1, o, [&](int var, int row) { return q.rho_at(row) * q.E[row] * q.D[var] * at[row]; });
-        int sv = q.row_slack(k, kind, o);
-        double sl = zt[r] + corr;
-        xt[sv] = sl;
-        zt[r] = at[r] - q.E[r] * q.D[sv] * sl;
+    wfor_nosync(K1 * 3, [&](int e) {  // Dyn position rows
+        int k = e / 3, a = e - 3 * k;
+        const double* R = q.R + 9 * k + 3 * a;
+        const double* xk = xd + 9 * k;
+        int r = k * SC + NM + a, sv = k * SV + 9 + NM + a;
+        double ar = E[r] * (xk[a] + dt * xk[3 + a] - hdt2 * (R[0] * xk[6] + R[1] * xk[7] + R[2] * xk[8]) - xk[9 + a]);
+        at[r] = ar;
+        xt[sv] = rho_eq * E[r] * D[sv] * ar;
+    });
+    wfor_nosync(K1 * 3, [&](int e) {  // Dyn velocity rows
+        int k = e / 3, a = e - 3 * k;
+        const double* R = q.R + 9 * k + 3 * a;
+        const double* xk = xd + 9 * k;
+        int r = k * SC + NM + 3 + a, sv = k * SV + 9 + NM + 3 + a;
+        double ar = E[r] * (xk[3 + a] - dt * (R[0] * xk[6] + R[1] * xk[7] + R[2] * xk[8]) - xk[12 + a]);
+        at[r] = ar;
+        xt[sv] = rho_eq * E[r] * D[sv] * ar;
+    });
+    wfor_nosync(K1 * 3, [&](int e) {  // Dyn bias rows
+        int k = e / 3, a = e - 3 * k;
+        const double* xk = xd + 9 * k;
+        int r = k * SC + NM + 6 + a, sv = k * SV + 9 + NM + 6 + a;
+        double ar = E[r] * (xk[6 + a] - xk[15 + a]);
+        at[r] = ar;
+        xt[sv] = rho_eq * E[r] * D[sv] * ar;
+    });
+    wfor(K1 * 3, [&](int e) {  // VO rows
+        int k = e / 3, a = e - 3 * k;
+        const double* xk = xd + 9 * k;
+        int r = k * SC + NM + 9 + a, sv = k * SV + 18 + NM + a;
+        double ar = E[r] * (xk[a] - xk[9 + a]);
+        at[r] = ar;
+        xt[sv] = q.rho_at(r) * E[r] * D[sv] * ar;
+    });
+    // G. slack back-substitution s = t + S^-1 (rho beta a) -> at[row];  zt = a - beta s
+    wfor_nosync(K * NM, [&](int e) {
+        int k = e / NM, o = e - k * NM, leg = o / 3, a = o - 3 * leg;
+        const double* si = q.Sv + (k * L + leg) * 6;
+        const double* in = xt + k * SV + 9 + 3 * leg;
+        int r = k * SC + o;
+        double sl = zt[r] + symget(si, a, 0, 3) * in[0] + symget(si, a, 1, 3) * in[1] + symget(si, a, 2, 3) * in[2];
+        zt[r] = at[r] - E[r] * D[k * SV + 9 + o] * sl;
+        at[r] = sl;
+    });
+    wfor_nosync(K1 * 6, [&](int e) {
+        int k = e / 6, o = e - 6 * k;
+        const double* sw = q.Sw + k * 24;
+        const double* in = xt + k * SV + 9 + NM;
+        int r = k * SC + NM + o;
+        double sl = zt[r];
+#pragma unroll
+        for (int u = 0; u < 6; ++u) sl += symget(sw, o, u, 6) * in[u];
+        zt[r] = at[r] - E[r] * D[k * SV + 9 + NM + o] * sl;
+        at[r] = sl;
+    });
+    wfor_nosync(K1 * 3, [&](int e) {
+        int k = e / 3, a = e - 3 * k;
+        int r = k * SC + NM + 6 + a, sv = k * SV + 9 + NM + 6 + a;
+        double sl = zt[r] + q.Sw[k * 24 + 21 + a] * xt[sv];
+        zt[r] = at[r] - E[r] * D[sv] * sl;
+        at[r] = sl;
+    });
+    wfor(K1 * 3, [&](int e) {
+        int k = e / 3, a = e - 3 * k;
+        const double* si = q.Sc + k * 6;
+        const double* in = xt + k * SV + 18 + NM;
+        int r = k * SC + NM + 9 + a;
+        double sl = zt[r] + symget(si, a, 0, 3) * in[0] + symget(si, a, 1, 3) * in[1] + symget(si, a, 2, 3) * in[2];
+        zt[r] = at[r] - E[r] * D[k * SV + 18 + NM + a] * sl;
+        at[r] = sl;
     });
 }
 
@@ -561,6 +696,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         q.zt = p; p += lay.m_pad;
         q.at = p; p += lay.m_pad;
         q.xs = p; p += 9 * c.N;
+        q.xd = p; p += 9 * c.N;
         q.tmp = p; p += SOLVE_TMP;
         if constexpr (FACTOR_LDS) {
             q.D = p; p += lay.n_pad;
@@ -611,47 +747,61 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     });
     bool ok = solve_factor(q);
     wfor(m, [&](int r) { at[r] = 0.0; });  // PA may alias at
-    double qs[9];  // scaled linear cost on x_0
+    double qs[9];  // scaled linear cost on x_0 (registers for the checks, LDS copy for the per-lane look-ups)
     for (int j = 0; j < 9; ++j) qs[j] = q.cc * q.D[ix.x(0, j)] * q.np[j];
+    wfor(9, [&](int j) { q.tmp[162 + j] = q.cc * q.D[ix.x(0, j)] * q.np[j]; });
     const double sigma = c.sigma, alpha = c.alpha;
     const double cinv = 1.0 / q.cc;
     int iter = 0;
     bool done = false;
     while (ok && !done && iter < c.max_iter) {
         ++iter;
-        // right-hand side: sigma x - q + A'u, u = rho z - y (left in `at` by the previous update)
-        wfor(n, [&](int i) {
-            int k, kind, o;
-            q.dec_var(i, k, kind, o);
-            double v = sigma * x[i];
-            if (kind == 0) {
-                if (k == 0) v -= qs[o];
-                v += q.gather_x(k, o, at);
-            } else {
-                int r = q.slack_row(k, kind, o);
-                v -= q.E[r] * q.D[i] * at[r];
-            }
-            xt[i] = v;
-        });
-        solve_linear(q);
-        // x, z, y updates (alpha relaxation, projection onto [lo, hi]); u for the next iteration
-        wfor(n + m, [&](int e) {
-            if (e < n) {
-                int k, kind, o;
-                q.dec_var(e, k, kind, o);
-                double xn = kind == 0 ? q.xs[9 * k + o] : xt[e];
-                x[e] = alpha * xn + (1.0 - alpha) * x[e];
-            } else {
-                int r = e - n;
-                double rv = q.rho_at(r);
+        // A. right-hand side: sigma x - q + A'u, u = rho z - y (left in `at` by the previous update)
+        {
+            constexpr int NM = 3 * L, SV = 21 + NM, SC = 12 + NM;
+            const double *D = q.D, *E = q.E;
+            const double* qsl = q.tmp + 162;
+            auto wu = [&](int r) { return E[r] * at[r]; };
+            wfor_nosync(m, [&](int r) {  // every slack lives in exactly one row: slack = k*SV + 9 + (r - k*SC)
+                int k = r / SC, sv = k * SV + 9 + (r - k * SC);
+                xt[sv] = sigma * x[sv] - E[r] * D[sv] * at[r];
+            });
+            wfor_nosync(K * 3, [&](int e) {
+                int k = e / 3, a = e - 3 * k, i = k * SV + a;
+                xt[i] = sigma * x[i] - (k == 0 ? qsl[a] : 0.0) + D[i] * gather_pcol(q, k, a, wu);
+            });
+            wfor_nosync(K * 3, [&](int e) {
+                int k = e / 3, a = e - 3 * k, i = k * SV + 3 + a;
+                xt[i] = sigma * x[i] - (k == 0 ? qsl[3 + a] : 0.0) + D[i] * gather_vcol(q, k, a, wu);
+            });
+            wfor(K * 3, [&](int e) {
+                int k = e / 3, a = e - 3 * k, i = k * SV + 6 + a;
+                xt[i] = sigma * x[i] - (k == 0 ? qsl[6 + a] : 0.0) + D[i] * gather_bcol(q, k, a, wu);
+            });
+        }
+        admm_linear(q);
+        // H. x, z, y updates (alpha relaxation, projection onto [lo, hi]); u for the next iteration
+        {
+            constexpr int NM = 3 * L, SV = 21 + NM, SC = 12 + NM;
+            const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho, rho_eq_inv = 1.0 / rho_eq;
+            wfor_nosync(K * 9, [&](int e) {
+                int k = e / 9, i = k * SV + (e - 9 * k);
+                x[i] = alpha * q.xs[e] + (1.0 - alpha) * x[i];
+            });
+            wfor(m, [&](int r) {
+                int k = r / SC, qq = r - k * SC, sv = k * SV + 9 + qq;
+                x[sv] = alpha * at[r] + (1.0 - alpha) * x[sv];
+                bool eq = qq < NM + 9;
+                double rv = eq ? rho_eq : q.rho_at(r);
+                double rinv = eq ? rho_eq_inv : 1.0 / rv;
                 double zh = alpha * zt[r] + (1.0 - alpha) * z[r];
-                double zn = dmin(dmax(zh + y[r] / rv, q.lo[r]), q.hi[r]);
+                double zn = dmin(dmax(zh + rinv * y[r], q.lo[r]), q.hi[r]);
                 double yn = y[r] + rv * (zh - zn);
                 y[r] = yn;
                 z[r] = zn;
                 at[r] = rv * zn - yn;
-            }
-        });
+            });
+        }
         bool can_check = c.check_termination > 0 && (iter % c.check_termination == 0);
         bool adapt_now = c.adaptive_rho && c.adaptive_rho_interval > 0 && (iter % c.adaptive_rho_interval == 0);
         if (can_check || adapt_now || iter == c.max_iter) {

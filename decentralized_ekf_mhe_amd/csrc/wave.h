@@ -179,6 +179,29 @@ inline int wred_argmax(int n, F f, double* best_out) {
 }
 #endif
 
+// Serial sections run by the first wavefront alone (the other wavefronts skip to the next group
+// sync): inside `if (DEKF_IN_WAVE0()) { ... }`, w0for(n, f) runs f(0..n-1) on n <= 64 lanes and
+// orders its LDS traffic against the next w0for with a wave-level fence — no s_barrier.
+#if DEKF_DEVICE_BUILD
+#define DEKF_IN_WAVE0() (threadIdx.x < 64)
+DEKF_FN void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+template <class F>
+DEKF_FN void w0for(int n, F f) {
+    if (DEKF_LANE() < n) f(DEKF_LANE());
+    wave_sync();
+}
+#else
+#define DEKF_IN_WAVE0() true
+template <class F>
+inline void w0for(int n, F f) {
+    for (int i = 0; i < n; ++i) f(i);
+}
+#endif
+
 DEKF_FN double dmax(double a, double b) { return a > b ? a : b; }
 DEKF_FN double dmin(double a, double b) { return a < b ? a : b; }
 

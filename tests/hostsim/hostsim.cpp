@@ -135,7 +135,7 @@ void hs_get_scaling(void* hv, int n, int m, double* D, double* E) {
     const double* Dp = h->s.gws + g.D;
     const double* Ep = h->s.gws + g.E;
     if (lay.factor_in_lds()) {  // same carve order as solve_window
-        Dp = h->lds.data() + 2 * lay.n_pad + 4 * lay.m_pad + 9 * h->c.N + SOLVE_TMP;
+        Dp = h->lds.data() + 2 * lay.n_pad + 4 * lay.m_pad + 18 * h->c.N + SOLVE_TMP;
         Ep = Dp + lay.n_pad;
     }
     std::memcpy(D, Dp, (size_t)n * 8); std::memcpy(E, Ep, (size_t)m * 8);
