@@ -9,7 +9,8 @@ import os
 from .params import DekfParams
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdekf.so")
+# DEKF_LIB lets tools/profile_sections.py point at the diagnostic build (libdekf_prof.so)
+LIB_PATH = os.environ.get("DEKF_LIB", os.path.join(_HERE, "csrc", "libdekf.so"))
 
 DEKF_OK, DEKF_ERR_INVALID, DEKF_ERR_NO_DEVICE, DEKF_ERR_HIP, DEKF_ERR_ORDER, DEKF_ERR_COMM = range(6)
 DEKF_HOST, DEKF_DEVICE = 0, 1

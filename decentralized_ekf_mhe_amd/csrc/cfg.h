@@ -131,6 +131,7 @@ struct DevState {
     double *x_mhe, *v_b;
     int *status, *iters, *rho_updates;
     double *pri_res, *dua_res;
+    double* prof;  // [B][16] section cycles, written by the diagnostic (-DDEKF_PROFILE) build only
 };
 
 }  // namespace dekf

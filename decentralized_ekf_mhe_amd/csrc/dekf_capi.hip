@@ -444,6 +444,15 @@ dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches) {
     return DEKF_OK;
 }
 
+// not part of include/dekf.h: section cycles [B][16] of the last solve; all zero unless this
+// library was built with -DDEKF_PROFILE (libdekf_prof.so, tools/profile_sections.py)
+dekf_status dekf_debug_sections(dekf_handle h, double* out_host) {
+    if (!h || !out_host) return fail(DEKF_ERR_INVALID, "null argument");
+    HIPCHK(hipMemcpyAsync(out_host, h->s.prof, 16 * (size_t)h->c.B * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return DEKF_OK;
+}
+
 // ---------------------------------------------------------------- RCCL all-gather
 dekf_status dekf_comm_unique_id(void* id_out) {
     if (!id_out) return fail(DEKF_ERR_INVALID, "null argument");

@@ -119,6 +119,7 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
     s.x_mhe = D(9 * B); s.v_b = D(3 * B);
     s.status = I(B); s.iters = I(B); s.rho_updates = I(B);
     s.pri_res = D(B); s.dua_res = D(B);
+    s.prof = D(16 * B);
 }
 
 }  // namespace dekf

@@ -30,6 +30,21 @@
 
 namespace dekf {
 
+// Section stamps for the DIAGNOSTIC build only (-DDEKF_PROFILE -> libdekf_prof.so); the product
+// kernel executes none of this.  Stamp values go to DevState::prof and nowhere else.
+#if defined(DEKF_PROFILE) && DEKF_DEVICE_BUILD
+#define DEKF_PROF_MARK(q, sec)                                                  \
+    do {                                                                        \
+        if (DEKF_LANE() == 0) {                                                 \
+            long long now_ = clock64();                                         \
+            (q).prof[sec] += (double)(now_ - (q).prof_last);                    \
+            (q).prof_last = now_;                                               \
+        }                                                                       \
+    } while (0)
+#else
+#define DEKF_PROF_MARK(q, sec) ((void)0)
+#endif
+
 constexpr int SOLVE_TMP = 176;  // [0,18) sweep ping-pong, [162,171) scaled q; at factor time [0,162) = 2 x 81 Gauss-Jordan
 
 // how many doubles of LDS a solve needs in each placement mode
@@ -82,6 +97,8 @@ struct SolveCtx {
     const double *Mp, *np;
     double cc;   // cost scaling c
     double rho;  // current scalar rho
+    double* prof;         // diagnostic build only
+    long long prof_last;  // diagnostic build only
 
     DEKF_FN const double* rec(int k) const {
         return s.rec + ((size_t)b * c.wcap + ((kstart + k) % c.wcap)) * c.rec;
@@ -490,6 +507,76 @@ DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
     return g;
 }
 
+#if DEKF_DEVICE_BUILD
+// Block-tridiagonal forward / backward sweeps with the running 9-vector held in registers of
+// lanes 0..8 of the first wavefront and broadcast with v_readlane: the dependent chain of one
+// step is 18 v_readlane + 9 FMA, with no LDS store->load round trip and therefore no exposure to
+// the LDS queue the other wavefronts keep busy.  Same arithmetic as the w0for form in
+// admm_linear (tests/hostsim runs that one); lanes >= 9 mirror lane 8 and never store.
+DEKF_FN double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+template <class Q>
+DEKF_FN void tri_sweeps_registers(Q& q) {
+    constexpr int SV = 21 + 3 * Q::LEGS;
+    const int K = q.K;
+    double *xs = q.xs, *xd = q.xd;
+    const int lane = DEKF_LANE();
+    const int i = lane < 9 ? lane : 8;
+    const bool act = lane < 9;
+    double f = xs[i];
+    for (int k = 1; k < K; ++k) {
+        const double* wr = q.Wk + (k - 1) * 81 + 9 * i;
+        double w[9], ft[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = wr[t];
+        double b = xs[9 * k + i];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) ft[t] = readlane_f64(f, t);
+        double a0 = w[0] * ft[0] + w[3] * ft[3] + w[6] * ft[6];
+        double a1 = w[1] * ft[1] + w[4] * ft[4] + w[7] * ft[7];
+        double a2 = w[2] * ft[2] + w[5] * ft[5] + w[8] * ft[8];
+        f = b - (a0 + a1 + a2);
+        if (act) xs[9 * k + i] = f;
+    }
+    wave_sync();
+    for (int e = lane; e < K * 9; e += WAVE) {  // g_k = S_k^-1 f_k, all k at once
+        int k = e / 9, r = e - 9 * k;
+        const double* Si = q.Sinv + k * 45;
+        const double* fk = xs + 9 * k;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; t += 3) {
+            a0 += symget(Si, r, t, 9) * fk[t];
+            a1 += symget(Si, r, t + 1, 9) * fk[t + 1];
+            a2 += symget(Si, r, t + 2, 9) * fk[t + 2];
+        }
+        xd[e] = a0 + a1 + a2;
+    }
+    wave_sync();
+    double u = xd[9 * (K - 1) + i];
+    if (act) { xs[9 * (K - 1) + i] = u; xd[9 * (K - 1) + i] = q.D[(K - 1) * SV + i] * u; }
+    for (int k = K - 2; k >= 0; --k) {
+        const double* W = q.Wk + k * 81;
+        double w[9], ut[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = W[9 * t + i];
+        double g = xd[9 * k + i];
+        double dk = q.D[k * SV + i];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) ut[t] = readlane_f64(u, t);
+        double a0 = w[0] * ut[0] + w[3] * ut[3] + w[6] * ut[6];
+        double a1 = w[1] * ut[1] + w[4] * ut[4] + w[7] * ut[7];
+        double a2 = w[2] * ut[2] + w[5] * ut[5] + w[8] * ut[8];
+        u = g - (a0 + a1 + a2);
+        if (act) { xs[9 * k + i] = u; xd[9 * k + i] = dk * u; }
+    }
+}
+#endif
+
 // In: xt = right-hand side (n), at = u (consumed by the caller).  Out: xs = xt on the x blocks
 // (K*9), at[row] = xt of that row's slack, zt = A xt.
 template <class Q>
@@ -538,6 +625,7 @@ DEKF_FN void admm_linear(Q& q) {
         zt[r] = t;
         at[r] = q.rho_at(r) * E[r] * E[r] * D[k * SV + 18 + NM + a] * t;
     });
+    DEKF_PROF_MARK(q, 3);
     // C. reduced right-hand side on the x blocks
     auto wh = [&](int r) { return at[r]; };
     wfor_nosync(K * 3, [&](int e) {
@@ -552,45 +640,58 @@ DEKF_FN void admm_linear(Q& q) {
         int k = e / 3, a = e - 3 * k;
         xs[9 * k + 6 + a] = xt[k * SV + 6 + a] + D[k * SV + 6 + a] * gather_bcol(q, k, a, wh);
     });
+    DEKF_PROF_MARK(q, 4);
     // D. block-tridiagonal solve, run by the first wavefront alone (no workgroup barriers):
-    //    forward f_k -= W_{k-1} f_{k-1};  backward u_k = S_k^-1 f_k - W_k' u_{k+1}.  The backward
-    //    results ping-pong through tmp so one step is one phase (f_{k+1} is dead when u_{k+1} lands).
+    //    forward f_k -= W_{k-1} f_{k-1};  g_k = S_k^-1 f_k for all k at once (it does not depend on
+    //    the backward recursion);  backward u_k = g_k - W_k' u_{k+1}.  Leaves xs = u, xd = D .* u.
+#if DEKF_DEVICE_BUILD
+    if (DEKF_IN_WAVE0()) tri_sweeps_registers(q);
+#else
     if (DEKF_IN_WAVE0()) {
         for (int k = 1; k < K; ++k) {
             const double* W = q.Wk + (k - 1) * 81;
             w0for(9, [&](int i) {
-                double acc = 0.0;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc += W[9 * i + t] * xs[9 * (k - 1) + t];
-                xs[9 * k + i] -= acc;
+                const double* wr = W + 9 * i;
+                const double* f = xs + 9 * (k - 1);
+                double a0 = wr[0] * f[0] + wr[3] * f[3] + wr[6] * f[6];
+                double a1 = wr[1] * f[1] + wr[4] * f[4] + wr[7] * f[7];
+                double a2 = wr[2] * f[2] + wr[5] * f[5] + wr[8] * f[8];
+                xs[9 * k + i] -= a0 + a1 + a2;
             });
         }
-        double* ub = q.tmp;  // [2][9]
-        for (int k = K - 1; k >= 0; --k) {
+        w0for(K * 9, [&](int e) {
+            int k = e / 9, i = e - 9 * k;
             const double* Si = q.Sinv + k * 45;
+            const double* f = xs + 9 * k;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int t = 0; t < 9; t += 3) {
+                a0 += symget(Si, i, t, 9) * f[t];
+                a1 += symget(Si, i, t + 1, 9) * f[t + 1];
+                a2 += symget(Si, i, t + 2, 9) * f[t + 2];
+            }
+            xd[e] = a0 + a1 + a2;
+        });
+        w0for(9, [&](int i) {
+            double u = xd[9 * (K - 1) + i];
+            xs[9 * (K - 1) + i] = u;
+            xd[9 * (K - 1) + i] = D[(K - 1) * SV + i] * u;
+        });
+        for (int k = K - 2; k >= 0; --k) {
             const double* W = q.Wk + k * 81;
-            double* un = ub + 9 * (k & 1);
-            const double* up = ub + 9 * ((k + 1) & 1);
             w0for(9, [&](int i) {
-                double acc = 0.0;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) acc += symget(Si, i, t, 9) * xs[9 * k + t];
-                if (k < K - 1) {
-#pragma unroll
-                    for (int t = 0; t < 9; ++t) acc -= W[9 * t + i] * up[t];
-                    xs[9 * (k + 1) + i] = up[i];
-                }
-                un[i] = acc;
+                const double* u = xs + 9 * (k + 1);
+                double a0 = W[i] * u[0] + W[27 + i] * u[3] + W[54 + i] * u[6];
+                double a1 = W[9 + i] * u[1] + W[36 + i] * u[4] + W[63 + i] * u[7];
+                double a2 = W[18 + i] * u[2] + W[45 + i] * u[5] + W[72 + i] * u[8];
+                double uk = xd[9 * k + i] - (a0 + a1 + a2);
+                xs[9 * k + i] = uk;
+                xd[9 * k + i] = D[k * SV + i] * uk;
             });
         }
-        w0for(9, [&](int i) { xs[i] = ub[i]; });
     }
+#endif
     DEKF_SYNC();
-    // E. column-scaled x part
-    wfor(K * 9, [&](int e) {
-        int k = e / 9, j = e - 9 * k;
-        xd[e] = D[k * SV + j] * xs[e];
-    });
+    DEKF_PROF_MARK(q, 5);
     // F. a = A_x xt_x -> at[row];  rho beta a -> xt[slack of the row]
     wfor_nosync(K * NM, [&](int e) {  // Meas
         int k = e / NM, o = e - k * NM, a = o % 3;
@@ -633,6 +734,7 @@ DEKF_FN void admm_linear(Q& q) {
         at[r] = ar;
         xt[sv] = q.rho_at(r) * E[r] * D[sv] * ar;
     });
+    DEKF_PROF_MARK(q, 7);
     // G. slack back-substitution s = t + S^-1 (rho beta a) -> at[row];  zt = a - beta s
     wfor_nosync(K * NM, [&](int e) {
         int k = e / NM, o = e - k * NM, leg = o / 3, a = o - 3 * leg;
@@ -670,6 +772,7 @@ DEKF_FN void admm_linear(Q& q) {
         zt[r] = at[r] - E[r] * D[k * SV + 18 + NM + a] * sl;
         at[r] = sl;
     });
+    DEKF_PROF_MARK(q, 8);
 }
 
 struct SolveInfo {
@@ -727,9 +830,17 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     const auto& ix = q.ix;
     SolveInfo info{0, DEKF_SOLVE_MAX_ITER, 0, 0.0, 0.0, c.rho0};
 
+    q.prof = s.prof + 16 * (size_t)b;
+#if defined(DEKF_PROFILE) && DEKF_DEVICE_BUILD
+    q.prof_last = clock64();
+    const long long prof_t0 = q.prof_last;
+    if (DEKF_LANE() == 0)
+        for (int i = 0; i < 16; ++i) q.prof[i] = 0.0;
+#endif
     wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });
     if (c.scaling > 0) solve_scale(q);
     else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
+    DEKF_PROF_MARK(q, 0);
     q.rho = dmin(dmax(c.rho0, RHO_MIN), RHO_MAX);
     // scaled bounds, cold start
     double *x = q.x, *z = q.z, *y = q.y, *xt = q.xt, *zt = q.zt, *at = q.at;
@@ -746,7 +857,10 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         at[r] = 0.0;  // u = rho z - y of the cold start
     });
     bool ok = solve_factor(q);
-    wfor(m, [&](int r) { at[r] = 0.0; });  // PA may alias at
+    wfor(n + m, [&](int e) {  // cold start: u = 0 and a zero right-hand side (PA may have aliased xt | zt | at)
+        if (e < n) xt[e] = 0.0;
+        else at[e - n] = 0.0;
+    });
     double qs[9];  // scaled linear cost on x_0 (registers for the checks, LDS copy for the per-lane look-ups)
     for (int j = 0; j < 9; ++j) qs[j] = q.cc * q.D[ix.x(0, j)] * q.np[j];
     wfor(9, [&](int j) { q.tmp[162 + j] = q.cc * q.D[ix.x(0, j)] * q.np[j]; });
@@ -754,18 +868,16 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     const double cinv = 1.0 / q.cc;
     int iter = 0;
     bool done = false;
+    DEKF_PROF_MARK(q, 1);
     while (ok && !done && iter < c.max_iter) {
         ++iter;
-        // A. right-hand side: sigma x - q + A'u, u = rho z - y (left in `at` by the previous update)
+        // A. right-hand side sigma x - q + A'u on the x columns (u = rho z - y sits in `at`; the slack
+        //    entries of the right-hand side were written together with u by the previous update)
         {
-            constexpr int NM = 3 * L, SV = 21 + NM, SC = 12 + NM;
+            constexpr int NM = 3 * L, SV = 21 + NM;
             const double *D = q.D, *E = q.E;
             const double* qsl = q.tmp + 162;
             auto wu = [&](int r) { return E[r] * at[r]; };
-            wfor_nosync(m, [&](int r) {  // every slack lives in exactly one row: slack = k*SV + 9 + (r - k*SC)
-                int k = r / SC, sv = k * SV + 9 + (r - k * SC);
-                xt[sv] = sigma * x[sv] - E[r] * D[sv] * at[r];
-            });
             wfor_nosync(K * 3, [&](int e) {
                 int k = e / 3, a = e - 3 * k, i = k * SV + a;
                 xt[i] = sigma * x[i] - (k == 0 ? qsl[a] : 0.0) + D[i] * gather_pcol(q, k, a, wu);
@@ -779,8 +891,10 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
                 xt[i] = sigma * x[i] - (k == 0 ? qsl[6 + a] : 0.0) + D[i] * gather_bcol(q, k, a, wu);
             });
         }
+        DEKF_PROF_MARK(q, 2);
         admm_linear(q);
-        // H. x, z, y updates (alpha relaxation, projection onto [lo, hi]); u for the next iteration
+        // H. x, z, y updates (alpha relaxation, projection onto [lo, hi]); u and the slack part of
+        //    the next right-hand side (every slack lives in exactly one row: slack = k*SV + 9 + q)
         {
             constexpr int NM = 3 * L, SV = 21 + NM, SC = 12 + NM;
             const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho, rho_eq_inv = 1.0 / rho_eq;
@@ -799,9 +913,12 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
                 double yn = y[r] + rv * (zh - zn);
                 y[r] = yn;
                 z[r] = zn;
-                at[r] = rv * zn - yn;
+                double un = rv * zn - yn;
+                at[r] = un;
+                xt[sv] = sigma * x[sv] - q.E[r] * q.D[sv] * un;
             });
         }
+        DEKF_PROF_MARK(q, 9);
         bool can_check = c.check_termination > 0 && (iter % c.check_termination == 0);
         bool adapt_now = c.adaptive_rho && c.adaptive_rho_interval > 0 && (iter % c.adaptive_rho_interval == 0);
         if (can_check || adapt_now || iter == c.max_iter) {
@@ -851,6 +968,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
                 double eps_dua = c.eps_abs + c.eps_rel * cinv * dmax(va[1], dmax(va[2], va[3]));
                 if (info.pri_res < eps_pri && info.dua_res < eps_dua) { info.status = DEKF_SOLVE_OK; done = true; }
             }
+            DEKF_PROF_MARK(q, 10);
             if (!done && adapt_now) {
                 double pr = ra[3] / (dmax(ra[4], ra[5]) + 1e-10);
                 double du = va[4] / (dmax(va[5], dmax(va[6], va[7])) + 1e-10);
@@ -860,7 +978,14 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
                     info.rho_updates++;
                     DEKF_SYNC();
                     ok = solve_factor(q);
-                    wfor(m, [&](int r) { at[r] = q.rho_at(r) * z[r] - y[r]; });
+                    wfor(m, [&](int r) {  // the factorisation scratch may alias xt | zt | at
+                        constexpr int SVc = 21 + 3 * L, SCc = 12 + 3 * L;
+                        int k = r / SCc, sv = k * SVc + 9 + (r - k * SCc);
+                        double un = q.rho_at(r) * z[r] - y[r];
+                        at[r] = un;
+                        xt[sv] = sigma * x[sv] - q.E[r] * q.D[sv] * un;
+                    });
+                    DEKF_PROF_MARK(q, 11);
                 }
             }
         }
@@ -891,6 +1016,10 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         s.dua_res[b] = info.dua_res;
     }
     DEKF_SYNC();
+#if defined(DEKF_PROFILE) && DEKF_DEVICE_BUILD
+    DEKF_PROF_MARK(q, 12);
+    if (DEKF_LANE() == 0) q.prof[13] = (double)(clock64() - prof_t0);
+#endif
     return info;
 }
 

@@ -191,7 +191,7 @@ DEKF_FN void wave_sync() {
 }
 template <class F>
 DEKF_FN void w0for(int n, F f) {
-    if (DEKF_LANE() < n) f(DEKF_LANE());
+    for (int i = DEKF_LANE(); i < n; i += WAVE) f(i);
     wave_sync();
 }
 #else

@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Where does one MHE solve spend its cycles?  Runs the DIAGNOSTIC build of the library
+(csrc/libdekf_prof.so, -DDEKF_PROFILE: s_memtime stamps at every phase boundary, written to a
+debug buffer only) on the bench workload and prints the share of each section.  Never quote the
+absolute time of this build; read the shares.
+
+    DEKF_LIB=decentralized_ekf_mhe_amd/csrc/libdekf_prof.so python tools/profile_sections.py
+"""
+import ctypes as C
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("DEKF_LIB", os.path.join(ROOT, "decentralized_ekf_mhe_amd", "csrc", "libdekf_prof.so"))
+
+from decentralized_ekf_mhe_amd import capi, go1_params  # noqa: E402
+from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_device  # noqa: E402
+from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
+
+NAMES = ["0 copy R + Ruiz scaling", "1 bounds + first factorisation", "2 A: right-hand side", "3 B: slack forward",
+         "4 C: gather to x blocks", "5 D: tridiagonal sweeps (wave 0)", "6 E: D.*x", "7 F: rows A_x x",
+         "8 G: slack back-substitution", "9 H: x/z/y update", "10 residuals + termination", "11 rho update + refactor",
+         "12 epilogue", "13 total"]
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    p = go1_params()
+    p.ekf_rate = p.rate
+    s = make_streams(p, B, K)
+    sd = streams_to_device(s)
+    est = BatchedEstimator(p, B)
+    for k in range(K):
+        est.push_stream_step(sd, k)
+        est.step(k)
+    est.sync()
+    lib = capi.load()
+    out = np.zeros((B, 16))
+    lib.dekf_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
+    capi.check(lib.dekf_debug_sections(est.h, C.c_void_p(out.ctypes.data)))
+    info = est.solver_info()
+    mean = out.mean(axis=0)
+    tot = mean[13]
+    res = {"batch": B, "T": K - 1, "mean_iters": float(info["iters"].mean()), "mean_rho_updates": float(info["rho_updates"].mean()),
+           "total_cycles_mean": tot, "sections": {}}
+    for i, nme in enumerate(NAMES[:13]):
+        res["sections"][nme] = {"cycles": mean[i], "share": mean[i] / tot if tot else 0.0}
+        print(f"{nme:38s} {mean[i]:12.0f} cyc  {100 * mean[i] / max(tot, 1):5.1f} %")
+    print(f"{'total':38s} {tot:12.0f} cyc   iters {res['mean_iters']:.1f}  rho updates {res['mean_rho_updates']:.2f}")
+    print(json.dumps(res))
+    est.close()
+
+
+if __name__ == "__main__":
+    main()
