@@ -31,6 +31,17 @@ B_ALG_GO1 = 5736
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def measured_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes
+    (profiles/traffic_k_mhe_solve.json, produced by tools/collect_traffic.sh); None if absent"""
+    path = os.path.join(ROOT, "profiles", "traffic_k_mhe_solve.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def cpu_baseline(params, steps, seed_first):
     """the oracle (CPU restatement of the reference algorithm) timed on this host's cores"""
     import oracle_lib
@@ -141,7 +152,8 @@ def main():
                        "robot": "go1", "legs": 4, "N": int(p.N), "batch_per_gpu": B, "global_batch": world * B,
                        "eps": 1e-6, "parallelism": f"instances sharded x{world}, RCCL all-gather of v_b per step"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": measured_traffic() if (B == 4096 and world == 1) else None,
                          "kernel": "k_mhe_solve", "avg_launch_ms": avg_solve_s * 1e3, "launches": solve_n,
                          "alg_bytes_per_step": B_ALG_GO1, "units_per_launch": B},
             "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items()},
