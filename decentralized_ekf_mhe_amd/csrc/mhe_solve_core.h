@@ -97,6 +97,8 @@ struct SolveCtx {
     const double *Mp, *np;
     double cc;   // cost scaling c
     double rho;  // current scalar rho
+    double* Pst;  // unscaled P blocks staged by solve_scale (aliases Sinv | Wk until the first factorisation)
+    bool staged;  // Pst valid
     double* prof;         // diagnostic build only
     long long prof_last;  // diagnostic build only
 
@@ -247,27 +249,154 @@ DEKF_FN double limit_scaling(double v) {
 }
 
 // Ruiz equilibration + cost scaling (OSQP scale_data), on the structured QP
+//
+// The unscaled P blocks (Q_meas, Q_dyn, Q_cam per step, M on x_0) are staged once into `q.Pst`
+// (it aliases the S^-1 / W arrays, which are dead until the factorisation), the P column norms are
+// cached in `q.x` (dead until the cold start) and every norm loop is kind-homogeneous, so the ten
+// passes touch LDS only.  Pst stays valid for step 3a of the FIRST factorisation.
+// stage the unscaled P blocks from the HBM window records into q.Pst:
+// per step [Qm 6L | Qd 21 | Qc 6], then M (upper triangle, packed 45)
+template <class Q>
+DEKF_FN void stage_p(Q& q) {
+    constexpr int L = Q::LEGS, NM = 3 * L, PS = 6 * L + 27;
+    const int K = q.K;
+    double* Pst = q.Pst;
+    wfor(K * PS + 45, [&](int e) {
+        if (e < K * PS) {
+            int k = e / PS, o = e - k * PS;
+            const double* r = q.rec(k);
+            Pst[e] = o < 6 * L ? r[Rec::qm(NM) + o] : (o < 6 * L + 21 ? r[Rec::QD + o - 6 * L] : r[Rec::QC + o - 6 * L - 21]);
+        } else {
+            int p = e - K * PS, i = 0;
+            while (p >= 9 - i) { p -= 9 - i; ++i; }
+            Pst[e] = q.Mp[9 * i + i + p];
+        }
+    });
+    q.staged = true;
+}
+
 template <class Q>
 DEKF_FN void solve_scale(Q& q) {
-    const int n = q.n, m = q.m;
-    wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; });
-    q.cc = 1.0;
+    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM, SC = 12 + NM, PS = 6 * L + 27;
+    const int n = q.n, m = q.m, K = q.K, K1 = q.K - 1;
+    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    double *D = q.D, *E = q.E, *Pst = q.Pst, *pc = q.x, *Dt = q.xt, *Et = q.zt;
     const double* g = q.np;
-    for (int it = 0; it < q.c.scaling; ++it) {
-        wfor(n + m, [&](int e) {
-            if (e < n) {
-                double v = dmax(q.p_apply(e, nullptr, true), q.a_colnorm(e));
-                q.xt[e] = 1.0 / sqrt(limit_scaling(v));
-            } else {
-                q.zt[e - n] = 1.0 / sqrt(limit_scaling(q.a_rownorm(e - n)));
-            }
+    stage_p(q);
+    wfor(n + m, [&](int e) { if (e < n) D[e] = 1.0; else E[e - n] = 1.0; });
+    q.cc = 1.0;
+    const double* Mst = Pst + K * PS;
+    // inf-norm of every column of c D P D -> pc[] (cc excluded: multiplied in where it is used)
+    auto pnorms = [&]() {
+        wfor_nosync(K * 9, [&](int e) {  // x columns: only x_0 carries a Hessian (the arrival cost)
+            int k = e / 9, j = e - 9 * k;
+            double v = 0.0;
+            if (k == 0)
+                for (int t = 0; t < 9; ++t) v = dmax(v, fabs(D[j] * symget(Mst, j, t, 9) * D[t]));
+            pc[k * SV + j] = v;
         });
-        wfor(n + m, [&](int e) { if (e < n) q.D[e] *= q.xt[e]; else q.E[e - n] *= q.zt[e - n]; });
-        double psum = wred_sum(n, [&](int i) { return q.p_apply(i, nullptr, true); });
+        wfor_nosync(K * NM, [&](int e) {  // v columns
+            int k = e / NM, o = e - k * NM, leg = o / 3, a = o - 3 * leg;
+            const double* q6 = Pst + k * PS + 6 * leg;
+            const double* d = D + k * SV + 9 + 3 * leg;
+            double v = dmax(fabs(symget(q6, a, 0, 3) * d[0]), dmax(fabs(symget(q6, a, 1, 3) * d[1]), fabs(symget(q6, a, 2, 3) * d[2])));
+            pc[k * SV + 9 + o] = v * d[a];
+        });
+        wfor_nosync(K1 * 9, [&](int e) {  // w columns
+            int k = e / 9, o = e - 9 * k;
+            const double* d = D + k * SV + 9 + NM;
+            double v;
+            if (o < 6) {
+                const double* q21 = Pst + k * PS + 6 * L;
+                v = 0.0;
+                for (int t = 0; t < 6; ++t) v = dmax(v, fabs(symget(q21, o, t, 6) * d[t]));
+                v *= d[o];
+            } else v = d[o] * q.c.Q_bias_dt2[o - 6] * d[o];
+            pc[k * SV + 9 + NM + o] = v;
+        });
+        wfor(K1 * 3, [&](int e) {  // c columns
+            int k = e / 3, a = e - 3 * k;
+            const double* q6 = Pst + k * PS + 6 * L + 21;
+            const double* d = D + k * SV + 18 + NM;
+            double v = dmax(fabs(symget(q6, a, 0, 3) * d[0]), dmax(fabs(symget(q6, a, 1, 3) * d[1]), fabs(symget(q6, a, 2, 3) * d[2])));
+            pc[k * SV + 18 + NM + a] = v * d[a];
+        });
+    };
+    pnorms();
+    for (int it = 0; it < q.c.scaling; ++it) {
+        const double cc = q.cc;
+        // ---- column norms of [P; A] -> Dt, row norms of A -> Et
+        wfor_nosync(K * 3, [&](int e) {  // position columns
+            int k = e / 3, a = e - 3 * k, i = k * SV + a;
+            double an = 0.0;
+            if (k < K1) an = dmax(E[k * SC + NM + a], E[k * SC + NM + 9 + a]);
+            if (k > 0) an = dmax(an, dmax(E[(k - 1) * SC + NM + a], E[(k - 1) * SC + NM + 9 + a]));
+            Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i])));
+        });
+        wfor_nosync(K * 3, [&](int e) {  // velocity columns
+            int k = e / 3, a = e - 3 * k, i = k * SV + 3 + a;
+            double an = 0.0;
+            for (int leg = 0; leg < L; ++leg) an = dmax(an, E[k * SC + 3 * leg + a]);
+            if (k < K1) an = dmax(an, dmax(E[k * SC + NM + 3 + a], dt * E[k * SC + NM + a]));
+            if (k > 0) an = dmax(an, E[(k - 1) * SC + NM + 3 + a]);
+            Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i])));
+        });
+        wfor_nosync(K * 3, [&](int e) {  // bias columns
+            int k = e / 3, a = e - 3 * k, i = k * SV + 6 + a;
+            double an = 0.0;
+            if (k < K1) {
+                const double* R = q.R + 9 * k;
+                an = E[k * SC + NM + 6 + a];
+                for (int r = 0; r < 3; ++r) {
+                    double ra = fabs(R[3 * r + a]);
+                    an = dmax(an, dmax(hdt2 * ra * E[k * SC + NM + r], dt * ra * E[k * SC + NM + 3 + r]));
+                }
+            }
+            if (k > 0) an = dmax(an, E[(k - 1) * SC + NM + 6 + a]);
+            Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i])));
+        });
+        wfor_nosync(m, [&](int r) {  // slack columns: one entry -1 in their own row
+            int k = r / SC, i = k * SV + 9 + (r - k * SC);
+            Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], E[r] * D[i])));
+        });
+        wfor_nosync(K * NM, [&](int e) {  // Meas rows
+            int k = e / NM, o = e - k * NM, r = k * SC + o;
+            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * dmax(D[k * SV + 9 + o], D[k * SV + 3 + o % 3])));
+        });
+        wfor_nosync(K1 * 3, [&](int e) {  // Dyn position rows
+            int k = e / 3, a = e - 3 * k, r = k * SC + NM + a;
+            const double* R = q.R + 9 * k + 3 * a;
+            const double* d = D + k * SV;
+            double v = dmax(dmax(d[9 + NM + a], d[a]), dmax(dt * d[3 + a], d[SV + a]));
+            for (int j = 0; j < 3; ++j) v = dmax(v, hdt2 * fabs(R[j]) * d[6 + j]);
+            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * v));
+        });
+        wfor_nosync(K1 * 3, [&](int e) {  // Dyn velocity rows
+            int k = e / 3, a = e - 3 * k, r = k * SC + NM + 3 + a;
+            const double* R = q.R + 9 * k + 3 * a;
+            const double* d = D + k * SV;
+            double v = dmax(dmax(d[9 + NM + 3 + a], d[3 + a]), d[SV + 3 + a]);
+            for (int j = 0; j < 3; ++j) v = dmax(v, dt * fabs(R[j]) * d[6 + j]);
+            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * v));
+        });
+        wfor_nosync(K1 * 3, [&](int e) {  // Dyn bias rows
+            int k = e / 3, a = e - 3 * k, r = k * SC + NM + 6 + a;
+            const double* d = D + k * SV;
+            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * dmax(d[9 + NM + 6 + a], dmax(d[6 + a], d[SV + 6 + a]))));
+        });
+        wfor(K1 * 3, [&](int e) {  // VO rows
+            int k = e / 3, a = e - 3 * k, r = k * SC + NM + 9 + a;
+            const double* d = D + k * SV;
+            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * dmax(d[18 + NM + a], dmax(d[a], d[SV + a]))));
+        });
+        wfor(n + m, [&](int e) { if (e < n) D[e] *= Dt[e]; else E[e - n] *= Et[e - n]; });
+        // ---- cost normalisation: mean column norm of the re-scaled P against |q|_inf
+        pnorms();
+        double psum = cc * wred_sum(n, [&](int i) { return pc[i]; });
         double qn = 0.0;
-        for (int j = 0; j < 9; ++j) qn = dmax(qn, fabs(q.cc * q.D[q.ix.x(0, j)] * g[j]));
+        for (int j = 0; j < 9; ++j) qn = dmax(qn, fabs(cc * D[j] * g[j]));
         double ct = 1.0 / limit_scaling(dmax(psum / (double)n, limit_scaling(qn)));
-        q.cc *= ct;
+        q.cc = cc * ct;
         DEKF_SYNC();
     }
 }
@@ -281,12 +410,16 @@ DEKF_FN bool solve_factor(Q& q) {
     const int K = q.K;
     const auto& ix = q.ix;
     const double sigma = c.sigma, cc = q.cc;
-    // 3a. slack blocks: one lane per block
+    // 3a. slack blocks: one lane per block, P blocks from the staged copy (Sinv | Wk are dead here:
+    //     the previous factor is being replaced)
+    constexpr int PS = 6 * L + 27;
+    if (!q.staged) stage_p(q);
+    q.staged = false;  // 3c overwrites the staging area
     wfor(K * (L + 2), [&](int e) {
         int k = e / (L + 2), blk = e - k * (L + 2);
-        const double* r = q.rec(k);
+        const double* pk = q.Pst + k * PS;  // [Qm 6L | Qd 21 | Qc 6]
         if (blk < L) {
-            const double* q6 = r + Rec::qm(nm) + 6 * blk;
+            const double* q6 = pk + 6 * blk;
             double gv[3], rr[3], S6[6], Si[6];
             for (int a = 0; a < 3; ++a) {
                 int row = ix.rm(k, 3 * blk + a);
@@ -303,7 +436,7 @@ DEKF_FN bool solve_factor(Q& q) {
                 for (int d = a; d < 3; ++d)
                     q.Wm[(k * L + blk) * 6 + symidx(a, d, 3)] = (a == d ? rr[a] : 0.0) - gv[a] * Si[symidx(a, d, 3)] * gv[d];
         } else if (k < K - 1 && blk == L) {
-            const double* q21 = r + Rec::QD;
+            const double* q21 = pk + 6 * L;
             double S[36], gv[9], rr[9];
 #pragma unroll
             for (int a = 0; a < 9; ++a) {
@@ -336,7 +469,7 @@ DEKF_FN bool solve_factor(Q& q) {
                 wd[21 + a - 6] = rr[a] - gv[a] * gv[a] / sdiag;
             }
         } else if (k < K - 1 && blk == L + 1) {
-            const double* q6 = r + Rec::QC;
+            const double* q6 = pk + 6 * L + 21;
             double gv[3], rr[3], S6[6], Si[6];
             for (int a = 0; a < 3; ++a) {
                 int row = ix.rv(k, a);
@@ -413,55 +546,63 @@ DEKF_FN bool solve_factor(Q& q) {
     bool ok = true;
     double* bufA = q.tmp;
     double* bufB = q.tmp + 81;
-    for (int k = 0; k < K; ++k) {
-        const double* Tk = q.Sinv + k * 45;
-        const double* Wp = q.Wk + (k - 1) * 81;
-        const double* Cp = q.PA + (k - 1) * 81;
-        wfor(81, [&](int p) {
-            int i = p / 9, j = p - 9 * i;
-            int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
-            double acc = Tk[symidx(lo_, hi_, 9)];
-            if (k > 0) {
-                double s1 = 0.0, s2 = 0.0;
-                for (int t = 0; t < 9; ++t) { s1 += Wp[9 * i + t] * Cp[9 * j + t]; s2 += Wp[9 * j + t] * Cp[9 * i + t]; }
-                acc -= 0.5 * (s1 + s2);
-            }
-            bufA[p] = acc;
-        });
-        double* src = bufA;
-        double* dst = bufB;
-        for (int pv = 0; pv < 9; ++pv) {
-            double piv = src[pv * 9 + pv];
-            if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) ok = false;
-            double d = 1.0 / piv;
-            wfor(81, [&](int p) {
+    // (run by the first wavefront alone: 11 short phases per block, wave-level syncs instead of
+    //  220 workgroup barriers per factorisation)
+    if (DEKF_IN_WAVE0()) {
+        for (int k = 0; k < K; ++k) {
+            const double* Tk = q.Sinv + k * 45;
+            const double* Wp = q.Wk + (k - 1) * 81;
+            const double* Cp = q.PA + (k - 1) * 81;
+            w0for(81, [&](int p) {
                 int i = p / 9, j = p - 9 * i;
-                double v;
-                if (i == pv) v = (j == pv) ? d : src[p] * d;
-                else if (j == pv) v = -src[p] * d;
-                else v = src[p] - src[i * 9 + pv] * src[pv * 9 + j] * d;
-                dst[p] = v;
+                int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
+                double acc = Tk[symidx(lo_, hi_, 9)];
+                if (k > 0) {
+                    double s1 = 0.0, s2 = 0.0;
+                    for (int t = 0; t < 9; ++t) { s1 += Wp[9 * i + t] * Cp[9 * j + t]; s2 += Wp[9 * j + t] * Cp[9 * i + t]; }
+                    acc -= 0.5 * (s1 + s2);
+                }
+                bufA[p] = acc;
             });
-            double* t = src; src = dst; dst = t;
-        }
-        // src holds S_k^-1
-        double* Sk = q.Sinv + k * 45;
-        const double* Ck = q.PA + k * 81;
-        double* Wk = q.Wk + k * 81;
-        wfor(45 + (k < K - 1 ? 81 : 0), [&](int e) {
-            if (e < 45) {
-                int p = e, i = 0;
-                while (p >= 9 - i) { p -= 9 - i; ++i; }
-                int j = i + p;
-                Sk[e] = 0.5 * (src[9 * i + j] + src[9 * j + i]);
-            } else {
-                int p = e - 45, i = p / 9, j = p - 9 * i;
-                double acc = 0.0;
-                for (int t = 0; t < 9; ++t) acc += Ck[9 * i + t] * src[9 * t + j];
-                Wk[p] = acc;
+            double* src = bufA;
+            double* dst = bufB;
+            for (int pv = 0; pv < 9; ++pv) {
+                double piv = src[pv * 9 + pv];
+                if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) ok = false;
+                double d = 1.0 / piv;
+                w0for(81, [&](int p) {
+                    int i = p / 9, j = p - 9 * i;
+                    double v;
+                    if (i == pv) v = (j == pv) ? d : src[p] * d;
+                    else if (j == pv) v = -src[p] * d;
+                    else v = src[p] - src[i * 9 + pv] * src[pv * 9 + j] * d;
+                    dst[p] = v;
+                });
+                double* t = src; src = dst; dst = t;
             }
-        });
+            // src holds S_k^-1
+            double* Sk = q.Sinv + k * 45;
+            const double* Ck = q.PA + k * 81;
+            double* Wk = q.Wk + k * 81;
+            w0for(45 + (k < K - 1 ? 81 : 0), [&](int e) {
+                if (e < 45) {
+                    int p = e, i = 0;
+                    while (p >= 9 - i) { p -= 9 - i; ++i; }
+                    int j = i + p;
+                    Sk[e] = 0.5 * (src[9 * i + j] + src[9 * j + i]);
+                } else {
+                    int p = e - 45, i = p / 9, j = p - 9 * i;
+                    double acc = 0.0;
+                    for (int t = 0; t < 9; ++t) acc += Ck[9 * i + t] * src[9 * t + j];
+                    Wk[p] = acc;
+                }
+            });
+        }
+        if (DEKF_LANE() == 0) q.tmp[172] = ok ? 1.0 : 0.0;  // [162,171) holds the scaled q
     }
+    DEKF_SYNC();
+    ok = q.tmp[172] != 0.0;
+    DEKF_SYNC();
     return ok;
 }
 
@@ -826,6 +967,8 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     q.Mp = s.Mp + 81 * (size_t)b;
     q.np = s.np_ + 9 * (size_t)b;
     q.cc = 1.0;
+    q.Pst = q.Sinv;  // Sinv | Wk are adjacent in both placements and dead until a factorisation writes them
+    q.staged = false;
     const int n = q.n, m = q.m;
     const auto& ix = q.ix;
     SolveInfo info{0, DEKF_SOLVE_MAX_ITER, 0, 0.0, 0.0, c.rho0};
