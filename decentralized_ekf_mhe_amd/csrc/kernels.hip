@@ -39,10 +39,12 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
 // three placements of the factor (mhe_solve_core.h: SolveLayout): _ll all in LDS (Go1, N = 20),
 // _lg LDS factor with the factor-time temporary in HBM (fewer legs), _gg factor streamed from HBM
 // One workgroup of DEKF_SOLVE_THREADS lanes (4 wavefronts, one per SIMD of the CU) per instance;
-// the leg count is a compile-time constant of each instantiation.
+// the leg count is a compile-time constant of each instantiation.  The second launch bound (2 waves
+// per SIMD) caps VGPR+AGPR at 256 so that TWO workgroups stay resident per CU — LDS allows exactly
+// two, and at 260 registers the kernel silently dropped to one (2x slower).
 #define DEKF_SOLVE_KERNEL(NAME, LEGS, FL, PL)                                                            \
-    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS) NAME(DevCfg c, DevState s, int kstart, int K,   \
-                                                               int gws_len) {                            \
+    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) NAME(DevCfg c, DevState s, int kstart, int K, \
+                                                                  int gws_len) {                         \
         extern __shared__ double lds[];                                                                  \
         double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                              \
         for (int b = blockIdx.x; b < c.B; b += gridDim.x)                                                \

@@ -546,63 +546,55 @@ DEKF_FN bool solve_factor(Q& q) {
     bool ok = true;
     double* bufA = q.tmp;
     double* bufB = q.tmp + 81;
-    // (run by the first wavefront alone: 11 short phases per block, wave-level syncs instead of
-    //  220 workgroup barriers per factorisation)
-    if (DEKF_IN_WAVE0()) {
-        for (int k = 0; k < K; ++k) {
-            const double* Tk = q.Sinv + k * 45;
-            const double* Wp = q.Wk + (k - 1) * 81;
-            const double* Cp = q.PA + (k - 1) * 81;
-            w0for(81, [&](int p) {
-                int i = p / 9, j = p - 9 * i;
-                int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
-                double acc = Tk[symidx(lo_, hi_, 9)];
-                if (k > 0) {
-                    double s1 = 0.0, s2 = 0.0;
-                    for (int t = 0; t < 9; ++t) { s1 += Wp[9 * i + t] * Cp[9 * j + t]; s2 += Wp[9 * j + t] * Cp[9 * i + t]; }
-                    acc -= 0.5 * (s1 + s2);
-                }
-                bufA[p] = acc;
-            });
-            double* src = bufA;
-            double* dst = bufB;
-            for (int pv = 0; pv < 9; ++pv) {
-                double piv = src[pv * 9 + pv];
-                if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) ok = false;
-                double d = 1.0 / piv;
-                w0for(81, [&](int p) {
-                    int i = p / 9, j = p - 9 * i;
-                    double v;
-                    if (i == pv) v = (j == pv) ? d : src[p] * d;
-                    else if (j == pv) v = -src[p] * d;
-                    else v = src[p] - src[i * 9 + pv] * src[pv * 9 + j] * d;
-                    dst[p] = v;
-                });
-                double* t = src; src = dst; dst = t;
+    for (int k = 0; k < K; ++k) {
+        const double* Tk = q.Sinv + k * 45;
+        const double* Wp = q.Wk + (k - 1) * 81;
+        const double* Cp = q.PA + (k - 1) * 81;
+        wfor(81, [&](int p) {
+            int i = p / 9, j = p - 9 * i;
+            int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
+            double acc = Tk[symidx(lo_, hi_, 9)];
+            if (k > 0) {
+                double s1 = 0.0, s2 = 0.0;
+                for (int t = 0; t < 9; ++t) { s1 += Wp[9 * i + t] * Cp[9 * j + t]; s2 += Wp[9 * j + t] * Cp[9 * i + t]; }
+                acc -= 0.5 * (s1 + s2);
             }
-            // src holds S_k^-1
-            double* Sk = q.Sinv + k * 45;
-            const double* Ck = q.PA + k * 81;
-            double* Wk = q.Wk + k * 81;
-            w0for(45 + (k < K - 1 ? 81 : 0), [&](int e) {
-                if (e < 45) {
-                    int p = e, i = 0;
-                    while (p >= 9 - i) { p -= 9 - i; ++i; }
-                    int j = i + p;
-                    Sk[e] = 0.5 * (src[9 * i + j] + src[9 * j + i]);
-                } else {
-                    int p = e - 45, i = p / 9, j = p - 9 * i;
-                    double acc = 0.0;
-                    for (int t = 0; t < 9; ++t) acc += Ck[9 * i + t] * src[9 * t + j];
-                    Wk[p] = acc;
-                }
+            bufA[p] = acc;
+        });
+        double* src = bufA;
+        double* dst = bufB;
+        for (int pv = 0; pv < 9; ++pv) {
+            double piv = src[pv * 9 + pv];
+            if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) ok = false;
+            double d = 1.0 / piv;
+            wfor(81, [&](int p) {
+                int i = p / 9, j = p - 9 * i;
+                double v;
+                if (i == pv) v = (j == pv) ? d : src[p] * d;
+                else if (j == pv) v = -src[p] * d;
+                else v = src[p] - src[i * 9 + pv] * src[pv * 9 + j] * d;
+                dst[p] = v;
             });
+            double* t = src; src = dst; dst = t;
         }
-        if (DEKF_LANE() == 0) q.tmp[172] = ok ? 1.0 : 0.0;  // [162,171) holds the scaled q
+        // src holds S_k^-1
+        double* Sk = q.Sinv + k * 45;
+        const double* Ck = q.PA + k * 81;
+        double* Wk = q.Wk + k * 81;
+        wfor(45 + (k < K - 1 ? 81 : 0), [&](int e) {
+            if (e < 45) {
+                int p = e, i = 0;
+                while (p >= 9 - i) { p -= 9 - i; ++i; }
+                int j = i + p;
+                Sk[e] = 0.5 * (src[9 * i + j] + src[9 * j + i]);
+            } else {
+                int p = e - 45, i = p / 9, j = p - 9 * i;
+                double acc = 0.0;
+                for (int t = 0; t < 9; ++t) acc += Ck[9 * i + t] * src[9 * t + j];
+                Wk[p] = acc;
+            }
+        });
     }
-    DEKF_SYNC();
-    ok = q.tmp[172] != 0.0;
-    DEKF_SYNC();
     return ok;
 }
 
