@@ -24,6 +24,7 @@ __global__ void k_mhe_assemble(DevCfg c, DevState s, int T, int pushes);
     __global__ void k_mhe_solve_ll_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);     \
     __global__ void k_mhe_solve_lg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);     \
     __global__ void k_mhe_solve_gg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);
+__global__ void k_mhe_solve_ll_4_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
 DEKF_DECL_SOLVE(1)
 DEKF_DECL_SOLVE(2)
 DEKF_DECL_SOLVE(3)
@@ -169,6 +170,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             {k_mhe_solve_ll_1, k_mhe_solve_lg_1, k_mhe_solve_gg_1}, {k_mhe_solve_ll_2, k_mhe_solve_lg_2, k_mhe_solve_gg_2},
             {k_mhe_solve_ll_3, k_mhe_solve_lg_3, k_mhe_solve_gg_3}, {k_mhe_solve_ll_4, k_mhe_solve_lg_4, k_mhe_solve_gg_4}};
         h->solve_kernel = table[c.L - 1][lay.pa_in_lds() ? 0 : (lay.factor_in_lds() ? 1 : 2)];
+        if (c.L == 4 && c.N == 20 && lay.pa_in_lds()) h->solve_kernel = k_mhe_solve_ll_4_n20;
     }
     h->lds_asm = (size_t)AsmScratch::len(c.L) * sizeof(double);
     h->lds_kf = (size_t)KfScratch::len(c.L) * sizeof(double);

@@ -54,6 +54,13 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
     DEKF_SOLVE_KERNEL(k_mhe_solve_ll_##LEGS, LEGS, true, true)   \
     DEKF_SOLVE_KERNEL(k_mhe_solve_lg_##LEGS, LEGS, true, false)  \
     DEKF_SOLVE_KERNEL(k_mhe_solve_gg_##LEGS, LEGS, false, false)
+// the benchmark shape (Go1, N = 20) additionally with the horizon as a compile-time constant
+extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) k_mhe_solve_ll_4_n20(DevCfg c, DevState s, int kstart, int K,
+                                                                                   int gws_len) {
+    extern __shared__ double lds[];
+    double* gws = s.gws + (size_t)blockIdx.x * gws_len;
+    for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<4, true, true, 20>(c, s, b, kstart, K, lds, gws);
+}
 DEKF_SOLVE_KERNELS(1)
 DEKF_SOLVE_KERNELS(2)
 DEKF_SOLVE_KERNELS(3)

@@ -866,11 +866,17 @@ DEKF_FN void admm_linear(Q& q) {
     //    forward f_k -= W_{k-1} f_{k-1};  g_k = S_k^-1 f_k for all k at once (it does not depend on
     //    the backward recursion);  backward u_k = g_k - W_k' u_{k+1}.  Leaves xs = u, xd = D .* u.
 #if DEKF_DEVICE_BUILD
+    // the sweep is the critical path of the workgroup and shares its SIMD with a wavefront of the
+    // other resident workgroup: raise its issue priority for the duration
+    if (DEKF_IN_WAVE0()) {
+        __builtin_amdgcn_s_setprio(3);
 #ifdef DEKF_SWEEP_MFMA
-    if (DEKF_IN_WAVE0()) tri_sweeps_mfma(q);
+        tri_sweeps_mfma(q);
 #else
-    if (DEKF_IN_WAVE0()) tri_sweeps_registers(q);
+        tri_sweeps_registers(q);
 #endif
+        __builtin_amdgcn_s_setprio(0);
+    }
 #else
     if (DEKF_IN_WAVE0()) {
         for (int k = 1; k < K; ++k) {
@@ -1008,12 +1014,15 @@ struct SolveInfo {
 // osqp_setup + osqp_solve + extraction.  window = steps kstart .. kstart+K-1 (newest = T).
 // FACTOR_LDS / PA_LDS are compile-time so that every pointer has a provable address space
 // (ds_read/ds_write instead of flat_load) — see SolveLayout::factor_in_lds / pa_in_lds.
-template <int L, bool FACTOR_LDS, bool PA_LDS>
+template <int L, bool FACTOR_LDS, bool PA_LDS, int NFIX = 0>
 DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, double* lds, double* gws) {
+    // NFIX != 0: the horizon is a compile-time constant, so every LDS array sits at a constant offset
+    // (folded into the ds_read/ds_write immediates instead of living in scalar registers)
+    const int NH = NFIX ? NFIX : c.N;
     SolveLayout lay;
-    lay.init(c.N, L);
+    lay.init(NH, L);
     Gws g;
-    g.init(c.N, L);
+    g.init(NH, L);
     SolveCtx<L> q{c, s, b, K, kstart, 0, 0, IdxT<L>{}};
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
         double* p = lds;
@@ -1023,20 +1032,20 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         q.xt = p; p += lay.n_pad;
         q.zt = p; p += lay.m_pad;
         q.at = p; p += lay.m_pad;
-        q.xs = p; p += 9 * c.N;
-        q.xd = p; p += 9 * c.N;
+        q.xs = p; p += 9 * NH;
+        q.xd = p; p += 9 * NH;
         q.tmp = p; p += SOLVE_TMP;
         if constexpr (FACTOR_LDS) {
             q.D = p; p += lay.n_pad;
             q.E = p; p += lay.m_pad;
             q.lo = p; p += lay.m_pad;
             q.hi = p; p += lay.m_pad;
-            q.Sv = p; p += c.N * 6 * L;
-            q.Sw = p; p += c.N * 24;
-            q.Sc = p; p += c.N * 6;
-            q.Sinv = p; p += c.N * 45;
-            q.Wk = p; p += c.N * 81;
-            q.R = p; p += c.N * 9;
+            q.Sv = p; p += NH * 6 * L;
+            q.Sw = p; p += NH * 24;
+            q.Sc = p; p += NH * 6;
+            q.Sinv = p; p += NH * 45;
+            q.Wk = p; p += NH * 81;
+            q.R = p; p += NH * 9;
         } else {
             q.D = gws + g.D; q.E = gws + g.E; q.lo = gws + g.lo; q.hi = gws + g.hi;
             q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc;
