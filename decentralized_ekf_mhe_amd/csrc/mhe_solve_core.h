@@ -45,7 +45,7 @@ namespace dekf {
 #define DEKF_PROF_MARK(q, sec) ((void)0)
 #endif
 
-constexpr int SOLVE_TMP = 176;  // [0,18) sweep ping-pong, [162,171) scaled q; at factor time [0,162) = 2 x 81 Gauss-Jordan
+constexpr int SOLVE_TMP = 344;  // [162,171) scaled q; at factor time [0,162) and [176,338): two Gauss-Jordan ping-pong pairs
 
 // how many doubles of LDS a solve needs in each placement mode
 struct SolveLayout {
@@ -542,56 +542,96 @@ DEKF_FN bool solve_factor(Q& q) {
     });
     // C_k moves to PA[k]; W_k will be written to Wk[k]
     wfor((K - 1) * 81, [&](int e) { q.PA[e] = q.Wk[e]; });
-    // 3d. block LDL': S_k = T_kk - W_{k-1} C_{k-1}'; S_k^-1 by Gauss-Jordan ping-pong; W_k = C_k S_k^-1
+    // 3d. TWO-SIDED block LDL' ("burn at both ends"): blocks 0..mid-1 are eliminated downwards,
+    //     blocks K-1..mid+1 upwards, both fronts in the same phases (two 9x9 problems per phase),
+    //     and they meet in block mid.  Same storage as a one-sided factorisation, half the depth:
+    //       top     S_k = T_kk - W_{k-1} C_{k-1}',      W_k     = C_k S_k^-1        (k <  mid)
+    //       bottom  S_k = T_kk - What_k C_k,            What_{k-1} = C_{k-1}' S_k^-1 (k >  mid)
+    //       middle  S_m = T_mm - W_{m-1} C_{m-1}' - What_m C_m
+    //     W_k lives in Wk[k] for k < mid, What_k in Wk[k] for k >= mid (it couples block k+1 to k).
     bool ok = true;
-    double* bufA = q.tmp;
-    double* bufB = q.tmp + 81;
-    for (int k = 0; k < K; ++k) {
-        const double* Tk = q.Sinv + k * 45;
-        const double* Wp = q.Wk + (k - 1) * 81;
-        const double* Cp = q.PA + (k - 1) * 81;
-        wfor(81, [&](int p) {
-            int i = p / 9, j = p - 9 * i;
-            int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
-            double acc = Tk[symidx(lo_, hi_, 9)];
-            if (k > 0) {
-                double s1 = 0.0, s2 = 0.0;
-                for (int t = 0; t < 9; ++t) { s1 += Wp[9 * i + t] * Cp[9 * j + t]; s2 += Wp[9 * j + t] * Cp[9 * i + t]; }
-                acc -= 0.5 * (s1 + s2);
-            }
-            bufA[p] = acc;
-        });
-        double* src = bufA;
-        double* dst = bufB;
-        for (int pv = 0; pv < 9; ++pv) {
-            double piv = src[pv * 9 + pv];
-            if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) ok = false;
-            double d = 1.0 / piv;
-            wfor(81, [&](int p) {
-                int i = p / 9, j = p - 9 * i;
-                double v;
-                if (i == pv) v = (j == pv) ? d : src[p] * d;
-                else if (j == pv) v = -src[p] * d;
-                else v = src[p] - src[i * 9 + pv] * src[pv * 9 + j] * d;
-                dst[p] = v;
-            });
-            double* t = src; src = dst; dst = t;
+    const int mid = K / 2;
+    const int nph = (mid > K - 1 - mid ? mid : K - 1 - mid);
+    double* bufs[2][2] = {{q.tmp, q.tmp + 81}, {q.tmp + 176, q.tmp + 257}};
+    // S of block k into dst; use_top / use_bot select the Schur terms
+    auto build_s = [&](int k, bool use_top, bool use_bot, int p, double* dst) {
+        int i = p / 9, j = p - 9 * i;
+        int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
+        double acc = q.Sinv[k * 45 + symidx(lo_, hi_, 9)];
+        if (use_top) {
+            const double* Wp = q.Wk + (k - 1) * 81;
+            const double* Cp = q.PA + (k - 1) * 81;
+            double s1 = 0.0, s2 = 0.0;
+            for (int t = 0; t < 9; ++t) { s1 += Wp[9 * i + t] * Cp[9 * j + t]; s2 += Wp[9 * j + t] * Cp[9 * i + t]; }
+            acc -= 0.5 * (s1 + s2);
         }
-        // src holds S_k^-1
-        double* Sk = q.Sinv + k * 45;
-        const double* Ck = q.PA + k * 81;
-        double* Wk = q.Wk + k * 81;
-        wfor(45 + (k < K - 1 ? 81 : 0), [&](int e) {
-            if (e < 45) {
-                int p = e, i = 0;
-                while (p >= 9 - i) { p -= 9 - i; ++i; }
-                int j = i + p;
-                Sk[e] = 0.5 * (src[9 * i + j] + src[9 * j + i]);
-            } else {
-                int p = e - 45, i = p / 9, j = p - 9 * i;
-                double acc = 0.0;
-                for (int t = 0; t < 9; ++t) acc += Ck[9 * i + t] * src[9 * t + j];
-                Wk[p] = acc;
+        if (use_bot) {
+            const double* Wh = q.Wk + k * 81;
+            const double* Ck = q.PA + k * 81;
+            double s1 = 0.0, s2 = 0.0;
+            for (int t = 0; t < 9; ++t) { s1 += Wh[9 * i + t] * Ck[9 * t + j]; s2 += Wh[9 * j + t] * Ck[9 * t + i]; }
+            acc -= 0.5 * (s1 + s2);
+        }
+        dst[p] = acc;
+    };
+    auto gj_step = [&](const double* src, double* dst, int pv, int p) {
+        int i = p / 9, j = p - 9 * i;
+        double d = 1.0 / src[pv * 9 + pv];
+        double v;
+        if (i == pv) v = (j == pv) ? d : src[p] * d;
+        else if (j == pv) v = -src[p] * d;
+        else v = src[p] - src[i * 9 + pv] * src[pv * 9 + j] * d;
+        dst[p] = v;
+    };
+    auto pivot_ok = [&](const double* src, int pv) { double piv = src[pv * 9 + pv]; return (fabs(piv) > 0.0) && (fabs(piv) < 1e300); };
+    auto store_sinv = [&](int k, const double* src, int e) {
+        int p = e, i = 0;
+        while (p >= 9 - i) { p -= 9 - i; ++i; }
+        int j = i + p;
+        q.Sinv[k * 45 + e] = 0.5 * (src[9 * i + j] + src[9 * j + i]);
+    };
+    for (int t = 0; t <= nph; ++t) {
+        const bool last = t == nph;             // the meeting block
+        const int kt = last ? mid : t, kb = K - 1 - t;
+        const bool vt = last || t < mid;        // side 0 active
+        const bool vb = !last && kb > mid;      // side 1 active
+        wfor(162, [&](int e) {
+            int side = e / 81, p = e - 81 * side;
+            if (side == 0 && vt) build_s(kt, kt > 0, last && mid < K - 1, p, bufs[0][0]);
+            if (side == 1 && vb) build_s(kb, false, kb < K - 1, p, bufs[1][0]);
+        });
+        int cur = 0;
+        for (int pv = 0; pv < 9; ++pv) {
+            if (vt && !pivot_ok(bufs[0][cur], pv)) ok = false;
+            if (vb && !pivot_ok(bufs[1][cur], pv)) ok = false;
+            wfor(162, [&](int e) {
+                int side = e / 81, p = e - 81 * side;
+                if ((side == 0 && vt) || (side == 1 && vb)) gj_step(bufs[side][cur], bufs[side][cur ^ 1], pv, p);
+            });
+            cur ^= 1;
+        }
+        const double* st = bufs[0][cur];
+        const double* sb = bufs[1][cur];
+        wfor(252, [&](int e) {
+            int side = e / 126, o = e - 126 * side;
+            if (side == 0 && vt) {
+                if (o < 45) store_sinv(kt, st, o);
+                else if (!last) {  // W_kt = C_kt S^-1
+                    int p = o - 45, i = p / 9, j = p - 9 * i;
+                    const double* Ck = q.PA + kt * 81;
+                    double acc = 0.0;
+                    for (int u = 0; u < 9; ++u) acc += Ck[9 * i + u] * st[9 * u + j];
+                    q.Wk[kt * 81 + p] = acc;
+                }
+            } else if (side == 1 && vb) {
+                if (o < 45) store_sinv(kb, sb, o);
+                else {  // What_{kb-1} = C_{kb-1}' S^-1
+                    int p = o - 45, i = p / 9, j = p - 9 * i;
+                    const double* Ck = q.PA + (kb - 1) * 81;
+                    double acc = 0.0;
+                    for (int u = 0; u < 9; ++u) acc += Ck[9 * u + i] * sb[9 * u + j];
+                    q.Wk[(kb - 1) * 81 + p] = acc;
+                }
             }
         });
     }
@@ -798,6 +838,64 @@ DEKF_FN void tri_sweeps_mfma(Q& q) {
 }
 #endif
 
+// One leg of the two-sided block-tridiagonal solve: a chain of `steps` dependent 9x9 mat-vecs
+//     v_new = rhs[k_new] - M v_prev,   k_new = k_prev + dk,   M = Wk[k_new + wofs] (TR: transposed)
+// starting from the vector stored at block k0.  Forward legs (BWD = false) read rhs from xs and
+// overwrite it; outward legs (BWD = true) read rhs = g from xd and leave xs = u, xd = D .* u.
+// Device: the running vector sits in registers of lanes 0..8 of the calling wavefront and is
+// broadcast with v_readlane (18 per step), so the dependent chain never touches LDS or a barrier;
+// all 64 lanes execute it (lanes >= 9 mirror lane 8 and never store).  Host build: plain loops.
+template <bool TR, bool BWD, class Q>
+DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs) {
+    constexpr int SV = 21 + 3 * Q::LEGS;
+    double *xs = q.xs, *xd = q.xd;
+#if DEKF_DEVICE_BUILD
+    const int lane = DEKF_LANE() & 63;
+    const int i = lane < 9 ? lane : 8;
+    const bool act = lane < 9;
+    double v = xs[9 * k0 + i];
+    for (int s = 1; s <= steps; ++s) {
+        const int kn = k0 + s * dk;
+        const double* W = q.Wk + (kn + wofs) * 81;
+        double w[9], vt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = TR ? W[9 * t + i] : W[9 * i + t];
+        const double rhs = BWD ? xd[9 * kn + i] : xs[9 * kn + i];
+        const double dsc = BWD ? q.D[kn * SV + i] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) vt[t] = readlane_f64(v, t);
+        double a0 = w[0] * vt[0] + w[3] * vt[3] + w[6] * vt[6];
+        double a1 = w[1] * vt[1] + w[4] * vt[4] + w[7] * vt[7];
+        double a2 = w[2] * vt[2] + w[5] * vt[5] + w[8] * vt[8];
+        v = rhs - (a0 + a1 + a2);
+        if (act) {
+            xs[9 * kn + i] = v;
+            if (BWD) xd[9 * kn + i] = dsc * v;
+        }
+    }
+#else
+    double v[9], nv[9];
+    for (int i = 0; i < 9; ++i) v[i] = xs[9 * k0 + i];
+    for (int s = 1; s <= steps; ++s) {
+        const int kn = k0 + s * dk;
+        const double* W = q.Wk + (kn + wofs) * 81;
+        for (int i = 0; i < 9; ++i) {
+            double w[9];
+            for (int t = 0; t < 9; ++t) w[t] = TR ? W[9 * t + i] : W[9 * i + t];
+            double a0 = w[0] * v[0] + w[3] * v[3] + w[6] * v[6];
+            double a1 = w[1] * v[1] + w[4] * v[4] + w[7] * v[7];
+            double a2 = w[2] * v[2] + w[5] * v[5] + w[8] * v[8];
+            nv[i] = (BWD ? xd[9 * kn + i] : xs[9 * kn + i]) - (a0 + a1 + a2);
+        }
+        for (int i = 0; i < 9; ++i) {
+            v[i] = nv[i];
+            xs[9 * kn + i] = v[i];
+            if (BWD) xd[9 * kn + i] = q.D[kn * SV + i] * v[i];
+        }
+    }
+#endif
+}
+
 // In: xt = right-hand side (n), at = u (consumed by the caller).  Out: xs = xt on the x blocks
 // (K*9), at[row] = xt of that row's slack, zt = A xt.
 template <class Q>
@@ -862,35 +960,37 @@ DEKF_FN void admm_linear(Q& q) {
         xs[9 * k + 6 + a] = xt[k * SV + 6 + a] + D[k * SV + 6 + a] * gather_bcol(q, k, a, wh);
     });
     DEKF_PROF_MARK(q, 4);
-    // D. block-tridiagonal solve, run by the first wavefront alone (no workgroup barriers):
-    //    forward f_k -= W_{k-1} f_{k-1};  g_k = S_k^-1 f_k for all k at once (it does not depend on
-    //    the backward recursion);  backward u_k = g_k - W_k' u_{k+1}.  Leaves xs = u, xd = D .* u.
+    // D. two-sided block-tridiagonal solve (factorisation: solve_factor 3d).  Wavefront 0 eliminates
+    //    blocks 0..mid-1 downwards while wavefront 1 eliminates K-1..mid+1 upwards; they meet in block
+    //    mid; g_k = S_k^-1 f_k for all k at once (it is outside both recursions); then both wavefronts
+    //    substitute outwards from the middle.  Half the sequential depth of a one-sided sweep, no
+    //    workgroup barrier inside a leg.  Leaves xs = u and xd = D .* u.
+    {
+        const int mid = K / 2;
 #if DEKF_DEVICE_BUILD
-    // the sweep is the critical path of the workgroup and shares its SIMD with a wavefront of the
-    // other resident workgroup: raise its issue priority for the duration
-    if (DEKF_IN_WAVE0()) {
-        __builtin_amdgcn_s_setprio(3);
-#ifdef DEKF_SWEEP_MFMA
-        tri_sweeps_mfma(q);
-#else
-        tri_sweeps_registers(q);
+        __builtin_amdgcn_s_setprio(3);  // the legs are the critical path and share their SIMDs
 #endif
+        two_waves([&] { sweep_chain<false, false>(q, 0, 1, mid - 1, -1); },
+                  [&] { sweep_chain<false, false>(q, K - 1, -1, K - 2 - mid, 0); });
+#if DEKF_DEVICE_BUILD
         __builtin_amdgcn_s_setprio(0);
-    }
-#else
-    if (DEKF_IN_WAVE0()) {
-        for (int k = 1; k < K; ++k) {
-            const double* W = q.Wk + (k - 1) * 81;
-            w0for(9, [&](int i) {
-                const double* wr = W + 9 * i;
-                const double* f = xs + 9 * (k - 1);
-                double a0 = wr[0] * f[0] + wr[3] * f[3] + wr[6] * f[6];
-                double a1 = wr[1] * f[1] + wr[4] * f[4] + wr[7] * f[7];
-                double a2 = wr[2] * f[2] + wr[5] * f[5] + wr[8] * f[8];
-                xs[9 * k + i] -= a0 + a1 + a2;
-            });
-        }
-        w0for(K * 9, [&](int e) {
+#endif
+        DEKF_SYNC();
+        wfor(9, [&](int i) {  // the meeting block
+            double acc = 0.0;
+            if (mid > 0) {
+                const double* W = q.Wk + (mid - 1) * 81 + 9 * i;
+                const double* f = xs + 9 * (mid - 1);
+                for (int t = 0; t < 9; ++t) acc += W[t] * f[t];
+            }
+            if (mid < K - 1) {
+                const double* W = q.Wk + mid * 81 + 9 * i;
+                const double* f = xs + 9 * (mid + 1);
+                for (int t = 0; t < 9; ++t) acc += W[t] * f[t];
+            }
+            xs[9 * mid + i] -= acc;
+        });
+        wfor(K * 9, [&](int e) {
             int k = e / 9, i = e - 9 * k;
             const double* Si = q.Sinv + k * 45;
             const double* f = xs + 9 * k;
@@ -902,25 +1002,20 @@ DEKF_FN void admm_linear(Q& q) {
             }
             xd[e] = a0 + a1 + a2;
         });
-        w0for(9, [&](int i) {
-            double u = xd[9 * (K - 1) + i];
-            xs[9 * (K - 1) + i] = u;
-            xd[9 * (K - 1) + i] = D[(K - 1) * SV + i] * u;
+        wfor(9, [&](int i) {
+            double u = xd[9 * mid + i];
+            xs[9 * mid + i] = u;
+            xd[9 * mid + i] = D[mid * SV + i] * u;
         });
-        for (int k = K - 2; k >= 0; --k) {
-            const double* W = q.Wk + k * 81;
-            w0for(9, [&](int i) {
-                const double* u = xs + 9 * (k + 1);
-                double a0 = W[i] * u[0] + W[27 + i] * u[3] + W[54 + i] * u[6];
-                double a1 = W[9 + i] * u[1] + W[36 + i] * u[4] + W[63 + i] * u[7];
-                double a2 = W[18 + i] * u[2] + W[45 + i] * u[5] + W[72 + i] * u[8];
-                double uk = xd[9 * k + i] - (a0 + a1 + a2);
-                xs[9 * k + i] = uk;
-                xd[9 * k + i] = D[k * SV + i] * uk;
-            });
-        }
-    }
+#if DEKF_DEVICE_BUILD
+        __builtin_amdgcn_s_setprio(3);
 #endif
+        two_waves([&] { sweep_chain<true, true>(q, mid, -1, mid, 0); },
+                  [&] { sweep_chain<true, true>(q, mid, 1, K - 1 - mid, -1); });
+#if DEKF_DEVICE_BUILD
+        __builtin_amdgcn_s_setprio(0);
+#endif
+    }
     DEKF_SYNC();
     DEKF_PROF_MARK(q, 5);
     // F. a = A_x xt_x -> at[row];  rho beta a -> xt[slack of the row]

@@ -202,6 +202,24 @@ inline void w0for(int n, F f) {
 }
 #endif
 
+// Two independent serial sections, one on wavefront 0 and one on wavefront 1 of the group
+// (sequentially when the group has a single wavefront, and in the lane-sequential host build).
+#if DEKF_DEVICE_BUILD
+template <class F0, class F1>
+DEKF_FN void two_waves(F0 f0, F1 f1) {
+    const int w = DEKF_LANE() >> 6;
+    if (DEKF_NLANES() <= WAVE) { f0(); f1(); }
+    else if (w == 0) f0();
+    else if (w == 1) f1();
+}
+#else
+template <class F0, class F1>
+inline void two_waves(F0 f0, F1 f1) {
+    f0();
+    f1();
+}
+#endif
+
 DEKF_FN double dmax(double a, double b) { return a > b ? a : b; }
 DEKF_FN double dmin(double a, double b) { return a < b ? a : b; }
 
