@@ -1,0 +1,421 @@
+// mhe_admm_core.h — the phases of one ADMM iteration of the window QP (included by
+// mhe_solve_core.h after SolveCtx; same namespace, same execution model: wave.h).
+//
+// OSQP's iteration (osqp_solve -> update_xz_tilde / update_x / update_z / update_y; called by the
+// reference through MHEproblem::solveQP, src/decentral_legged_est/src/MheSrb.cpp:340-349) is
+//     solve  [P + sigma I, A'; A, -1/rho] [xt; nu] = [sigma x - q; z - y/rho]
+//     x <- alpha xt + (1-alpha) x ;  z <- clip(alpha zt + (1-alpha) z + y/rho) ;  y <- y + rho (...)
+// Here the slack variables v_k, w_k, c_k (each lives in exactly one row, with a block-diagonal P)
+// are eliminated analytically, which leaves a block-tridiagonal SPD system in the x_k (9x9 blocks,
+// factor: solve_factor) — so one iteration is four phases separated by workgroup barriers:
+//
+//   X  phase_xcols   x columns : xs = sigma x - q + D .* A_x' w             (w: row vector left by R)
+//   S1 phase_sweeps  two wavefronts eliminate towards the middle block     (forward legs)
+//   S2               meeting block on wavefront 0 | g_k = S_k^-1 f_k on the other three
+//   S3               two wavefronts substitute outwards; x <- alpha u + (1-alpha) x, xd = D .* u
+//   R  phase_rows    rows, ONE LANE PER 3-ROW (or 6-row) BLOCK, everything of a row block in registers:
+//                    a = A_x xd ; slack solution s = t + S^-1(rho E D a) ; zt = a - E D s ;
+//                    x_s, z, y updates ; next slack right-hand side ; t = S^-1 rhs ; w = E (u + rho E D t)
+//
+// Row-block kinds (Meas leg blocks, Dyn position+velocity 6-blocks, Dyn bias, VO) are mapped to
+// wavefront-sized tiles (wtiles): a wavefront executes one kind's straight-line body, and a row
+// block never leaves its lane, so phase R needs no LDS exchange and no barrier inside.
+#pragma once
+// (no namespace block of its own: the including header is inside namespace dekf)
+
+// sum over the rows that touch x_k[a] / x_k[3+a] / x_k[6+a] of A(row, col) * w(row), w(row) already
+// carrying the row scaling E[row]
+template <class Q, class WF>
+DEKF_FN double gather_pcol(const Q& q, int k, int a, WF w) {
+    constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
+    double g = 0.0;
+    if (k < q.K - 1) g += w(k * SC + NM + a) + w(k * SC + NM + 9 + a);
+    if (k > 0) g -= w((k - 1) * SC + NM + a) + w((k - 1) * SC + NM + 9 + a);
+    return g;
+}
+template <class Q, class WF>
+DEKF_FN double gather_vcol(const Q& q, int k, int a, WF w) {
+    constexpr int L = Q::LEGS, NM = 3 * L, SC = 12 + NM;
+    double g = 0.0;
+#pragma unroll
+    for (int leg = 0; leg < L; ++leg) g += w(k * SC + 3 * leg + a);
+    if (k < q.K - 1) g += w(k * SC + NM + 3 + a) + q.c.dt * w(k * SC + NM + a);
+    if (k > 0) g -= w((k - 1) * SC + NM + 3 + a);
+    return g;
+}
+template <class Q, class WF>
+DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
+    constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
+    double g = 0.0;
+    if (k < q.K - 1) {
+        const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+        const double* R = q.R + 9 * k;
+        g += w(k * SC + NM + 6 + a);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) g -= R[3 * r + a] * (hdt2 * w(k * SC + NM + r) + dt * w(k * SC + NM + 3 + r));
+    }
+    if (k > 0) g -= w((k - 1) * SC + NM + 6 + a);
+    return g;
+}
+
+// ---------------------------------------------------------------- X: reduced right-hand side
+// xs_k = sigma x_k - q_k + D_k .* (A_x' w)_k, one lane per x entry, one tile kind per column
+// kind (position / velocity / bias) because their gathers differ.
+template <class Q>
+DEKF_FN void phase_xcols(Q& q, double sigma) {
+    constexpr int SV = 21 + 3 * Q::LEGS;
+    const int K = q.K, n3 = 3 * K, nt = (n3 + 63) >> 6;
+    const double* qsl = q.tmp + 162;
+    const double* at = q.at;
+    auto w = [&](int r) { return at[r]; };
+    wtiles(3 * nt, [&](int tile, int lane) {
+        const int kind = tile < nt ? 0 : (tile < 2 * nt ? 1 : 2);
+        const int e = (tile - kind * nt) * 64 + lane;
+        if (e >= n3) return;
+        const int k = e / 3, a = e - 3 * k, j = 3 * kind + a, i = k * SV + j;
+        double g;
+        if (kind == 0) g = gather_pcol(q, k, a, w);
+        else if (kind == 1) g = gather_vcol(q, k, a, w);
+        else g = gather_bcol(q, k, a, w);
+        q.xs[9 * k + j] = sigma * q.x[i] - (k == 0 ? qsl[j] : 0.0) + q.D[i] * g;
+    });
+    DEKF_SYNC();
+}
+
+// ---------------------------------------------------------------- S: block-tridiagonal solve
+#if DEKF_DEVICE_BUILD
+DEKF_FN double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+#endif
+
+// One leg of the two-sided block-tridiagonal solve: a chain of `steps` dependent 9x9 mat-vecs
+//     v_new = rhs[k_new] - M v_prev,   k_new = k_prev + dk,   M = Wk[k_new + wofs] (TR: transposed)
+// starting from the vector stored in xs at block k0.  Forward legs (BWD = false) read rhs from xs
+// and overwrite it with f; outward legs (BWD = true) read rhs = g from xd, and leave
+// x <- alpha u + (1-alpha) x (the ADMM relaxation of the x blocks) and xd = D .* u.
+// Device: the running vector sits in registers of lanes 0..8 of the calling wavefront and is
+// broadcast with v_readlane (18 per step), so the dependent chain never touches LDS or a barrier;
+// all 64 lanes execute it (lanes >= 9 mirror lane 8 and never store).  Host build: plain loops.
+template <bool TR, bool BWD, class Q>
+DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha) {
+    constexpr int SV = 21 + 3 * Q::LEGS;
+    double *xs = q.xs, *xd = q.xd, *x = q.x;
+#if DEKF_DEVICE_BUILD
+    const int lane = DEKF_LANE() & 63;
+    const int i = lane < 9 ? lane : 8;
+    const bool act = lane < 9;
+    double v = xs[9 * k0 + i];
+    for (int s = 1; s <= steps; ++s) {
+        const int kn = k0 + s * dk;
+        const double* W = q.Wk + (kn + wofs) * 81;
+        double w[9], vt[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = TR ? W[9 * t + i] : W[9 * i + t];
+        const double rhs = BWD ? xd[9 * kn + i] : xs[9 * kn + i];
+        const double dsc = BWD ? q.D[kn * SV + i] : 0.0;
+        const double xo = BWD ? x[kn * SV + i] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) vt[t] = readlane_f64(v, t);
+        double a0 = w[0] * vt[0] + w[3] * vt[3] + w[6] * vt[6];
+        double a1 = w[1] * vt[1] + w[4] * vt[4] + w[7] * vt[7];
+        double a2 = w[2] * vt[2] + w[5] * vt[5] + w[8] * vt[8];
+        v = rhs - (a0 + a1 + a2);
+        if (act) {
+            if (BWD) {
+                xd[9 * kn + i] = dsc * v;
+                x[kn * SV + i] = alpha * v + (1.0 - alpha) * xo;
+            } else {
+                xs[9 * kn + i] = v;
+            }
+        }
+    }
+#else
+    double v[9], nv[9];
+    for (int i = 0; i < 9; ++i) v[i] = xs[9 * k0 + i];
+    for (int s = 1; s <= steps; ++s) {
+        const int kn = k0 + s * dk;
+        const double* W = q.Wk + (kn + wofs) * 81;
+        for (int i = 0; i < 9; ++i) {
+            double w[9];
+            for (int t = 0; t < 9; ++t) w[t] = TR ? W[9 * t + i] : W[9 * i + t];
+            double a0 = w[0] * v[0] + w[3] * v[3] + w[6] * v[6];
+            double a1 = w[1] * v[1] + w[4] * v[4] + w[7] * v[7];
+            double a2 = w[2] * v[2] + w[5] * v[5] + w[8] * v[8];
+            nv[i] = (BWD ? xd[9 * kn + i] : xs[9 * kn + i]) - (a0 + a1 + a2);
+        }
+        for (int i = 0; i < 9; ++i) {
+            v[i] = nv[i];
+            if (BWD) {
+                xd[9 * kn + i] = q.D[kn * SV + i] * v[i];
+                x[kn * SV + i] = alpha * v[i] + (1.0 - alpha) * x[kn * SV + i];
+            } else {
+                xs[9 * kn + i] = v[i];
+            }
+        }
+    }
+#endif
+}
+
+// The meeting block: f_m -= W^_m f^_{m+1} (the top leg has already folded in W_{m-1} f_{m-1}), then
+// u_m = S_m^-1 f_m.  Leaves xs_m = u_m (start vector of both outward legs), xd_m, x_m.
+// Device: called for all 64 lanes of one wavefront.  Host build: lane 0 does the whole block.
+template <class Q>
+DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
+    constexpr int SV = 21 + 3 * Q::LEGS;
+    const int K = q.K, mid = K / 2;
+    double *xs = q.xs, *xd = q.xd, *x = q.x;
+    const double* Si = q.Sinv + mid * 45;
+#if DEKF_DEVICE_BUILD
+    const int i = lane < 9 ? lane : 8;
+    double f = xs[9 * mid + i];
+    if (mid < K - 1) {
+        const double* W = q.Wk + mid * 81 + 9 * i;
+        const double* fh = xs + 9 * (mid + 1);
+        double a0 = W[0] * fh[0] + W[3] * fh[3] + W[6] * fh[6];
+        double a1 = W[1] * fh[1] + W[4] * fh[4] + W[7] * fh[7];
+        double a2 = W[2] * fh[2] + W[5] * fh[5] + W[8] * fh[8];
+        f -= a0 + a1 + a2;
+    }
+    double s[9], ft[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) s[t] = symget(Si, i, t, 9);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) ft[t] = readlane_f64(f, t);
+    double a0 = s[0] * ft[0] + s[3] * ft[3] + s[6] * ft[6];
+    double a1 = s[1] * ft[1] + s[4] * ft[4] + s[7] * ft[7];
+    double a2 = s[2] * ft[2] + s[5] * ft[5] + s[8] * ft[8];
+    const double u = a0 + a1 + a2;
+    if (lane < 9) {
+        const int xi = mid * SV + i;
+        xs[9 * mid + i] = u;
+        xd[9 * mid + i] = q.D[xi] * u;
+        x[xi] = alpha * u + (1.0 - alpha) * x[xi];
+    }
+#else
+    if (lane != 0) return;
+    double f[9];
+    for (int i = 0; i < 9; ++i) {
+        f[i] = xs[9 * mid + i];
+        if (mid < K - 1) {
+            const double* W = q.Wk + mid * 81 + 9 * i;
+            const double* fh = xs + 9 * (mid + 1);
+            double a0 = W[0] * fh[0] + W[3] * fh[3] + W[6] * fh[6];
+            double a1 = W[1] * fh[1] + W[4] * fh[4] + W[7] * fh[7];
+            double a2 = W[2] * fh[2] + W[5] * fh[5] + W[8] * fh[8];
+            f[i] -= a0 + a1 + a2;
+        }
+    }
+    for (int i = 0; i < 9; ++i) {
+        double a0 = symget(Si, i, 0, 9) * f[0] + symget(Si, i, 3, 9) * f[3] + symget(Si, i, 6, 9) * f[6];
+        double a1 = symget(Si, i, 1, 9) * f[1] + symget(Si, i, 4, 9) * f[4] + symget(Si, i, 7, 9) * f[7];
+        double a2 = symget(Si, i, 2, 9) * f[2] + symget(Si, i, 5, 9) * f[5] + symget(Si, i, 8, 9) * f[8];
+        const double u = a0 + a1 + a2;
+        const int xi = mid * SV + i;
+        xs[9 * mid + i] = u;
+        xd[9 * mid + i] = q.D[xi] * u;
+        x[xi] = alpha * u + (1.0 - alpha) * x[xi];
+    }
+#endif
+}
+
+// In: xs = reduced right-hand side.  Out: x blocks relaxed, xd = D .* (solution).  The
+// factorisation is two-sided (solve_factor 3d): W_k = C_k S_k^-1 in Wk[k] for k < mid,
+// W^_k = C_k' S^_{k+1}^-1 in Wk[k] for k >= mid.
+template <class Q>
+DEKF_FN void phase_sweeps(Q& q, double alpha) {
+    const int K = q.K, mid = K / 2;
+#if DEKF_DEVICE_BUILD
+    __builtin_amdgcn_s_setprio(3);  // the legs are the critical path and share their SIMDs
+#endif
+    two_waves([&] { sweep_chain<false, false>(q, 0, 1, mid, -1, alpha); },
+              [&] { sweep_chain<false, false>(q, K - 1, -1, K - 2 - mid, 0, alpha); });
+#if DEKF_DEVICE_BUILD
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    DEKF_SYNC();
+    DEKF_PROF_MARK(q, 3);
+    // g_k = S_k^-1 f_k is outside both recursions: 7 blocks (63 lanes) per tile, next to the meeting block
+    const int ngt = (K + 6) / 7;
+    wtiles(1 + ngt, [&](int tile, int lane) {
+        if (tile == 0) { sweep_mid_block(q, lane, alpha); return; }
+        const int blk = lane / 9, i = lane - 9 * blk, k = (tile - 1) * 7 + blk;
+        if (blk >= 7 || k >= K || k == mid) return;
+        const double* Si = q.Sinv + k * 45;
+        const double* f = q.xs + 9 * k;
+        double a0 = symget(Si, i, 0, 9) * f[0] + symget(Si, i, 3, 9) * f[3] + symget(Si, i, 6, 9) * f[6];
+        double a1 = symget(Si, i, 1, 9) * f[1] + symget(Si, i, 4, 9) * f[4] + symget(Si, i, 7, 9) * f[7];
+        double a2 = symget(Si, i, 2, 9) * f[2] + symget(Si, i, 5, 9) * f[5] + symget(Si, i, 8, 9) * f[8];
+        q.xd[9 * k + i] = a0 + a1 + a2;
+    });
+    DEKF_SYNC();
+    DEKF_PROF_MARK(q, 4);
+#if DEKF_DEVICE_BUILD
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    two_waves([&] { sweep_chain<true, true>(q, mid, -1, mid, 0, alpha); },
+              [&] { sweep_chain<true, true>(q, mid, 1, K - 1 - mid, -1, alpha); });
+#if DEKF_DEVICE_BUILD
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    DEKF_SYNC();
+    DEKF_PROF_MARK(q, 5);
+}
+
+// ---------------------------------------------------------------- R: rows
+// Everything a block of NR rows (one slack block: S is NR x NR) does in an iteration, in registers.
+// ar[j] = (A_x xd)(row r0+j), already scaled by E.  sapply(in, out): out = S^-1 in (S = P_s + sigma I +
+// rho (E D)^2 of the block, inverted by solve_factor 3a).  EQ: the rows are equalities by
+// construction (Meas, Dyn: l == u), so rho = rho_eq and the projection returns the bound itself.
+// State kept between iterations: zt[r] = t (slack forward-elimination result), at[r] = w (what the
+// next phase X gathers), q.cf[r] = rho E D (refreshed by rows_restart after every factorisation).
+template <int NR, bool EQ, class Q, class SA>
+DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, SA sapply, double alpha, double sigma) {
+    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+    double e[NR], cf[NR], c2[NR], v[NR], sl[NR], un[NR], rhs[NR], t[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        e[j] = q.E[r0 + j];
+        cf[j] = q.cf[r0 + j];
+        c2[j] = e[j] * q.D[sv0 + j];
+        v[j] = cf[j] * ar[j];
+    }
+    sapply(v, sl);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + j, sv = sv0 + j;
+        const double s = q.zt[r] + sl[j];       // slack solution
+        const double ztn = ar[j] - c2[j] * s;   // (A xt)(r)
+        const double xn = alpha * s + (1.0 - alpha) * q.x[sv];
+        q.x[sv] = xn;
+        const double zh = alpha * ztn + (1.0 - alpha) * q.z[r];
+        double rv, zn;
+        if (EQ) {
+            rv = rho_eq;
+            zn = q.lo[r];
+        } else {
+            rv = q.rho_at(r);
+            zn = dmin(dmax(zh + (1.0 / rv) * q.y[r], q.lo[r]), q.hi[r]);
+        }
+        const double yn = q.y[r] + rv * (zh - zn);
+        q.y[r] = yn;
+        q.z[r] = zn;
+        un[j] = rv * zn - yn;
+        rhs[j] = sigma * xn - c2[j] * un[j];
+    }
+    sapply(rhs, t);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        q.zt[r0 + j] = t[j];
+        q.at[r0 + j] = e[j] * (un[j] + cf[j] * t[j]);
+    }
+}
+// the same block from (x, z, y) alone: after a (re)factorisation, and for the cold start
+template <int NR, bool EQ, class Q, class SA>
+DEKF_FN void row_block_restart(Q& q, int r0, int sv0, SA sapply, double sigma) {
+    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+    double e[NR], cf[NR], un[NR], rhs[NR], t[NR];
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + j, sv = sv0 + j;
+        const double rv = EQ ? rho_eq : q.rho_at(r);
+        const double d = q.D[sv];
+        e[j] = q.E[r];
+        cf[j] = rv * e[j] * d;
+        un[j] = rv * q.z[r] - q.y[r];
+        rhs[j] = sigma * q.x[sv] - e[j] * d * un[j];
+    }
+    sapply(rhs, t);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        q.cf[r0 + j] = cf[j];
+        q.zt[r0 + j] = t[j];
+        q.at[r0 + j] = e[j] * (un[j] + cf[j] * t[j]);
+    }
+}
+
+template <int N>
+struct SymApply {  // out = S in, S symmetric N x N, packed upper triangle
+    const double* s;
+    DEKF_FN void operator()(const double* in, double* out) const {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            double a = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) a += symget(s, i, j, N) * in[j];
+            out[i] = a;
+        }
+    }
+};
+struct DiagApply3 {
+    const double* s;
+    DEKF_FN void operator()(const double* in, double* out) const {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i] = s[i] * in[i];
+    }
+};
+
+// RESTART = false: one iteration's row work (needs xd from phase_sweeps).  RESTART = true: rebuild
+// cf, t, w from (x, z, y).  Tiles: [Meas leg blocks][Dyn p+v 6-blocks][VO][Dyn bias].
+template <bool RESTART, class Q>
+DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
+    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM, SC = 12 + NM;
+    const int K = q.K, K1 = K - 1, nmeas = K * L;
+    const int ntm = (nmeas + 63) >> 6, ntd = (K1 + 63) >> 6;
+    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double *xd = q.xd, *E = q.E;
+    wtiles(ntm + 3 * ntd, [&](int tile, int lane) {
+        if (tile < ntm) {  // Meas: leg block (k, leg), A_meas = [0 I 0]
+            const int e = tile * 64 + lane;
+            if (e >= nmeas) return;
+            const int k = e / L, leg = e - k * L;
+            const int r0 = k * SC + 3 * leg, sv0 = k * SV + 9 + 3 * leg;
+            SymApply<3> S{q.Sv + e * 6};
+            if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
+            double ar[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * xd[9 * k + 3 + a];
+            row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma);
+            return;
+        }
+        const int td = tile - ntm;
+        const int kind = td < ntd ? 0 : (td < 2 * ntd ? 1 : 2);
+        const int k = (td - kind * ntd) * 64 + lane;
+        if (k >= K1) return;
+        const double* xk = xd + 9 * k;
+        if (kind == 0) {  // Dyn position + velocity rows: 6x6 slack block
+            const int r0 = k * SC + NM, sv0 = k * SV + 9 + NM;
+            SymApply<6> S{q.Sw + k * 24};
+            if (RESTART) { row_block_restart<6, true>(q, r0, sv0, S, sigma); return; }
+            const double* R = q.R + 9 * k;
+            double ar[6];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double rb = R[3 * a] * xk[6] + R[3 * a + 1] * xk[7] + R[3 * a + 2] * xk[8];
+                ar[a] = E[r0 + a] * (xk[a] + dt * xk[3 + a] - hdt2 * rb - xk[9 + a]);
+                ar[3 + a] = E[r0 + 3 + a] * (xk[3 + a] - dt * rb - xk[12 + a]);
+            }
+            row_block_update<6, true>(q, r0, sv0, ar, S, alpha, sigma);
+        } else if (kind == 1) {  // VO rows: +-inf box or equality, per-row rho
+            const int r0 = k * SC + NM + 9, sv0 = k * SV + 18 + NM;
+            SymApply<3> S{q.Sc + k * 6};
+            if (RESTART) { row_block_restart<3, false>(q, r0, sv0, S, sigma); return; }
+            double ar[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[a] - xk[9 + a]);
+            row_block_update<3, false>(q, r0, sv0, ar, S, alpha, sigma);
+        } else {  // Dyn bias rows: diagonal slack block
+            const int r0 = k * SC + NM + 6, sv0 = k * SV + 9 + NM + 6;
+            DiagApply3 S{q.Sw + k * 24 + 21};
+            if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
+            double ar[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[6 + a] - xk[15 + a]);
+            row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma);
+        }
+    });
+    DEKF_SYNC();
+}

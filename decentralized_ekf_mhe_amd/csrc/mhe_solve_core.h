@@ -90,6 +90,7 @@ struct SolveCtx {
     IdxT<L> ix;
     // LDS always
     double *x, *z, *y, *xt, *zt, *at, *xs, *xd, *tmp;
+    double* cf;  // per row rho E D (aliases xt, which only the factorisation uses otherwise)
     // LDS or HBM scratch
     double *D, *E, *lo, *hi, *Sv, *Sw, *Sc, *Sinv, *Wk, *R;
     // factor-time temporaries
@@ -638,468 +639,7 @@ DEKF_FN bool solve_factor(Q& q) {
     return ok;
 }
 
-// ---------------------------------------------------------------- one ADMM linear solve
-// Every loop below runs over ONE kind of row / variable (Meas rows, Dyn p/v rows, Dyn bias rows,
-// VO rows; x position / velocity / bias columns), so the 64 lanes of a wavefront execute the same
-// straight-line code instead of diverging three ways, and all index arithmetic is by constants.
-// Meas and Dyn rows are equalities by construction (l == u), so their rho is rho_eq without a
-// look-up; VO rows go through rho_at() because their bounds switch between +-inf and equality.
-
-// sum over the rows that touch x_k[a] / x_k[3+a] / x_k[6+a] of A(row, col) * w(row), w(row) already
-// carrying the row scaling E[row]
-template <class Q, class WF>
-DEKF_FN double gather_pcol(const Q& q, int k, int a, WF w) {
-    constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
-    double g = 0.0;
-    if (k < q.K - 1) g += w(k * SC + NM + a) + w(k * SC + NM + 9 + a);
-    if (k > 0) g -= w((k - 1) * SC + NM + a) + w((k - 1) * SC + NM + 9 + a);
-    return g;
-}
-template <class Q, class WF>
-DEKF_FN double gather_vcol(const Q& q, int k, int a, WF w) {
-    constexpr int L = Q::LEGS, NM = 3 * L, SC = 12 + NM;
-    double g = 0.0;
-#pragma unroll
-    for (int leg = 0; leg < L; ++leg) g += w(k * SC + 3 * leg + a);
-    if (k < q.K - 1) g += w(k * SC + NM + 3 + a) + q.c.dt * w(k * SC + NM + a);
-    if (k > 0) g -= w((k - 1) * SC + NM + 3 + a);
-    return g;
-}
-template <class Q, class WF>
-DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
-    constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
-    double g = 0.0;
-    if (k < q.K - 1) {
-        const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-        const double* R = q.R + 9 * k;
-        g += w(k * SC + NM + 6 + a);
-#pragma unroll
-        for (int r = 0; r < 3; ++r) g -= R[3 * r + a] * (hdt2 * w(k * SC + NM + r) + dt * w(k * SC + NM + 3 + r));
-    }
-    if (k > 0) g -= w((k - 1) * SC + NM + 6 + a);
-    return g;
-}
-
-#if DEKF_DEVICE_BUILD
-// Block-tridiagonal forward / backward sweeps with the running 9-vector held in registers of
-// lanes 0..8 of the first wavefront and broadcast with v_readlane: the dependent chain of one
-// step is 18 v_readlane + 9 FMA, with no LDS store->load round trip and therefore no exposure to
-// the LDS queue the other wavefronts keep busy.  Same arithmetic as the w0for form in
-// admm_linear (tests/hostsim runs that one); lanes >= 9 mirror lane 8 and never store.
-DEKF_FN double readlane_f64(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-template <class Q>
-DEKF_FN void tri_sweeps_registers(Q& q) {
-    constexpr int SV = 21 + 3 * Q::LEGS;
-    const int K = q.K;
-    double *xs = q.xs, *xd = q.xd;
-    const int lane = DEKF_LANE();
-    const int i = lane < 9 ? lane : 8;
-    const bool act = lane < 9;
-    double f = xs[i];
-    for (int k = 1; k < K; ++k) {
-        const double* wr = q.Wk + (k - 1) * 81 + 9 * i;
-        double w[9], ft[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = wr[t];
-        double b = xs[9 * k + i];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) ft[t] = readlane_f64(f, t);
-        double a0 = w[0] * ft[0] + w[3] * ft[3] + w[6] * ft[6];
-        double a1 = w[1] * ft[1] + w[4] * ft[4] + w[7] * ft[7];
-        double a2 = w[2] * ft[2] + w[5] * ft[5] + w[8] * ft[8];
-        f = b - (a0 + a1 + a2);
-        if (act) xs[9 * k + i] = f;
-    }
-    wave_sync();
-    for (int e = lane; e < K * 9; e += WAVE) {  // g_k = S_k^-1 f_k, all k at once
-        int k = e / 9, r = e - 9 * k;
-        const double* Si = q.Sinv + k * 45;
-        const double* fk = xs + 9 * k;
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-#pragma unroll
-        for (int t = 0; t < 9; t += 3) {
-            a0 += symget(Si, r, t, 9) * fk[t];
-            a1 += symget(Si, r, t + 1, 9) * fk[t + 1];
-            a2 += symget(Si, r, t + 2, 9) * fk[t + 2];
-        }
-        xd[e] = a0 + a1 + a2;
-    }
-    wave_sync();
-    double u = xd[9 * (K - 1) + i];
-    if (act) { xs[9 * (K - 1) + i] = u; xd[9 * (K - 1) + i] = q.D[(K - 1) * SV + i] * u; }
-    for (int k = K - 2; k >= 0; --k) {
-        const double* W = q.Wk + k * 81;
-        double w[9], ut[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = W[9 * t + i];
-        double g = xd[9 * k + i];
-        double dk = q.D[k * SV + i];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) ut[t] = readlane_f64(u, t);
-        double a0 = w[0] * ut[0] + w[3] * ut[3] + w[6] * ut[6];
-        double a1 = w[1] * ut[1] + w[4] * ut[4] + w[7] * ut[7];
-        double a2 = w[2] * ut[2] + w[5] * ut[5] + w[8] * ut[8];
-        u = g - (a0 + a1 + a2);
-        if (act) { xs[9 * k + i] = u; xd[9 * k + i] = dk * u; }
-    }
-}
-#endif
-
-#if DEKF_DEVICE_BUILD
-// ALTERNATIVE (compiled only with -DDEKF_SWEEP_MFMA; measured and rejected in round 1, see below):
-// block-tridiagonal forward / backward sweeps on the matrix cores.  One step of either recurrence
-// is a 9x9 mat-vec plus a vector, f_k = b_k - W f_{k-1}: as D = C + A*B with A = -W (padded to
-// 16 x 12, three k-steps of v_mfma_f64_16x16x4_f64), B = the previous vector in column 0 and
-// C = b_k in column 0.  On gfx950 the f64 accumulator map is D[row = (lane>>4) + 4*reg][col = lane&15]
-// and the B operand map is B[k = lane>>4][col = lane&15] (probe: tools/probes/mfma_f64_probe.hip), so
-// register `s` of the previous result IS the B operand of k-step s in the same lane: the dependent
-// chain of a step is three MFMAs with no cross-lane traffic at all (the hardware does the broadcast
-// that cost 18 v_readlane per step before).  Columns 1..15 stay identically zero.  Same arithmetic
-// as the w0for form in admm_linear (tests/hostsim runs that one).
-// Measured on MI355X (tools/profile_sections.py, Go1 B=4096): correct (all GPU parity tests pass) but
-// ~980 ticks per step against ~450 for the v_readlane form: the dependent f64 MFMA costs 64 (D->C) to
-// 96 (D->B) ticks on an idle chip (tools/probes/mfma_f64_latency.hip), three per step, plus the
-// MFMA->VALU hazards and the operand loads in the chain; with only 81 of 3072 MACs useful it does not pay.
-typedef double dekf_v4d __attribute__((ext_vector_type(4)));
-template <class Q>
-DEKF_FN void tri_sweeps_mfma(Q& q) {
-    constexpr int SV = 21 + 3 * Q::LEGS;
-    const int K = q.K;
-    double *xs = q.xs, *xd = q.xd;
-    const int l = DEKF_LANE();
-    const int ci = l & 15, kq = l >> 4;          // A row / B,C,D column ; k-quad = accumulator row group
-    const int cr = ci < 9 ? ci : 0;              // clamped row for the (masked) A loads
-    const bool arow = ci < 9, col0 = ci == 0;
-    const bool r2 = kq == 0;                     // row 8 = kq + 4*2 exists only for kq == 0
-    // accumulator rows held by this lane: kq, kq+4, kq+8 (reg 3 = rows 12..15 is always zero)
-    // every load below is unconditional (in-bounds for all lanes) and masked by a multiply: a
-    // branch per operand would serialise one LDS round trip per branch inside the dependent chain
-    const double am = arow ? -1.0 : 0.0, am2 = (arow && r2) ? -1.0 : 0.0;
-    const double cm = col0 ? 1.0 : 0.0, cm2 = (col0 && r2) ? 1.0 : 0.0;
-    dekf_v4d f = {cm * xs[kq], cm * xs[kq + 4], cm2 * xs[8], 0.0};
-    for (int k = 1; k < K; ++k) {
-        const double* W = q.Wk + (k - 1) * 81 + 9 * cr;
-        double a0 = am * W[kq];
-        double a1 = am * W[4 + kq];
-        double a2 = am2 * W[8];
-        dekf_v4d c = {cm * xs[9 * k + kq], cm * xs[9 * k + kq + 4], cm2 * xs[9 * k + 8], 0.0};
-        dekf_v4d acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, f[0], c, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, f[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, f[2], acc, 0, 0, 0);
-        f = acc;
-        if (col0) { xs[9 * k + kq] = f[0]; xs[9 * k + kq + 4] = f[1]; if (r2) xs[9 * k + 8] = f[2]; }
-    }
-    wave_sync();
-    for (int e = l; e < K * 9; e += WAVE) {  // g_k = S_k^-1 f_k, all k at once
-        int k = e / 9, r = e - 9 * k;
-        const double* Si = q.Sinv + k * 45;
-        const double* fk = xs + 9 * k;
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int t = 0; t < 9; t += 3) {
-            s0 += symget(Si, r, t, 9) * fk[t];
-            s1 += symget(Si, r, t + 1, 9) * fk[t + 1];
-            s2 += symget(Si, r, t + 2, 9) * fk[t + 2];
-        }
-        xd[e] = s0 + s1 + s2;
-    }
-    wave_sync();
-    dekf_v4d u = {0.0, 0.0, 0.0, 0.0};
-    if (col0) {
-        const int o = 9 * (K - 1);
-        u[0] = xd[o + kq]; u[1] = xd[o + kq + 4]; if (r2) u[2] = xd[o + 8];
-        const double* Dk = q.D + (K - 1) * SV;
-        xs[o + kq] = u[0]; xs[o + kq + 4] = u[1];
-        xd[o + kq] = Dk[kq] * u[0]; xd[o + kq + 4] = Dk[kq + 4] * u[1];
-        if (r2) { xs[o + 8] = u[2]; xd[o + 8] = Dk[8] * u[2]; }
-    }
-    for (int k = K - 2; k >= 0; --k) {
-        const double* W = q.Wk + k * 81 + cr;   // A = -W': A[ci][kk] = -W[kk][ci]
-        double a0 = am * W[9 * kq];
-        double a1 = am * W[9 * (4 + kq)];
-        double a2 = am2 * W[72];
-        dekf_v4d c = {cm * xd[9 * k + kq], cm * xd[9 * k + kq + 4], cm2 * xd[9 * k + 8], 0.0};
-        dekf_v4d acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, u[0], c, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, u[1], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, u[2], acc, 0, 0, 0);
-        u = acc;
-        if (col0) {
-            const double* Dk = q.D + k * SV;
-            xs[9 * k + kq] = u[0]; xs[9 * k + kq + 4] = u[1];
-            xd[9 * k + kq] = Dk[kq] * u[0]; xd[9 * k + kq + 4] = Dk[kq + 4] * u[1];
-            if (r2) { xs[9 * k + 8] = u[2]; xd[9 * k + 8] = Dk[8] * u[2]; }
-        }
-    }
-}
-#endif
-
-// One leg of the two-sided block-tridiagonal solve: a chain of `steps` dependent 9x9 mat-vecs
-//     v_new = rhs[k_new] - M v_prev,   k_new = k_prev + dk,   M = Wk[k_new + wofs] (TR: transposed)
-// starting from the vector stored at block k0.  Forward legs (BWD = false) read rhs from xs and
-// overwrite it; outward legs (BWD = true) read rhs = g from xd and leave xs = u, xd = D .* u.
-// Device: the running vector sits in registers of lanes 0..8 of the calling wavefront and is
-// broadcast with v_readlane (18 per step), so the dependent chain never touches LDS or a barrier;
-// all 64 lanes execute it (lanes >= 9 mirror lane 8 and never store).  Host build: plain loops.
-template <bool TR, bool BWD, class Q>
-DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs) {
-    constexpr int SV = 21 + 3 * Q::LEGS;
-    double *xs = q.xs, *xd = q.xd;
-#if DEKF_DEVICE_BUILD
-    const int lane = DEKF_LANE() & 63;
-    const int i = lane < 9 ? lane : 8;
-    const bool act = lane < 9;
-    double v = xs[9 * k0 + i];
-    for (int s = 1; s <= steps; ++s) {
-        const int kn = k0 + s * dk;
-        const double* W = q.Wk + (kn + wofs) * 81;
-        double w[9], vt[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = TR ? W[9 * t + i] : W[9 * i + t];
-        const double rhs = BWD ? xd[9 * kn + i] : xs[9 * kn + i];
-        const double dsc = BWD ? q.D[kn * SV + i] : 0.0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) vt[t] = readlane_f64(v, t);
-        double a0 = w[0] * vt[0] + w[3] * vt[3] + w[6] * vt[6];
-        double a1 = w[1] * vt[1] + w[4] * vt[4] + w[7] * vt[7];
-        double a2 = w[2] * vt[2] + w[5] * vt[5] + w[8] * vt[8];
-        v = rhs - (a0 + a1 + a2);
-        if (act) {
-            xs[9 * kn + i] = v;
-            if (BWD) xd[9 * kn + i] = dsc * v;
-        }
-    }
-#else
-    double v[9], nv[9];
-    for (int i = 0; i < 9; ++i) v[i] = xs[9 * k0 + i];
-    for (int s = 1; s <= steps; ++s) {
-        const int kn = k0 + s * dk;
-        const double* W = q.Wk + (kn + wofs) * 81;
-        for (int i = 0; i < 9; ++i) {
-            double w[9];
-            for (int t = 0; t < 9; ++t) w[t] = TR ? W[9 * t + i] : W[9 * i + t];
-            double a0 = w[0] * v[0] + w[3] * v[3] + w[6] * v[6];
-            double a1 = w[1] * v[1] + w[4] * v[4] + w[7] * v[7];
-            double a2 = w[2] * v[2] + w[5] * v[5] + w[8] * v[8];
-            nv[i] = (BWD ? xd[9 * kn + i] : xs[9 * kn + i]) - (a0 + a1 + a2);
-        }
-        for (int i = 0; i < 9; ++i) {
-            v[i] = nv[i];
-            xs[9 * kn + i] = v[i];
-            if (BWD) xd[9 * kn + i] = q.D[kn * SV + i] * v[i];
-        }
-    }
-#endif
-}
-
-// In: xt = right-hand side (n), at = u (consumed by the caller).  Out: xs = xt on the x blocks
-// (K*9), at[row] = xt of that row's slack, zt = A xt.
-template <class Q>
-DEKF_FN void admm_linear(Q& q) {
-    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM, SC = 12 + NM;
-    const int K = q.K, K1 = q.K - 1;
-    double *xt = q.xt, *zt = q.zt, *at = q.at, *xs = q.xs, *xd = q.xd;
-    const double *D = q.D, *E = q.E;
-    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
-
-    // B. slack forward elimination: t = S^-1 rhs_s -> zt[row];  E rho beta t -> at[row]
-    wfor_nosync(K * NM, [&](int e) {  // Meas rows, 3x3 block per leg
-        int k = e / NM, o = e - k * NM, leg = o / 3, a = o - 3 * leg;
-        const double* si = q.Sv + (k * L + leg) * 6;
-        const double* in = xt + k * SV + 9 + 3 * leg;
-        double t = symget(si, a, 0, 3) * in[0] + symget(si, a, 1, 3) * in[1] + symget(si, a, 2, 3) * in[2];
-        int r = k * SC + o;
-        zt[r] = t;
-        at[r] = rho_eq * E[r] * E[r] * D[k * SV + 9 + o] * t;
-    });
-    wfor_nosync(K1 * 6, [&](int e) {  // Dyn rows, position / velocity: 6x6 block
-        int k = e / 6, o = e - 6 * k;
-        const double* sw = q.Sw + k * 24;
-        const double* in = xt + k * SV + 9 + NM;
-        double t = 0.0;
-#pragma unroll
-        for (int u = 0; u < 6; ++u) t += symget(sw, o, u, 6) * in[u];
-        int r = k * SC + NM + o;
-        zt[r] = t;
-        at[r] = rho_eq * E[r] * E[r] * D[k * SV + 9 + NM + o] * t;
-    });
-    wfor_nosync(K1 * 3, [&](int e) {  // Dyn rows, bias: diagonal
-        int k = e / 3, a = e - 3 * k;
-        int r = k * SC + NM + 6 + a, sv = k * SV + 9 + NM + 6 + a;
-        double t = q.Sw[k * 24 + 21 + a] * xt[sv];
-        zt[r] = t;
-        at[r] = rho_eq * E[r] * E[r] * D[sv] * t;
-    });
-    wfor(K1 * 3, [&](int e) {  // VO rows, 3x3 block
-        int k = e / 3, a = e - 3 * k;
-        const double* si = q.Sc + k * 6;
-        const double* in = xt + k * SV + 18 + NM;
-        double t = symget(si, a, 0, 3) * in[0] + symget(si, a, 1, 3) * in[1] + symget(si, a, 2, 3) * in[2];
-        int r = k * SC + NM + 9 + a;
-        zt[r] = t;
-        at[r] = q.rho_at(r) * E[r] * E[r] * D[k * SV + 18 + NM + a] * t;
-    });
-    DEKF_PROF_MARK(q, 3);
-    // C. reduced right-hand side on the x blocks
-    auto wh = [&](int r) { return at[r]; };
-    wfor_nosync(K * 3, [&](int e) {
-        int k = e / 3, a = e - 3 * k;
-        xs[9 * k + a] = xt[k * SV + a] + D[k * SV + a] * gather_pcol(q, k, a, wh);
-    });
-    wfor_nosync(K * 3, [&](int e) {
-        int k = e / 3, a = e - 3 * k;
-        xs[9 * k + 3 + a] = xt[k * SV + 3 + a] + D[k * SV + 3 + a] * gather_vcol(q, k, a, wh);
-    });
-    wfor(K * 3, [&](int e) {
-        int k = e / 3, a = e - 3 * k;
-        xs[9 * k + 6 + a] = xt[k * SV + 6 + a] + D[k * SV + 6 + a] * gather_bcol(q, k, a, wh);
-    });
-    DEKF_PROF_MARK(q, 4);
-    // D. two-sided block-tridiagonal solve (factorisation: solve_factor 3d).  Wavefront 0 eliminates
-    //    blocks 0..mid-1 downwards while wavefront 1 eliminates K-1..mid+1 upwards; they meet in block
-    //    mid; g_k = S_k^-1 f_k for all k at once (it is outside both recursions); then both wavefronts
-    //    substitute outwards from the middle.  Half the sequential depth of a one-sided sweep, no
-    //    workgroup barrier inside a leg.  Leaves xs = u and xd = D .* u.
-    {
-        const int mid = K / 2;
-#if DEKF_DEVICE_BUILD
-        __builtin_amdgcn_s_setprio(3);  // the legs are the critical path and share their SIMDs
-#endif
-        two_waves([&] { sweep_chain<false, false>(q, 0, 1, mid - 1, -1); },
-                  [&] { sweep_chain<false, false>(q, K - 1, -1, K - 2 - mid, 0); });
-#if DEKF_DEVICE_BUILD
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        DEKF_SYNC();
-        wfor(9, [&](int i) {  // the meeting block
-            double acc = 0.0;
-            if (mid > 0) {
-                const double* W = q.Wk + (mid - 1) * 81 + 9 * i;
-                const double* f = xs + 9 * (mid - 1);
-                for (int t = 0; t < 9; ++t) acc += W[t] * f[t];
-            }
-            if (mid < K - 1) {
-                const double* W = q.Wk + mid * 81 + 9 * i;
-                const double* f = xs + 9 * (mid + 1);
-                for (int t = 0; t < 9; ++t) acc += W[t] * f[t];
-            }
-            xs[9 * mid + i] -= acc;
-        });
-        wfor(K * 9, [&](int e) {
-            int k = e / 9, i = e - 9 * k;
-            const double* Si = q.Sinv + k * 45;
-            const double* f = xs + 9 * k;
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-            for (int t = 0; t < 9; t += 3) {
-                a0 += symget(Si, i, t, 9) * f[t];
-                a1 += symget(Si, i, t + 1, 9) * f[t + 1];
-                a2 += symget(Si, i, t + 2, 9) * f[t + 2];
-            }
-            xd[e] = a0 + a1 + a2;
-        });
-        wfor(9, [&](int i) {
-            double u = xd[9 * mid + i];
-            xs[9 * mid + i] = u;
-            xd[9 * mid + i] = D[mid * SV + i] * u;
-        });
-#if DEKF_DEVICE_BUILD
-        __builtin_amdgcn_s_setprio(3);
-#endif
-        two_waves([&] { sweep_chain<true, true>(q, mid, -1, mid, 0); },
-                  [&] { sweep_chain<true, true>(q, mid, 1, K - 1 - mid, -1); });
-#if DEKF_DEVICE_BUILD
-        __builtin_amdgcn_s_setprio(0);
-#endif
-    }
-    DEKF_SYNC();
-    DEKF_PROF_MARK(q, 5);
-    // F. a = A_x xt_x -> at[row];  rho beta a -> xt[slack of the row]
-    wfor_nosync(K * NM, [&](int e) {  // Meas
-        int k = e / NM, o = e - k * NM, a = o % 3;
-        int r = k * SC + o, sv = k * SV + 9 + o;
-        double ar = E[r] * xd[9 * k + 3 + a];
-        at[r] = ar;
-        xt[sv] = rho_eq * E[r] * D[sv] * ar;
-    });
-    wfor_nosync(K1 * 3, [&](int e) {  // Dyn position rows
-        int k = e / 3, a = e - 3 * k;
-        const double* R = q.R + 9 * k + 3 * a;
-        const double* xk = xd + 9 * k;
-        int r = k * SC + NM + a, sv = k * SV + 9 + NM + a;
-        double ar = E[r] * (xk[a] + dt * xk[3 + a] - hdt2 * (R[0] * xk[6] + R[1] * xk[7] + R[2] * xk[8]) - xk[9 + a]);
-        at[r] = ar;
-        xt[sv] = rho_eq * E[r] * D[sv] * ar;
-    });
-    wfor_nosync(K1 * 3, [&](int e) {  // Dyn velocity rows
-        int k = e / 3, a = e - 3 * k;
-        const double* R = q.R + 9 * k + 3 * a;
-        const double* xk = xd + 9 * k;
-        int r = k * SC + NM + 3 + a, sv = k * SV + 9 + NM + 3 + a;
-        double ar = E[r] * (xk[3 + a] - dt * (R[0] * xk[6] + R[1] * xk[7] + R[2] * xk[8]) - xk[12 + a]);
-        at[r] = ar;
-        xt[sv] = rho_eq * E[r] * D[sv] * ar;
-    });
-    wfor_nosync(K1 * 3, [&](int e) {  // Dyn bias rows
-        int k = e / 3, a = e - 3 * k;
-        const double* xk = xd + 9 * k;
-        int r = k * SC + NM + 6 + a, sv = k * SV + 9 + NM + 6 + a;
-        double ar = E[r] * (xk[6 + a] - xk[15 + a]);
-        at[r] = ar;
-        xt[sv] = rho_eq * E[r] * D[sv] * ar;
-    });
-    wfor(K1 * 3, [&](int e) {  // VO rows
-        int k = e / 3, a = e - 3 * k;
-        const double* xk = xd + 9 * k;
-        int r = k * SC + NM + 9 + a, sv = k * SV + 18 + NM + a;
-        double ar = E[r] * (xk[a] - xk[9 + a]);
-        at[r] = ar;
-        xt[sv] = q.rho_at(r) * E[r] * D[sv] * ar;
-    });
-    DEKF_PROF_MARK(q, 7);
-    // G. slack back-substitution s = t + S^-1 (rho beta a) -> at[row];  zt = a - beta s
-    wfor_nosync(K * NM, [&](int e) {
-        int k = e / NM, o = e - k * NM, leg = o / 3, a = o - 3 * leg;
-        const double* si = q.Sv + (k * L + leg) * 6;
-        const double* in = xt + k * SV + 9 + 3 * leg;
-        int r = k * SC + o;
-        double sl = zt[r] + symget(si, a, 0, 3) * in[0] + symget(si, a, 1, 3) * in[1] + symget(si, a, 2, 3) * in[2];
-        zt[r] = at[r] - E[r] * D[k * SV + 9 + o] * sl;
-        at[r] = sl;
-    });
-    wfor_nosync(K1 * 6, [&](int e) {
-        int k = e / 6, o = e - 6 * k;
-        const double* sw = q.Sw + k * 24;
-        const double* in = xt + k * SV + 9 + NM;
-        int r = k * SC + NM + o;
-        double sl = zt[r];
-#pragma unroll
-        for (int u = 0; u < 6; ++u) sl += symget(sw, o, u, 6) * in[u];
-        zt[r] = at[r] - E[r] * D[k * SV + 9 + NM + o] * sl;
-        at[r] = sl;
-    });
-    wfor_nosync(K1 * 3, [&](int e) {
-        int k = e / 3, a = e - 3 * k;
-        int r = k * SC + NM + 6 + a, sv = k * SV + 9 + NM + 6 + a;
-        double sl = zt[r] + q.Sw[k * 24 + 21 + a] * xt[sv];
-        zt[r] = at[r] - E[r] * D[sv] * sl;
-        at[r] = sl;
-    });
-    wfor(K1 * 3, [&](int e) {
-        int k = e / 3, a = e - 3 * k;
-        const double* si = q.Sc + k * 6;
-        const double* in = xt + k * SV + 18 + NM;
-        int r = k * SC + NM + 9 + a;
-        double sl = zt[r] + symget(si, a, 0, 3) * in[0] + symget(si, a, 1, 3) * in[1] + symget(si, a, 2, 3) * in[2];
-        zt[r] = at[r] - E[r] * D[k * SV + 18 + NM + a] * sl;
-        at[r] = sl;
-    });
-    DEKF_PROF_MARK(q, 8);
-}
+#include "mhe_admm_core.h"
 
 struct SolveInfo {
     int iters, status, rho_updates;
@@ -1125,6 +665,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         q.z = p; p += lay.m_pad;
         q.y = p; p += lay.m_pad;
         q.xt = p; p += lay.n_pad;
+        q.cf = q.xt;
         q.zt = p; p += lay.m_pad;
         q.at = p; p += lay.m_pad;
         q.xs = p; p += 9 * NH;
@@ -1188,10 +729,6 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         at[r] = 0.0;  // u = rho z - y of the cold start
     });
     bool ok = solve_factor(q);
-    wfor(n + m, [&](int e) {  // cold start: u = 0 and a zero right-hand side (PA may have aliased xt | zt | at)
-        if (e < n) xt[e] = 0.0;
-        else at[e - n] = 0.0;
-    });
     double qs[9];  // scaled linear cost on x_0 (registers for the checks, LDS copy for the per-lane look-ups)
     for (int j = 0; j < 9; ++j) qs[j] = q.cc * q.D[ix.x(0, j)] * q.np[j];
     wfor(9, [&](int j) { q.tmp[162 + j] = q.cc * q.D[ix.x(0, j)] * q.np[j]; });
@@ -1199,56 +736,14 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     const double cinv = 1.0 / q.cc;
     int iter = 0;
     bool done = false;
+    if (ok) phase_rows<true>(q, alpha, sigma);  // cold start: cf, t = 0, w = 0 (the factorisation scratch aliased xt | zt | at)
     DEKF_PROF_MARK(q, 1);
     while (ok && !done && iter < c.max_iter) {
         ++iter;
-        // A. right-hand side sigma x - q + A'u on the x columns (u = rho z - y sits in `at`; the slack
-        //    entries of the right-hand side were written together with u by the previous update)
-        {
-            constexpr int NM = 3 * L, SV = 21 + NM;
-            const double *D = q.D, *E = q.E;
-            const double* qsl = q.tmp + 162;
-            auto wu = [&](int r) { return E[r] * at[r]; };
-            wfor_nosync(K * 3, [&](int e) {
-                int k = e / 3, a = e - 3 * k, i = k * SV + a;
-                xt[i] = sigma * x[i] - (k == 0 ? qsl[a] : 0.0) + D[i] * gather_pcol(q, k, a, wu);
-            });
-            wfor_nosync(K * 3, [&](int e) {
-                int k = e / 3, a = e - 3 * k, i = k * SV + 3 + a;
-                xt[i] = sigma * x[i] - (k == 0 ? qsl[3 + a] : 0.0) + D[i] * gather_vcol(q, k, a, wu);
-            });
-            wfor(K * 3, [&](int e) {
-                int k = e / 3, a = e - 3 * k, i = k * SV + 6 + a;
-                xt[i] = sigma * x[i] - (k == 0 ? qsl[6 + a] : 0.0) + D[i] * gather_bcol(q, k, a, wu);
-            });
-        }
+        phase_xcols(q, sigma);
         DEKF_PROF_MARK(q, 2);
-        admm_linear(q);
-        // H. x, z, y updates (alpha relaxation, projection onto [lo, hi]); u and the slack part of
-        //    the next right-hand side (every slack lives in exactly one row: slack = k*SV + 9 + q)
-        {
-            constexpr int NM = 3 * L, SV = 21 + NM, SC = 12 + NM;
-            const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho, rho_eq_inv = 1.0 / rho_eq;
-            wfor_nosync(K * 9, [&](int e) {
-                int k = e / 9, i = k * SV + (e - 9 * k);
-                x[i] = alpha * q.xs[e] + (1.0 - alpha) * x[i];
-            });
-            wfor(m, [&](int r) {
-                int k = r / SC, qq = r - k * SC, sv = k * SV + 9 + qq;
-                x[sv] = alpha * at[r] + (1.0 - alpha) * x[sv];
-                bool eq = qq < NM + 9;
-                double rv = eq ? rho_eq : q.rho_at(r);
-                double rinv = eq ? rho_eq_inv : 1.0 / rv;
-                double zh = alpha * zt[r] + (1.0 - alpha) * z[r];
-                double zn = dmin(dmax(zh + rinv * y[r], q.lo[r]), q.hi[r]);
-                double yn = y[r] + rv * (zh - zn);
-                y[r] = yn;
-                z[r] = zn;
-                double un = rv * zn - yn;
-                at[r] = un;
-                xt[sv] = sigma * x[sv] - q.E[r] * q.D[sv] * un;
-            });
-        }
+        phase_sweeps(q, alpha);
+        phase_rows<false>(q, alpha, sigma);
         DEKF_PROF_MARK(q, 9);
         bool can_check = c.check_termination > 0 && (iter % c.check_termination == 0);
         bool adapt_now = c.adaptive_rho && c.adaptive_rho_interval > 0 && (iter % c.adaptive_rho_interval == 0);
@@ -1309,13 +804,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
                     info.rho_updates++;
                     DEKF_SYNC();
                     ok = solve_factor(q);
-                    wfor(m, [&](int r) {  // the factorisation scratch may alias xt | zt | at
-                        constexpr int SVc = 21 + 3 * L, SCc = 12 + 3 * L;
-                        int k = r / SCc, sv = k * SVc + 9 + (r - k * SCc);
-                        double un = q.rho_at(r) * z[r] - y[r];
-                        at[r] = un;
-                        xt[sv] = sigma * x[sv] - q.E[r] * q.D[sv] * un;
-                    });
+                    if (ok) phase_rows<true>(q, alpha, sigma);  // cf, t, w for the new rho (the scratch aliased xt | zt | at)
                     DEKF_PROF_MARK(q, 11);
                 }
             }

@@ -220,6 +220,25 @@ inline void two_waves(F0 f0, F1 f1) {
 }
 #endif
 
+// Wave-granular work split: `ntiles` tiles of up to 64 lanes; a tile is executed by ONE wavefront
+// (tile t by wavefront t mod #wavefronts), so a branch on the tile index is wave-uniform (scalar) and
+// every wavefront runs ONE straight-line body per tile.  f(tile, lane) with lane = 0..63 is called
+// for all 64 lanes of the wavefront (cross-lane reads inside f are legal).  No trailing sync.
+#if DEKF_DEVICE_BUILD
+template <class F>
+DEKF_FN void wtiles(int ntiles, F f) {
+    const int nw = DEKF_NLANES() > WAVE ? DEKF_NLANES() >> 6 : 1;
+    const int lane = DEKF_LANE() & 63;
+    for (int t = DEKF_LANE() >> 6; t < ntiles; t += nw) f(t, lane);
+}
+#else
+template <class F>
+inline void wtiles(int ntiles, F f) {
+    for (int t = 0; t < ntiles; ++t)
+        for (int lane = 0; lane < WAVE; ++lane) f(t, lane);
+}
+#endif
+
 DEKF_FN double dmax(double a, double b) { return a > b ? a : b; }
 DEKF_FN double dmin(double a, double b) { return a < b ? a : b; }
 

@@ -21,10 +21,9 @@ from decentralized_ekf_mhe_amd import capi, go1_params  # noqa: E402
 from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_device  # noqa: E402
 from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
 
-NAMES = ["0 copy R + Ruiz scaling", "1 bounds + first factorisation", "2 A: right-hand side", "3 B: slack forward",
-         "4 C: gather to x blocks", "5 D: tridiagonal sweeps (wave 0)", "6 E: D.*x", "7 F: rows A_x x",
-         "8 G: slack back-substitution", "9 H: x/z/y update", "10 residuals + termination", "11 rho update + refactor",
-         "12 epilogue", "13 total"]
+NAMES = ["0 copy R + Ruiz scaling", "1 bounds + first factorisation + restart", "2 X: reduced rhs on x columns",
+         "3 S1: forward legs (2 waves)", "4 S2: meeting block | g_k", "5 S3: outward legs (2 waves)", "6 -", "7 -", "8 -",
+         "9 R: fused row blocks", "10 residuals + termination", "11 rho update + refactor", "12 epilogue", "13 total"]
 
 
 def main():
