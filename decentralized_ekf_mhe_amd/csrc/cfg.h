@@ -18,7 +18,9 @@
 
 namespace dekf {
 
+#ifndef DEKF_SOLVE_THREADS
 #define DEKF_SOLVE_THREADS 256  // lanes of the workgroup that solves one instance (4 wavefronts)
+#endif
 
 constexpr double OSQP_INFTY = 1e30;
 constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e6, RHO_EQ_OVER_RHO_INEQ = 1e3, RHO_TOL = 1e-4;
@@ -62,6 +64,12 @@ DEKF_FN double symget(const double* s, int i, int j, int n) {
     int lo = i < j ? i : j, hi = i < j ? j : i;
     return s[(lo * (2 * n - 1 - lo)) / 2 + hi];
 }
+
+// the same element for a RUN-TIME row i and a COMPILE-TIME column t: one select between two affine
+// forms (t < i: column i of row t, a constant plus i; else row i, symrow_start(i) plus a constant)
+// instead of min / max / multiply per element
+DEKF_FN int symrow_start(int i, int n) { return (i * (2 * n - 1 - i)) / 2; }
+DEKF_FN int symrow_idx(int i, int row_start, int t, int n) { return t < i ? (t * (2 * n - 1 - t)) / 2 + i : row_start + t; }
 
 // variable / row indices of the QP in the reference's own order
 // (x_k v_k w_k c_k per step; Meas_k Dyn_k VO_k per step — SURVEY.md Appendix A)

@@ -1,6 +1,7 @@
 // dekf_capi.hip — implementation of the C ABI in include/dekf.h on top of the gfx950 kernels.
 // No CPU fallback: without a usable HIP device dekf_create fails with DEKF_ERR_NO_DEVICE.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include <cstdio>
 #include <cstring>
@@ -164,6 +165,10 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     SolveLayout lay;
     lay.init(c.N, c.L);
     h->lds_solve = lay.lds_bytes();
+#ifdef DEKF_PROFILE
+    // diagnostic build only: DEKF_DEBUG_LDS_PAD=<bytes> inflates the request (e.g. to force one workgroup per CU)
+    if (const char* pad = getenv("DEKF_DEBUG_LDS_PAD")) h->lds_solve += (size_t)atol(pad);
+#endif
     {
         typedef void (*SolveFn)(DevCfg, DevState, int, int, int);
         static const SolveFn table[4][3] = {
@@ -171,6 +176,14 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             {k_mhe_solve_ll_3, k_mhe_solve_lg_3, k_mhe_solve_gg_3}, {k_mhe_solve_ll_4, k_mhe_solve_lg_4, k_mhe_solve_gg_4}};
         h->solve_kernel = table[c.L - 1][lay.pa_in_lds() ? 0 : (lay.factor_in_lds() ? 1 : 2)];
         if (c.L == 4 && c.N == 20 && lay.pa_in_lds()) h->solve_kernel = k_mhe_solve_ll_4_n20;
+#ifdef DEKF_PROFILE
+        // diagnostic build only: DEKF_DEBUG_PLACEMENT=1|2 forces the _lg / _gg placement (2 also shrinks the LDS request)
+        if (const char* pl = getenv("DEKF_DEBUG_PLACEMENT")) {
+            int p = atoi(pl);
+            if (p == 1 || p == 2) h->solve_kernel = table[c.L - 1][p];
+            if (p == 2) h->lds_solve = (size_t)lay.vec * sizeof(double);
+        }
+#endif
     }
     h->lds_asm = (size_t)AsmScratch::len(c.L) * sizeof(double);
     h->lds_kf = (size_t)KfScratch::len(c.L) * sizeof(double);

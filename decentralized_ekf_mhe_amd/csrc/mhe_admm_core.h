@@ -25,37 +25,40 @@
 
 // sum over the rows that touch x_k[a] / x_k[3+a] / x_k[6+a] of A(row, col) * w(row), w(row) already
 // carrying the row scaling E[row]
+// Branch-free: the neighbour step is clamped to a valid one and its contribution selected away, so
+// every load of a gather is issued up front (a branch per neighbour costs an LDS round trip each).
 template <class Q, class WF>
 DEKF_FN double gather_pcol(const Q& q, int k, int a, WF w) {
     constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
-    double g = 0.0;
-    if (k < q.K - 1) g += w(k * SC + NM + a) + w(k * SC + NM + 9 + a);
-    if (k > 0) g -= w((k - 1) * SC + NM + a) + w((k - 1) * SC + NM + 9 + a);
-    return g;
+    const bool hn = k < q.K - 1, hp = k > 0;
+    const int rn = (hn ? k : 0) * SC + NM + a, rp = (hp ? k - 1 : 0) * SC + NM + a;
+    const double n0 = w(rn), n1 = w(rn + 9), p0 = w(rp), p1 = w(rp + 9);
+    return (hn ? n0 + n1 : 0.0) - (hp ? p0 + p1 : 0.0);
 }
 template <class Q, class WF>
 DEKF_FN double gather_vcol(const Q& q, int k, int a, WF w) {
     constexpr int L = Q::LEGS, NM = 3 * L, SC = 12 + NM;
+    const bool hn = k < q.K - 1, hp = k > 0;
+    const int rn = (hn ? k : 0) * SC + NM + a, rp = (hp ? k - 1 : 0) * SC + NM + 3 + a;
+    const double n0 = w(rn + 3), n1 = w(rn), p0 = w(rp);
     double g = 0.0;
 #pragma unroll
     for (int leg = 0; leg < L; ++leg) g += w(k * SC + 3 * leg + a);
-    if (k < q.K - 1) g += w(k * SC + NM + 3 + a) + q.c.dt * w(k * SC + NM + a);
-    if (k > 0) g -= w((k - 1) * SC + NM + 3 + a);
-    return g;
+    return g + (hn ? n0 + q.c.dt * n1 : 0.0) - (hp ? p0 : 0.0);
 }
 template <class Q, class WF>
 DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
     constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
-    double g = 0.0;
-    if (k < q.K - 1) {
-        const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-        const double* R = q.R + 9 * k;
-        g += w(k * SC + NM + 6 + a);
+    const bool hn = k < q.K - 1, hp = k > 0;
+    const int kn = hn ? k : 0;
+    const int rn = kn * SC + NM, rp = (hp ? k - 1 : 0) * SC + NM + 6 + a;
+    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double* R = q.R + 9 * kn;
+    const double p0 = w(rp);
+    double g = w(rn + 6 + a);
 #pragma unroll
-        for (int r = 0; r < 3; ++r) g -= R[3 * r + a] * (hdt2 * w(k * SC + NM + r) + dt * w(k * SC + NM + 3 + r));
-    }
-    if (k > 0) g -= w((k - 1) * SC + NM + 6 + a);
-    return g;
+    for (int r = 0; r < 3; ++r) g -= R[3 * r + a] * (hdt2 * w(rn + r) + dt * w(rn + 3 + r));
+    return (hn ? g : 0.0) - (hp ? p0 : 0.0);
 }
 
 // ---------------------------------------------------------------- X: reduced right-hand side
@@ -73,11 +76,12 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
         const int e = (tile - kind * nt) * 64 + lane;
         if (e >= n3) return;
         const int k = e / 3, a = e - 3 * k, j = 3 * kind + a, i = k * SV + j;
+        const double xv = q.x[i], dv = q.D[i], qv = qsl[j];
         double g;
         if (kind == 0) g = gather_pcol(q, k, a, w);
         else if (kind == 1) g = gather_vcol(q, k, a, w);
         else g = gather_bcol(q, k, a, w);
-        q.xs[9 * k + j] = sigma * q.x[i] - (k == 0 ? qsl[j] : 0.0) + q.D[i] * g;
+        q.xs[9 * k + j] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
     });
     DEKF_SYNC();
 }
@@ -100,7 +104,7 @@ DEKF_FN double readlane_f64(double v, int lane) {
 // Device: the running vector sits in registers of lanes 0..8 of the calling wavefront and is
 // broadcast with v_readlane (18 per step), so the dependent chain never touches LDS or a barrier;
 // all 64 lanes execute it (lanes >= 9 mirror lane 8 and never store).  Host build: plain loops.
-template <bool TR, bool BWD, class Q>
+template <bool TR, bool BWD, int STEPS = 0, class Q>
 DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
     double *xs = q.xs, *xd = q.xd, *x = q.x;
@@ -108,30 +112,73 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
     const int lane = DEKF_LANE() & 63;
     const int i = lane < 9 ? lane : 8;
     const bool act = lane < 9;
-    double v = xs[9 * k0 + i];
-    for (int s = 1; s <= steps; ++s) {
-        const int kn = k0 + s * dk;
+    // Software-pipelined: the operands of step s+1 (a 9-vector of W, rhs, D, x) are requested from
+    // LDS before the dependent arithmetic of step s, so the chain sees register operands only.  (The
+    // compiler cannot do this itself: it may not move the loads above the step's own LDS store.)
+    struct Ops { double w[9], rhs, dsc, xo; };
+    auto load = [&](int kn, Ops& o) {
         const double* W = q.Wk + (kn + wofs) * 81;
-        double w[9], vt[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = TR ? W[9 * t + i] : W[9 * i + t];
-        const double rhs = BWD ? xd[9 * kn + i] : xs[9 * kn + i];
-        const double dsc = BWD ? q.D[kn * SV + i] : 0.0;
-        const double xo = BWD ? x[kn * SV + i] : 0.0;
+        for (int t = 0; t < 9; ++t) o.w[t] = TR ? W[9 * t + i] : W[9 * i + t];
+        o.rhs = BWD ? xd[9 * kn + i] : xs[9 * kn + i];
+        o.dsc = BWD ? q.D[kn * SV + i] : 0.0;
+        o.xo = BWD ? x[kn * SV + i] : 0.0;
+    };
+    double v = xs[9 * k0 + i];
+    auto step = [&](const Ops& c, Ops& n, int s) {
+        const int kn = k0 + s * dk;
+        if (s < steps) load(kn + dk, n);
+        double vt[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) vt[t] = readlane_f64(v, t);
-        double a0 = w[0] * vt[0] + w[3] * vt[3] + w[6] * vt[6];
-        double a1 = w[1] * vt[1] + w[4] * vt[4] + w[7] * vt[7];
-        double a2 = w[2] * vt[2] + w[5] * vt[5] + w[8] * vt[8];
-        v = rhs - (a0 + a1 + a2);
+        double a0 = c.rhs - c.w[0] * vt[0];   // 5 dependent f64 operations per step
+        double a1 = c.w[1] * vt[1], a2 = c.w[2] * vt[2];
+        a0 -= c.w[3] * vt[3]; a1 += c.w[4] * vt[4]; a2 += c.w[5] * vt[5];
+        a0 -= c.w[6] * vt[6]; a1 += c.w[7] * vt[7]; a2 += c.w[8] * vt[8];
+        v = a0 - (a1 + a2);
         if (act) {
             if (BWD) {
-                xd[9 * kn + i] = dsc * v;
-                x[kn * SV + i] = alpha * v + (1.0 - alpha) * xo;
+                xd[9 * kn + i] = c.dsc * v;
+                x[kn * SV + i] = alpha * v + (1.0 - alpha) * c.xo;
             } else {
                 xs[9 * kn + i] = v;
             }
         }
+    };
+    if constexpr (STEPS > 0) {
+        // compile-time step count: straight-line code, so every s_waitcnt the compiler inserts counts
+        // exactly; across a loop back-edge it waits for lgkmcnt(0), i.e. for the prefetch just issued
+        // (tools/probes/chain_probe.hip: 198 against 261 cycles per step, 331 without the pipeline)
+        Ops o[2];
+        load(k0 + dk, o[0]);
+#pragma unroll
+        for (int s = 1; s <= STEPS; ++s) {
+            const int kn = k0 + s * dk;
+            const Ops& c = o[(s - 1) & 1];
+            if (s < STEPS) load(kn + dk, o[s & 1]);
+            double vt[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) vt[t] = readlane_f64(v, t);
+            double a0 = c.rhs - c.w[0] * vt[0];
+            double a1 = c.w[1] * vt[1], a2 = c.w[2] * vt[2];
+            a0 -= c.w[3] * vt[3]; a1 += c.w[4] * vt[4]; a2 += c.w[5] * vt[5];
+            a0 -= c.w[6] * vt[6]; a1 += c.w[7] * vt[7]; a2 += c.w[8] * vt[8];
+            v = a0 - (a1 + a2);
+            if (act) {
+                if (BWD) {
+                    xd[9 * kn + i] = c.dsc * v;
+                    x[kn * SV + i] = alpha * v + (1.0 - alpha) * c.xo;
+                } else {
+                    xs[9 * kn + i] = v;
+                }
+            }
+        }
+    } else {
+        Ops A, B;
+        if (steps >= 1) load(k0 + dk, A);
+        int s = 1;
+        for (; s + 1 <= steps; s += 2) { step(A, B, s); step(B, A, s + 1); }
+        if (s <= steps) step(A, B, s);
     }
 #else
     double v[9], nv[9];
@@ -142,10 +189,11 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
         for (int i = 0; i < 9; ++i) {
             double w[9];
             for (int t = 0; t < 9; ++t) w[t] = TR ? W[9 * t + i] : W[9 * i + t];
-            double a0 = w[0] * v[0] + w[3] * v[3] + w[6] * v[6];
-            double a1 = w[1] * v[1] + w[4] * v[4] + w[7] * v[7];
-            double a2 = w[2] * v[2] + w[5] * v[5] + w[8] * v[8];
-            nv[i] = (BWD ? xd[9 * kn + i] : xs[9 * kn + i]) - (a0 + a1 + a2);
+            double a0 = (BWD ? xd[9 * kn + i] : xs[9 * kn + i]) - w[0] * v[0];
+            double a1 = w[1] * v[1], a2 = w[2] * v[2];
+            a0 -= w[3] * v[3]; a1 += w[4] * v[4]; a2 += w[5] * v[5];
+            a0 -= w[6] * v[6]; a1 += w[7] * v[7]; a2 += w[8] * v[8];
+            nv[i] = a0 - (a1 + a2);
         }
         for (int i = 0; i < 9; ++i) {
             v[i] = nv[i];
@@ -182,7 +230,7 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
     }
     double s[9], ft[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] = symget(Si, i, t, 9);
+    for (int t = 0; t < 9; ++t) s[t] = Si[symrow_idx(i, symrow_start(i, 9), t, 9)];
 #pragma unroll
     for (int t = 0; t < 9; ++t) ft[t] = readlane_f64(f, t);
     double a0 = s[0] * ft[0] + s[3] * ft[3] + s[6] * ft[6];
@@ -231,8 +279,14 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
 #if DEKF_DEVICE_BUILD
     __builtin_amdgcn_s_setprio(3);  // the legs are the critical path and share their SIMDs
 #endif
-    two_waves([&] { sweep_chain<false, false>(q, 0, 1, mid, -1, alpha); },
-              [&] { sweep_chain<false, false>(q, K - 1, -1, K - 2 - mid, 0, alpha); });
+    constexpr int NF = Q::NFIXED, FM = NF / 2;  // full window (steady state) of a compile-time horizon
+    const bool fixed = NF >= 4 && K == NF;
+    if (fixed)
+        two_waves([&] { sweep_chain<false, false, (NF >= 4 ? FM : 1)>(q, 0, 1, FM, -1, alpha); },
+                  [&] { sweep_chain<false, false, (NF >= 4 ? NF - 2 - FM : 1)>(q, NF - 1, -1, NF - 2 - FM, 0, alpha); });
+    else
+        two_waves([&] { sweep_chain<false, false>(q, 0, 1, mid, -1, alpha); },
+                  [&] { sweep_chain<false, false>(q, K - 1, -1, K - 2 - mid, 0, alpha); });
 #if DEKF_DEVICE_BUILD
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -246,9 +300,13 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
         if (blk >= 7 || k >= K || k == mid) return;
         const double* Si = q.Sinv + k * 45;
         const double* f = q.xs + 9 * k;
-        double a0 = symget(Si, i, 0, 9) * f[0] + symget(Si, i, 3, 9) * f[3] + symget(Si, i, 6, 9) * f[6];
-        double a1 = symget(Si, i, 1, 9) * f[1] + symget(Si, i, 4, 9) * f[4] + symget(Si, i, 7, 9) * f[7];
-        double a2 = symget(Si, i, 2, 9) * f[2] + symget(Si, i, 5, 9) * f[5] + symget(Si, i, 8, 9) * f[8];
+        const int rs = symrow_start(i, 9);
+        double sv[9], fv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { sv[t] = Si[symrow_idx(i, rs, t, 9)]; fv[t] = f[t]; }
+        double a0 = sv[0] * fv[0] + sv[3] * fv[3] + sv[6] * fv[6];
+        double a1 = sv[1] * fv[1] + sv[4] * fv[4] + sv[7] * fv[7];
+        double a2 = sv[2] * fv[2] + sv[5] * fv[5] + sv[8] * fv[8];
         q.xd[9 * k + i] = a0 + a1 + a2;
     });
     DEKF_SYNC();
@@ -256,8 +314,12 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
 #if DEKF_DEVICE_BUILD
     __builtin_amdgcn_s_setprio(3);
 #endif
-    two_waves([&] { sweep_chain<true, true>(q, mid, -1, mid, 0, alpha); },
-              [&] { sweep_chain<true, true>(q, mid, 1, K - 1 - mid, -1, alpha); });
+    if (fixed)
+        two_waves([&] { sweep_chain<true, true, (NF >= 4 ? FM : 1)>(q, FM, -1, FM, 0, alpha); },
+                  [&] { sweep_chain<true, true, (NF >= 4 ? NF - 1 - FM : 1)>(q, FM, 1, NF - 1 - FM, -1, alpha); });
+    else
+        two_waves([&] { sweep_chain<true, true>(q, mid, -1, mid, 0, alpha); },
+                  [&] { sweep_chain<true, true>(q, mid, 1, K - 1 - mid, -1, alpha); });
 #if DEKF_DEVICE_BUILD
     __builtin_amdgcn_s_setprio(0);
 #endif
@@ -272,50 +334,64 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
 // construction (Meas, Dyn: l == u), so rho = rho_eq and the projection returns the bound itself.
 // State kept between iterations: zt[r] = t (slack forward-elimination result), at[r] = w (what the
 // next phase X gathers), q.cf[r] = rho E D (refreshed by rows_restart after every factorisation).
-template <int NR, bool EQ, class Q, class SA>
-DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, SA sapply, double alpha, double sigma) {
+// Every LDS load of the block is issued before the first store (the compiler cannot move a load
+// across a store through another pointer, so interleaving them serialises one LDS round trip per row).
+template <int NR, bool EQ, class Q, class SM>
+DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM& S, double alpha, double sigma) {
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
-    double e[NR], cf[NR], c2[NR], v[NR], sl[NR], un[NR], rhs[NR], t[NR];
-#pragma unroll
-    for (int j = 0; j < NR; ++j) {
-        e[j] = q.E[r0 + j];
-        cf[j] = q.cf[r0 + j];
-        c2[j] = e[j] * q.D[sv0 + j];
-        v[j] = cf[j] * ar[j];
-    }
-    sapply(v, sl);
+    double e[NR], cf[NR], c2[NR], t0[NR], x0[NR], z0[NR], y0[NR], lo[NR], hi[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int r = r0 + j, sv = sv0 + j;
-        const double s = q.zt[r] + sl[j];       // slack solution
-        const double ztn = ar[j] - c2[j] * s;   // (A xt)(r)
-        const double xn = alpha * s + (1.0 - alpha) * q.x[sv];
-        q.x[sv] = xn;
-        const double zh = alpha * ztn + (1.0 - alpha) * q.z[r];
-        double rv, zn;
-        if (EQ) {
-            rv = rho_eq;
-            zn = q.lo[r];
-        } else {
-            rv = q.rho_at(r);
-            zn = dmin(dmax(zh + (1.0 / rv) * q.y[r], q.lo[r]), q.hi[r]);
-        }
-        const double yn = q.y[r] + rv * (zh - zn);
-        q.y[r] = yn;
-        q.z[r] = zn;
-        un[j] = rv * zn - yn;
-        rhs[j] = sigma * xn - c2[j] * un[j];
+        e[j] = q.E[r];
+        cf[j] = q.cf[r];
+        c2[j] = q.D[sv];
+        t0[j] = q.zt[r];
+        x0[j] = q.x[sv];
+        z0[j] = q.z[r];
+        y0[j] = q.y[r];
+        lo[j] = q.lo[r];
+        hi[j] = EQ ? 0.0 : q.hi[r];
     }
-    sapply(rhs, t);
+    double v[NR], sl[NR], xn[NR], zn[NR], yn[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        q.zt[r0 + j] = t[j];
-        q.at[r0 + j] = e[j] * (un[j] + cf[j] * t[j]);
+        c2[j] *= e[j];
+        v[j] = cf[j] * ar[j];
+    }
+    S.apply(v, sl);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const double sj = t0[j] + sl[j];         // slack solution
+        const double ztn = ar[j] - c2[j] * sj;   // (A xt)(r)
+        xn[j] = alpha * sj + (1.0 - alpha) * x0[j];
+        const double zh = alpha * ztn + (1.0 - alpha) * z0[j];
+        double rv;
+        if (EQ) {
+            rv = rho_eq;
+            zn[j] = lo[j];
+        } else {
+            rv = q.rho_of(lo[j], hi[j]);
+            zn[j] = dmin(dmax(zh + (1.0 / rv) * y0[j], lo[j]), hi[j]);
+        }
+        yn[j] = y0[j] + rv * (zh - zn[j]);
+        un[j] = rv * zn[j] - yn[j];
+        rhs[j] = sigma * xn[j] - c2[j] * un[j];
+    }
+    S.apply(rhs, t);
+#pragma unroll
+    for (int j = 0; j < NR; ++j) {
+        const int r = r0 + j, sv = sv0 + j;
+        q.x[sv] = xn[j];
+        q.y[r] = yn[j];
+        q.z[r] = zn[j];
+        q.zt[r] = t[j];
+        q.at[r] = e[j] * (un[j] + cf[j] * t[j]);
     }
 }
 // the same block from (x, z, y) alone: after a (re)factorisation, and for the cold start
-template <int NR, bool EQ, class Q, class SA>
-DEKF_FN void row_block_restart(Q& q, int r0, int sv0, SA sapply, double sigma) {
+template <int NR, bool EQ, class Q, class SM>
+DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma) {
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
     double e[NR], cf[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll
@@ -328,7 +404,7 @@ DEKF_FN void row_block_restart(Q& q, int r0, int sv0, SA sapply, double sigma) {
         un[j] = rv * q.z[r] - q.y[r];
         rhs[j] = sigma * q.x[sv] - e[j] * d * un[j];
     }
-    sapply(rhs, t);
+    S.apply(rhs, t);
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         q.cf[r0 + j] = cf[j];
@@ -338,23 +414,31 @@ DEKF_FN void row_block_restart(Q& q, int r0, int sv0, SA sapply, double sigma) {
 }
 
 template <int N>
-struct SymApply {  // out = S in, S symmetric N x N, packed upper triangle
-    const double* s;
-    DEKF_FN void operator()(const double* in, double* out) const {
+struct SymMat {  // symmetric N x N, packed upper triangle, held in registers
+    double p[N * (N + 1) / 2];
+    DEKF_FN explicit SymMat(const double* s) {
+#pragma unroll
+        for (int i = 0; i < N * (N + 1) / 2; ++i) p[i] = s[i];
+    }
+    DEKF_FN void apply(const double* in, double* out) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             double a = 0.0;
 #pragma unroll
-            for (int j = 0; j < N; ++j) a += symget(s, i, j, N) * in[j];
+            for (int j = 0; j < N; ++j) a += p[i < j ? symidx(i, j, N) : symidx(j, i, N)] * in[j];
             out[i] = a;
         }
     }
 };
-struct DiagApply3 {
-    const double* s;
-    DEKF_FN void operator()(const double* in, double* out) const {
+struct DiagMat3 {
+    double p[3];
+    DEKF_FN explicit DiagMat3(const double* s) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) out[i] = s[i] * in[i];
+        for (int i = 0; i < 3; ++i) p[i] = s[i];
+    }
+    DEKF_FN void apply(const double* in, double* out) const {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i] = p[i] * in[i];
     }
 };
 
@@ -373,7 +457,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             if (e >= nmeas) return;
             const int k = e / L, leg = e - k * L;
             const int r0 = k * SC + 3 * leg, sv0 = k * SV + 9 + 3 * leg;
-            SymApply<3> S{q.Sv + e * 6};
+            const SymMat<3> S(q.Sv + e * 6);
             if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
             double ar[3];
 #pragma unroll
@@ -388,7 +472,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
         const double* xk = xd + 9 * k;
         if (kind == 0) {  // Dyn position + velocity rows: 6x6 slack block
             const int r0 = k * SC + NM, sv0 = k * SV + 9 + NM;
-            SymApply<6> S{q.Sw + k * 24};
+            const SymMat<6> S(q.Sw + k * 24);
             if (RESTART) { row_block_restart<6, true>(q, r0, sv0, S, sigma); return; }
             const double* R = q.R + 9 * k;
             double ar[6];
@@ -401,7 +485,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             row_block_update<6, true>(q, r0, sv0, ar, S, alpha, sigma);
         } else if (kind == 1) {  // VO rows: +-inf box or equality, per-row rho
             const int r0 = k * SC + NM + 9, sv0 = k * SV + 18 + NM;
-            SymApply<3> S{q.Sc + k * 6};
+            const SymMat<3> S(q.Sc + k * 6);
             if (RESTART) { row_block_restart<3, false>(q, r0, sv0, S, sigma); return; }
             double ar[3];
 #pragma unroll
@@ -409,7 +493,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             row_block_update<3, false>(q, r0, sv0, ar, S, alpha, sigma);
         } else {  // Dyn bias rows: diagonal slack block
             const int r0 = k * SC + NM + 6, sv0 = k * SV + 9 + NM + 6;
-            DiagApply3 S{q.Sw + k * 24 + 21};
+            const DiagMat3 S(q.Sw + k * 24 + 21);
             if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
             double ar[3];
 #pragma unroll

@@ -81,9 +81,10 @@ struct IdxT {
     DEKF_FN static int rv(int k, int a) { return k * SC + nm + 9 + a; }
 };
 
-template <int L>
+template <int L, int NF = 0>
 struct SolveCtx {
     static constexpr int LEGS = L;
+    static constexpr int NFIXED = NF;  // != 0: horizon known at compile time (sweeps fully unrolled when K == NF)
     const DevCfg& c;
     const DevState& s;
     int b, K, kstart, n, m;
@@ -108,11 +109,11 @@ struct SolveCtx {
     }
     DEKF_FN double adyn(int k, int r, int j) const { return adyn_entry(R + 9 * k, c.dt, r, j); }
     // per-row rho from the scaled bounds (OSQP set_rho_vec / osqp_update_rho)
-    DEKF_FN double rho_at(int r) const {
-        double lb = lo[r], ub = hi[r];
+    DEKF_FN double rho_of(double lb, double ub) const {
         if (lb < -OSQP_INFTY * MIN_SCALING && ub > OSQP_INFTY * MIN_SCALING) return RHO_MIN;
         return (ub - lb < RHO_TOL) ? RHO_EQ_OVER_RHO_INEQ * rho : rho;
     }
+    DEKF_FN double rho_at(int r) const { return rho_of(lo[r], hi[r]); }
     // unscaled bound of row (k, kind, o): kind 0 Meas, 1 Dyn, 2 VO
     DEKF_FN void bounds(int k, int kind, int o, double& lb, double& ub) const {
         const double* r = rec(k);
@@ -658,7 +659,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     lay.init(NH, L);
     Gws g;
     g.init(NH, L);
-    SolveCtx<L> q{c, s, b, K, kstart, 0, 0, IdxT<L>{}};
+    SolveCtx<L, NFIX> q{c, s, b, K, kstart, 0, 0, IdxT<L>{}};
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
         double* p = lds;
         q.x = p; p += lay.n_pad;

@@ -21,7 +21,16 @@
 #define DEKF_DEVICE_BUILD 1
 #define DEKF_FN __device__ __forceinline__
 #define DEKF_HD __host__ __device__ __forceinline__
-#define DEKF_LANE() ((int)threadIdx.x)
+// The lane id goes through an empty volatile asm at every use: the compiler then cannot hoist the
+// per-lane address arithmetic of a phase out of the ADMM iteration loop.  Hoisted, those values
+// stayed live across every phase, pushed the kernel over its 256-register budget and came back as
+// scratch (HBM-backed) reloads at the head of the sweeps; recomputing them costs a few VALU ops.
+static __device__ __forceinline__ int dekf_lane_id() {
+    int v = (int)threadIdx.x;
+    asm volatile("" : "+v"(v));
+    return v;
+}
+#define DEKF_LANE() dekf_lane_id()
 #define DEKF_NLANES() ((int)blockDim.x)
 #define DEKF_SYNC() __syncthreads()
 #else
@@ -207,7 +216,7 @@ inline void w0for(int n, F f) {
 #if DEKF_DEVICE_BUILD
 template <class F0, class F1>
 DEKF_FN void two_waves(F0 f0, F1 f1) {
-    const int w = DEKF_LANE() >> 6;
+    const int w = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6);  // wave-uniform: scalar branches
     if (DEKF_NLANES() <= WAVE) { f0(); f1(); }
     else if (w == 0) f0();
     else if (w == 1) f1();
@@ -229,7 +238,7 @@ template <class F>
 DEKF_FN void wtiles(int ntiles, F f) {
     const int nw = DEKF_NLANES() > WAVE ? DEKF_NLANES() >> 6 : 1;
     const int lane = DEKF_LANE() & 63;
-    for (int t = DEKF_LANE() >> 6; t < ntiles; t += nw) f(t, lane);
+    for (int t = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6); t < ntiles; t += nw) f(t, lane);  // t is scalar
 }
 #else
 template <class F>
