@@ -102,7 +102,7 @@ struct Gws {
         hi = o; o += m_pad;
         rho = o; o += m_pad;
         Sv = o; o += K * 6 * L;
-        Sw = o; o += K * 24;
+        Sw = o; o += K * 25;  // SWS (mhe_solve_core.h)
         Sc = o; o += K * 6;
         Wm = o; o += K * 6 * L;
         Wd = o; o += K * 24;

@@ -29,32 +29,30 @@
 // every load of a gather is issued up front (a branch per neighbour costs an LDS round trip each).
 template <class Q, class WF>
 DEKF_FN double gather_pcol(const Q& q, int k, int a, WF w) {
-    constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
     const bool hn = k < q.K - 1, hp = k > 0;
-    const int rn = (hn ? k : 0) * SC + NM + a, rp = (hp ? k - 1 : 0) * SC + NM + a;
-    const double n0 = w(rn), n1 = w(rn + 9), p0 = w(rp), p1 = w(rp + 9);
+    const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
+    const double n0 = w(q.ix.rd(kn, a)), n1 = w(q.ix.rv(kn, a)), p0 = w(q.ix.rd(kp, a)), p1 = w(q.ix.rv(kp, a));
     return (hn ? n0 + n1 : 0.0) - (hp ? p0 + p1 : 0.0);
 }
 template <class Q, class WF>
 DEKF_FN double gather_vcol(const Q& q, int k, int a, WF w) {
-    constexpr int L = Q::LEGS, NM = 3 * L, SC = 12 + NM;
+    constexpr int L = Q::LEGS;
     const bool hn = k < q.K - 1, hp = k > 0;
-    const int rn = (hn ? k : 0) * SC + NM + a, rp = (hp ? k - 1 : 0) * SC + NM + 3 + a;
-    const double n0 = w(rn + 3), n1 = w(rn), p0 = w(rp);
+    const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
+    const double n0 = w(q.ix.rd(kn, 3 + a)), n1 = w(q.ix.rd(kn, a)), p0 = w(q.ix.rd(kp, 3 + a));
     double g = 0.0;
 #pragma unroll
-    for (int leg = 0; leg < L; ++leg) g += w(k * SC + 3 * leg + a);
+    for (int leg = 0; leg < L; ++leg) g += w(q.ix.rm(k, 3 * leg + a));
     return g + (hn ? n0 + q.c.dt * n1 : 0.0) - (hp ? p0 : 0.0);
 }
 template <class Q, class WF>
 DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
-    constexpr int NM = 3 * Q::LEGS, SC = 12 + NM;
     const bool hn = k < q.K - 1, hp = k > 0;
-    const int kn = hn ? k : 0;
-    const int rn = kn * SC + NM, rp = (hp ? k - 1 : 0) * SC + NM + 6 + a;
+    const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
     const double* R = q.R + 9 * kn;
-    const double p0 = w(rp);
+    const int rn = q.ix.rd(kn, 0);
+    const double p0 = w(q.ix.rd(kp, 6 + a));
     double g = w(rn + 6 + a);
 #pragma unroll
     for (int r = 0; r < 3; ++r) g -= R[3 * r + a] * (hdt2 * w(rn + r) + dt * w(rn + 3 + r));
@@ -446,7 +444,7 @@ struct DiagMat3 {
 // cf, t, w from (x, z, y).  Tiles: [Meas leg blocks][Dyn p+v 6-blocks][VO][Dyn bias].
 template <bool RESTART, class Q>
 DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
-    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM, SC = 12 + NM;
+    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     const int ntm = (nmeas + 63) >> 6, ntd = (K1 + 63) >> 6;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
@@ -456,7 +454,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             const int e = tile * 64 + lane;
             if (e >= nmeas) return;
             const int k = e / L, leg = e - k * L;
-            const int r0 = k * SC + 3 * leg, sv0 = k * SV + 9 + 3 * leg;
+            const int r0 = q.ix.rm(k, 3 * leg), sv0 = k * SV + 9 + 3 * leg;
             const SymMat<3> S(q.Sv + e * 6);
             if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
             double ar[3];
@@ -471,8 +469,8 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
         if (k >= K1) return;
         const double* xk = xd + 9 * k;
         if (kind == 0) {  // Dyn position + velocity rows: 6x6 slack block
-            const int r0 = k * SC + NM, sv0 = k * SV + 9 + NM;
-            const SymMat<6> S(q.Sw + k * 24);
+            const int r0 = q.ix.rd(k, 0), sv0 = k * SV + 9 + NM;
+            const SymMat<6> S(q.Sw + k * SWS);
             if (RESTART) { row_block_restart<6, true>(q, r0, sv0, S, sigma); return; }
             const double* R = q.R + 9 * k;
             double ar[6];
@@ -484,7 +482,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             }
             row_block_update<6, true>(q, r0, sv0, ar, S, alpha, sigma);
         } else if (kind == 1) {  // VO rows: +-inf box or equality, per-row rho
-            const int r0 = k * SC + NM + 9, sv0 = k * SV + 18 + NM;
+            const int r0 = q.ix.rv(k, 0), sv0 = k * SV + 18 + NM;
             const SymMat<3> S(q.Sc + k * 6);
             if (RESTART) { row_block_restart<3, false>(q, r0, sv0, S, sigma); return; }
             double ar[3];
@@ -492,8 +490,8 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[a] - xk[9 + a]);
             row_block_update<3, false>(q, r0, sv0, ar, S, alpha, sigma);
         } else {  // Dyn bias rows: diagonal slack block
-            const int r0 = k * SC + NM + 6, sv0 = k * SV + 9 + NM + 6;
-            const DiagMat3 S(q.Sw + k * 24 + 21);
+            const int r0 = q.ix.rd(k, 6), sv0 = k * SV + 9 + NM + 6;
+            const DiagMat3 S(q.Sw + k * SWS + 21);
             if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
             double ar[3];
 #pragma unroll

@@ -45,6 +45,7 @@ namespace dekf {
 #define DEKF_PROF_MARK(q, sec) ((void)0)
 #endif
 
+constexpr int SWS = 25;  // doubles per step of Sw (21 packed 6x6 + 3 bias diagonal + 1 pad: an odd stride keeps one-lane-per-step reads off the same banks)
 constexpr int SOLVE_TMP = 344;  // [162,171) scaled q; at factor time [0,162) and [176,338): two Gauss-Jordan ping-pong pairs
 
 // how many doubles of LDS a solve needs in each placement mode
@@ -58,7 +59,7 @@ struct SolveLayout {
         n_pad = N * (9 + nm + 12);
         m_pad = N * (nm + 12);
         vec = 2 * n_pad + 4 * m_pad + 18 * N + SOLVE_TMP;
-        resident = n_pad + 3 * m_pad + N * (6 * L + 24 + 6) + N * (45 + 81) + 9 * N;
+        resident = n_pad + 3 * m_pad + N * (6 * L + SWS + 6) + N * (45 + 81) + 9 * N;
     }
     // LDS-resident factor only if two workgroups still fit in one CU's 160 KiB
     DEKF_HD bool factor_in_lds() const { return (size_t)(vec + resident) * 8 <= 80 * 1024; }
@@ -76,9 +77,16 @@ struct IdxT {
     DEKF_FN static int v(int k, int r) { return k * SV + 9 + r; }
     DEKF_FN static int w(int k, int r) { return k * SV + 9 + nm + r; }
     DEKF_FN static int c(int k, int a) { return k * SV + 18 + nm + a; }
-    DEKF_FN static int rm(int k, int r) { return k * SC + r; }
-    DEKF_FN static int rd(int k, int r) { return k * SC + nm + r; }
-    DEKF_FN static int rv(int k, int a) { return k * SC + nm + 9 + a; }
+    // Rows are stored KIND-MAJOR in LDS: [Meas rows of all steps | Dyn rows of all steps | VO rows of all
+    // steps], not step-major as in the reference's QP (k * SC + ...).  A wavefront works on one kind of
+    // row with one lane per step, so consecutive lanes are 3 / 9 / nm doubles apart (conflict-free);
+    // step-major they were SC = 24 doubles = 48 banks apart, which mod 32 banks leaves two distinct
+    // banks for 16 lanes: every ds_read2_b64 of the row phase ran 8-way conflicted.
+    int rdb, rvb;  // first Dyn row, first VO row
+    DEKF_FN explicit IdxT(int K) : rdb(K * nm), rvb(K * nm + 9 * (K - 1)) {}
+    DEKF_FN int rm(int k, int r) const { return k * nm + r; }
+    DEKF_FN int rd(int k, int r) const { return rdb + 9 * k + r; }
+    DEKF_FN int rv(int k, int a) const { return rvb + 3 * k + a; }
 };
 
 template <int L, int NF = 0>
@@ -131,11 +139,9 @@ struct SolveCtx {
         else { kind = 3; o = q - 18 - ix.nm; }
     }
     DEKF_FN void dec_row(int r, int& k, int& kind, int& o) const {
-        k = r / ix.SC;
-        int q = r - k * ix.SC;
-        if (q < ix.nm) { kind = 0; o = q; }
-        else if (q < ix.nm + 9) { kind = 1; o = q - ix.nm; }
-        else { kind = 2; o = q - ix.nm - 9; }
+        if (r < ix.rdb) { kind = 0; k = r / ix.nm; o = r - k * ix.nm; }
+        else if (r < ix.rvb) { kind = 1; int t = r - ix.rdb; k = t / 9; o = t - 9 * k; }
+        else { kind = 2; int t = r - ix.rvb; k = t / 3; o = t - 3 * k; }
     }
     // row that slack variable (k, kind 1..3, o) lives in, and vice versa
     DEKF_FN int slack_row(int k, int kind, int o) const { return kind == 1 ? ix.rm(k, o) : (kind == 2 ? ix.rd(k, o) : ix.rv(k, o)); }
@@ -284,6 +290,7 @@ DEKF_FN void solve_scale(Q& q) {
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
     double *D = q.D, *E = q.E, *Pst = q.Pst, *pc = q.x, *Dt = q.xt, *Et = q.zt;
     const double* g = q.np;
+    const auto& ix = q.ix;
     stage_p(q);
     wfor(n + m, [&](int e) { if (e < n) D[e] = 1.0; else E[e - n] = 1.0; });
     q.cc = 1.0;
@@ -331,16 +338,16 @@ DEKF_FN void solve_scale(Q& q) {
         wfor_nosync(K * 3, [&](int e) {  // position columns
             int k = e / 3, a = e - 3 * k, i = k * SV + a;
             double an = 0.0;
-            if (k < K1) an = dmax(E[k * SC + NM + a], E[k * SC + NM + 9 + a]);
-            if (k > 0) an = dmax(an, dmax(E[(k - 1) * SC + NM + a], E[(k - 1) * SC + NM + 9 + a]));
+            if (k < K1) an = dmax(E[ix.rd(k, a)], E[ix.rv(k, a)]);
+            if (k > 0) an = dmax(an, dmax(E[ix.rd(k - 1, a)], E[ix.rv(k - 1, a)]));
             Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i])));
         });
         wfor_nosync(K * 3, [&](int e) {  // velocity columns
             int k = e / 3, a = e - 3 * k, i = k * SV + 3 + a;
             double an = 0.0;
-            for (int leg = 0; leg < L; ++leg) an = dmax(an, E[k * SC + 3 * leg + a]);
-            if (k < K1) an = dmax(an, dmax(E[k * SC + NM + 3 + a], dt * E[k * SC + NM + a]));
-            if (k > 0) an = dmax(an, E[(k - 1) * SC + NM + 3 + a]);
+            for (int leg = 0; leg < L; ++leg) an = dmax(an, E[ix.rm(k, 3 * leg + a)]);
+            if (k < K1) an = dmax(an, dmax(E[ix.rd(k, 3 + a)], dt * E[ix.rd(k, a)]));
+            if (k > 0) an = dmax(an, E[ix.rd(k - 1, 3 + a)]);
             Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i])));
         });
         wfor_nosync(K * 3, [&](int e) {  // bias columns
@@ -348,25 +355,27 @@ DEKF_FN void solve_scale(Q& q) {
             double an = 0.0;
             if (k < K1) {
                 const double* R = q.R + 9 * k;
-                an = E[k * SC + NM + 6 + a];
+                an = E[ix.rd(k, 6 + a)];
                 for (int r = 0; r < 3; ++r) {
                     double ra = fabs(R[3 * r + a]);
-                    an = dmax(an, dmax(hdt2 * ra * E[k * SC + NM + r], dt * ra * E[k * SC + NM + 3 + r]));
+                    an = dmax(an, dmax(hdt2 * ra * E[ix.rd(k, r)], dt * ra * E[ix.rd(k, 3 + r)]));
                 }
             }
-            if (k > 0) an = dmax(an, E[(k - 1) * SC + NM + 6 + a]);
+            if (k > 0) an = dmax(an, E[ix.rd(k - 1, 6 + a)]);
             Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i])));
         });
         wfor_nosync(m, [&](int r) {  // slack columns: one entry -1 in their own row
-            int k = r / SC, i = k * SV + 9 + (r - k * SC);
+            int k, kind, o;
+            q.dec_row(r, k, kind, o);
+            int i = q.row_slack(k, kind, o);
             Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], E[r] * D[i])));
         });
         wfor_nosync(K * NM, [&](int e) {  // Meas rows
-            int k = e / NM, o = e - k * NM, r = k * SC + o;
+            int k = e / NM, o = e - k * NM, r = ix.rm(k, o);
             Et[r] = 1.0 / sqrt(limit_scaling(E[r] * dmax(D[k * SV + 9 + o], D[k * SV + 3 + o % 3])));
         });
         wfor_nosync(K1 * 3, [&](int e) {  // Dyn position rows
-            int k = e / 3, a = e - 3 * k, r = k * SC + NM + a;
+            int k = e / 3, a = e - 3 * k, r = ix.rd(k, a);
             const double* R = q.R + 9 * k + 3 * a;
             const double* d = D + k * SV;
             double v = dmax(dmax(d[9 + NM + a], d[a]), dmax(dt * d[3 + a], d[SV + a]));
@@ -374,7 +383,7 @@ DEKF_FN void solve_scale(Q& q) {
             Et[r] = 1.0 / sqrt(limit_scaling(E[r] * v));
         });
         wfor_nosync(K1 * 3, [&](int e) {  // Dyn velocity rows
-            int k = e / 3, a = e - 3 * k, r = k * SC + NM + 3 + a;
+            int k = e / 3, a = e - 3 * k, r = ix.rd(k, 3 + a);
             const double* R = q.R + 9 * k + 3 * a;
             const double* d = D + k * SV;
             double v = dmax(dmax(d[9 + NM + 3 + a], d[3 + a]), d[SV + 3 + a]);
@@ -382,12 +391,12 @@ DEKF_FN void solve_scale(Q& q) {
             Et[r] = 1.0 / sqrt(limit_scaling(E[r] * v));
         });
         wfor_nosync(K1 * 3, [&](int e) {  // Dyn bias rows
-            int k = e / 3, a = e - 3 * k, r = k * SC + NM + 6 + a;
+            int k = e / 3, a = e - 3 * k, r = ix.rd(k, 6 + a);
             const double* d = D + k * SV;
             Et[r] = 1.0 / sqrt(limit_scaling(E[r] * dmax(d[9 + NM + 6 + a], dmax(d[6 + a], d[SV + 6 + a]))));
         });
         wfor(K1 * 3, [&](int e) {  // VO rows
-            int k = e / 3, a = e - 3 * k, r = k * SC + NM + 9 + a;
+            int k = e / 3, a = e - 3 * k, r = ix.rv(k, a);
             const double* d = D + k * SV;
             Et[r] = 1.0 / sqrt(limit_scaling(E[r] * dmax(d[18 + NM + a], dmax(d[a], d[SV + a]))));
         });
@@ -453,7 +462,7 @@ DEKF_FN bool solve_factor(Q& q) {
                     S[6 * a + d] = cc * q.D[ix.w(k, a)] * symget(q21, a, d, 6) * q.D[ix.w(k, d)] +
                                    (a == d ? sigma + gv[a] * q.E[ix.rd(k, a)] * q.D[ix.w(k, a)] : 0.0);
             inv_spd_unrolled<6>(S);
-            double* sw = q.Sw + k * 24;
+            double* sw = q.Sw + k * SWS;
             double* wd = q.Wd + k * 24;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
@@ -659,7 +668,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     lay.init(NH, L);
     Gws g;
     g.init(NH, L);
-    SolveCtx<L, NFIX> q{c, s, b, K, kstart, 0, 0, IdxT<L>{}};
+    SolveCtx<L, NFIX> q{c, s, b, K, kstart, 0, 0, IdxT<L>(K)};
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
         double* p = lds;
         q.x = p; p += lay.n_pad;
@@ -678,7 +687,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
             q.lo = p; p += lay.m_pad;
             q.hi = p; p += lay.m_pad;
             q.Sv = p; p += NH * 6 * L;
-            q.Sw = p; p += NH * 24;
+            q.Sw = p; p += NH * SWS;
             q.Sc = p; p += NH * 6;
             q.Sinv = p; p += NH * 45;
             q.Wk = p; p += NH * 81;
