@@ -440,6 +440,47 @@ struct DiagMat3 {
     }
 };
 
+#if DEKF_DEVICE_BUILD
+// The Dyn 6x6 slack block on a PAIR of adjacent lanes (even lane: position rows, odd lane: velocity
+// rows): each lane keeps its 3 rows of S (own 3x3 symmetric part + 3x3 coupling part) and gets the
+// partner's 3-vector through DPP quad_perm [1,0,3,2] — no LDS, no barrier.  One lane per 6-block made
+// this tile the critical path of the row phase (2.3x the instructions of a Meas lane on 19 lanes).
+DEKF_FN double pair_swap(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+struct DynPairMat {
+    double a[6];  // own rows x own columns (symmetric, packed)
+    double b[9];  // own rows x partner columns
+    DEKF_FN DynPairMat(const double* s, bool vel) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = i; j < 3; ++j) a[symidx(i, j, 3)] = s[vel ? symidx(3 + i, 3 + j, 6) : symidx(i, j, 6)];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) b[3 * i + j] = s[vel ? symidx(j, 3 + i, 6) : symidx(i, 3 + j, 6)];
+    }
+    DEKF_FN void apply(const double* in, double* out) const {
+        double pin[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) pin[j] = pair_swap(in[j]);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc += a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)] * in[j];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc += b[3 * i + j] * pin[j];
+            out[i] = acc;
+        }
+    }
+};
+#endif
+
 // RESTART = false: one iteration's row work (needs xd from phase_sweeps).  RESTART = true: rebuild
 // cf, t, w from (x, z, y).  Tiles: [Meas leg blocks][Dyn p+v 6-blocks][VO][Dyn bias].
 template <bool RESTART, class Q>
@@ -447,9 +488,24 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
     constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     const int ntm = (nmeas + 63) >> 6, ntd = (K1 + 63) >> 6;
+#if DEKF_DEVICE_BUILD
+    const int ntp = (2 * K1 + 63) >> 6;  // Dyn p+v blocks: a lane pair per block
+#else
+    const int ntp = ntd;                 // host build: one (sequential) lane per 6-block
+#endif
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
     const double *xd = q.xd, *E = q.E;
-    wtiles(ntm + 3 * ntd, [&](int tile, int lane) {
+    // Tile order [Meas | Dyn pairs | VO | (empty) | bias]: the bias tiles (cheapest kind) start on the wavefront
+    // that got the LAST Meas tile (the least full one) instead of piling onto wavefront 0 behind a full Meas
+    // tile — measured 1 % of the whole solve on Go1 (tools/ab_bench.sh).
+    const int nw = wave_count();
+    const int npad = (((ntm - 1) - (ntm + ntp + ntd)) % nw + nw) % nw;
+    const int tbias = ntm + ntp + ntd + npad;
+    wtiles(tbias + ntd, [&](int tile, int lane) {
+        if (tile >= ntm + ntp + ntd) {
+            if (tile < tbias) return;
+            tile -= npad;
+        }
         if (tile < ntm) {  // Meas: leg block (k, leg), A_meas = [0 I 0]
             const int e = tile * 64 + lane;
             if (e >= nmeas) return;
@@ -464,11 +520,33 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             return;
         }
         const int td = tile - ntm;
-        const int kind = td < ntd ? 0 : (td < 2 * ntd ? 1 : 2);
-        const int k = (td - kind * ntd) * 64 + lane;
+#if DEKF_DEVICE_BUILD
+        if (td < ntp) {  // Dyn position + velocity rows: lane pair per 6x6 slack block
+            const int pl = td * 64 + lane, k = pl >> 1;
+            const bool vel = pl & 1;
+            if (k >= K1) return;
+            const int r0 = q.ix.rd(k, vel ? 3 : 0), sv0 = k * SV + 9 + NM + (vel ? 3 : 0);
+            const DynPairMat S(q.Sw + k * SWS, vel);
+            if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
+            const double* xk = xd + 9 * k;
+            const double* R = q.R + 9 * k;
+            const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
+            const int o = vel ? 3 : 0;
+            double ar[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double rb = R[3 * a] * xk[6] + R[3 * a + 1] * xk[7] + R[3 * a + 2] * xk[8];
+                ar[a] = E[r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+            }
+            row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma);
+            return;
+        }
+#endif
+        const int kind = td < ntp ? 0 : (td < ntp + ntd ? 1 : 2);
+        const int k = (td - (kind == 0 ? 0 : ntp + (kind - 1) * ntd)) * 64 + lane;
         if (k >= K1) return;
         const double* xk = xd + 9 * k;
-        if (kind == 0) {  // Dyn position + velocity rows: 6x6 slack block
+        if (kind == 0) {  // Dyn position + velocity rows: 6x6 slack block (host build)
             const int r0 = q.ix.rd(k, 0), sv0 = k * SV + 9 + NM;
             const SymMat<6> S(q.Sw + k * SWS);
             if (RESTART) { row_block_restart<6, true>(q, r0, sv0, S, sigma); return; }

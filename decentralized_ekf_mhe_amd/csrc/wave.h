@@ -233,6 +233,7 @@ inline void two_waves(F0 f0, F1 f1) {
 // (tile t by wavefront t mod #wavefronts), so a branch on the tile index is wave-uniform (scalar) and
 // every wavefront runs ONE straight-line body per tile.  f(tile, lane) with lane = 0..63 is called
 // for all 64 lanes of the wavefront (cross-lane reads inside f are legal).  No trailing sync.
+DEKF_FN int wave_count() { return DEKF_NLANES() > WAVE ? DEKF_NLANES() >> 6 : 1; }
 #if DEKF_DEVICE_BUILD
 template <class F>
 DEKF_FN void wtiles(int ntiles, F f) {

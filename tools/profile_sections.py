@@ -51,6 +51,7 @@ def main():
         res["sections"][nme] = {"cycles": mean[i], "share": mean[i] / tot if tot else 0.0}
         print(f"{nme:38s} {mean[i]:12.0f} cyc  {100 * mean[i] / max(tot, 1):5.1f} %")
     print(f"{'total':38s} {tot:12.0f} cyc   iters {res['mean_iters']:.1f}  rho updates {res['mean_rho_updates']:.2f}")
+    print("R phase per wavefront (cycles/iteration, waves 0..3):", [round(float(mean[i]) / max(res["mean_iters"], 1)) for i in (6, 7, 8, 14)])
     print(json.dumps(res))
     est.close()
 
