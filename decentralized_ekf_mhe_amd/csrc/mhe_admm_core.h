@@ -85,14 +85,6 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
 }
 
 // ---------------------------------------------------------------- S: block-tridiagonal solve
-#if DEKF_DEVICE_BUILD
-DEKF_FN double readlane_f64(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-#endif
 
 // One leg of the two-sided block-tridiagonal solve: a chain of `steps` dependent 9x9 mat-vecs
 //     v_new = rhs[k_new] - M v_prev,   k_new = k_prev + dk,   M = Wk[k_new + wofs] (TR: transposed)

@@ -601,6 +601,93 @@ DEKF_FN bool solve_factor(Q& q) {
         int j = i + p;
         q.Sinv[k * 45 + e] = 0.5 * (src[9 * i + j] + src[9 * j + i]);
     };
+#if DEKF_DEVICE_BUILD
+    // Device: each side is ONE wavefront working through its blocks with wave-level syncs only; the
+    // 9x9 inversion is a Gauss-Jordan sweep on registers (lane j < 9 holds column j, the pivot column is
+    // broadcast with v_readlane), so a block costs three LDS round trips instead of eleven workgroup
+    // barriers.  The host build below keeps the phase-per-pivot form (same arithmetic up to rounding).
+    (void)nph; (void)bufs; (void)gj_step; (void)pivot_ok; (void)store_sinv;
+    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, double* tb) -> bool {
+        // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]
+        const int lane = DEKF_LANE() & 63;
+        double* ts = tb;        // S, then the full inverse
+        for (int p = lane; p < 81; p += WAVE) build_s(k, use_top, use_bot, p, ts);
+        wave_sync();
+        const int j = lane < 9 ? lane : 8;
+        double a[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) a[i] = ts[9 * i + j];
+        bool good = true;
+#pragma unroll
+        for (int pv = 0; pv < 9; ++pv) {
+            double col[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) col[i] = readlane_f64(a[i], pv);
+            const double piv = col[pv];
+            good = good && (fabs(piv) > 0.0) && (fabs(piv) < 1e300);
+            const double d = 1.0 / piv;
+            const bool own = lane == pv;
+            const double m = a[pv] * d;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (i == pv) a[i] = own ? d : m;
+                else a[i] = own ? -col[i] * d : a[i] - col[i] * m;
+            }
+        }
+        wave_sync();  // every lane has read its column of S
+        if (lane < 9) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) ts[9 * i + j] = a[i];
+        }
+        wave_sync();
+        if (lane < 45) store_sinv(k, ts, lane);
+        if (wmode == 1) {
+            const double* Ck = q.PA + k * 81;
+            for (int p = lane; p < 81; p += WAVE) {
+                int i = p / 9, jj = p - 9 * i;
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u < 9; ++u) acc += Ck[9 * i + u] * ts[9 * u + jj];
+                q.Wk[k * 81 + p] = acc;
+            }
+        } else if (wmode == 2) {
+            const double* Ck = q.PA + (k - 1) * 81;
+            for (int p = lane; p < 81; p += WAVE) {
+                int i = p / 9, jj = p - 9 * i;
+                double acc = 0.0;
+#pragma unroll
+                for (int u = 0; u < 9; ++u) acc += Ck[9 * u + i] * ts[9 * u + jj];
+                q.Wk[(k - 1) * 81 + p] = acc;
+            }
+        }
+        wave_sync();
+        return good;
+    };
+    double* fail = q.tmp + 172;  // [162, 171) is the scaled q
+    if (DEKF_LANE() == 0) *fail = 0.0;
+    DEKF_SYNC();
+    two_waves(
+        [&] {
+            bool g = true;
+            for (int k = 0; k < mid; ++k) g = factor_block(k, k > 0, false, 1, q.tmp) && g;
+            if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
+        },
+        [&] {
+            bool g = true;
+            for (int k = K - 1; k > mid; --k) g = factor_block(k, false, k < K - 1, 2, q.tmp + 176) && g;
+            if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
+        });
+    DEKF_SYNC();
+    two_waves(
+        [&] {
+            bool g = factor_block(mid, mid > 0, mid < K - 1, 0, q.tmp);
+            if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
+        },
+        [&] {});
+    DEKF_SYNC();
+    ok = *fail == 0.0;
+    DEKF_SYNC();
+#else
     for (int t = 0; t <= nph; ++t) {
         const bool last = t == nph;             // the meeting block
         const int kt = last ? mid : t, kb = K - 1 - t;
@@ -646,6 +733,7 @@ DEKF_FN bool solve_factor(Q& q) {
             }
         });
     }
+#endif
     return ok;
 }
 

@@ -233,6 +233,15 @@ inline void two_waves(F0 f0, F1 f1) {
 // (tile t by wavefront t mod #wavefronts), so a branch on the tile index is wave-uniform (scalar) and
 // every wavefront runs ONE straight-line body per tile.  f(tile, lane) with lane = 0..63 is called
 // for all 64 lanes of the wavefront (cross-lane reads inside f are legal).  No trailing sync.
+#if DEKF_DEVICE_BUILD
+// broadcast lane `lane`'s value of a double to the whole wavefront (two v_readlane_b32 into an SGPR pair)
+DEKF_FN double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+#endif
 DEKF_FN int wave_count() { return DEKF_NLANES() > WAVE ? DEKF_NLANES() >> 6 : 1; }
 #if DEKF_DEVICE_BUILD
 template <class F>
