@@ -571,3 +571,166 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
     });
     DEKF_SYNC();
 }
+
+// ---------------------------------------------------------------- residual norms
+// What OSQP's compute_pri_res / compute_dua_res / compute_pri_tol / compute_dua_tol / compute_rho_estimate
+// need, in one pass: ra = {|Ax-z|/E, |z|/E, |Ax|/E, |Ax-z|, |z|, |Ax|} (inf-norms over the rows) and
+// va = {|Px+q+A'y|/D, |q|/D, |A'y|/D, |Px|/D, and the same four scaled} (over the variables).
+// Same lane mapping as the row phase: a lane owns a 3-row block AND its slack block (the slack of a row
+// lives in that row only), so Ax, P_s x_s and A'y of the block are lane-local; the x columns go through
+// the branch-free gathers.  The P blocks come from the window records in HBM (requested first, they
+// arrive while the LDS part is being computed).  Replaces two wfor sweeps over rows / variables with
+// per-item kind decoding (50 k cycles per check on Go1, 3 checks per solve).
+template <class Q>
+DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
+    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
+    const int K = q.K, K1 = K - 1, nmeas = K * L;
+    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt, cc = q.cc;
+    double *x = q.x, *z = q.z, *y = q.y, *xd = q.xd;
+    const double *D = q.D, *E = q.E;
+    wfor(K * 9, [&](int e) {
+        int k = e / 9, j = e - 9 * k;
+        xd[e] = D[k * SV + j] * x[k * SV + j];
+    });
+    double acc[14];
+#pragma unroll
+    for (int r = 0; r < 14; ++r) acc[r] = 0.0;
+    // rows r0.. and slack variables sv0.. of one 3-block: ar = E .* (A_x D x), ps = unscaled P_s (D_s x_s)
+    auto block = [&](int r0, int sv0, const double* ar, const double* ps) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int r = r0 + j, sv = sv0 + j;
+            const double e = E[r], d = D[sv];
+            const double Ax = ar[j] - e * d * x[sv];
+            const double pr = Ax - z[r], ei = 1.0 / e;
+            acc[0] = dmax(acc[0], fabs(pr) * ei);
+            acc[1] = dmax(acc[1], fabs(z[r]) * ei);
+            acc[2] = dmax(acc[2], fabs(Ax) * ei);
+            acc[3] = dmax(acc[3], fabs(pr));
+            acc[4] = dmax(acc[4], fabs(z[r]));
+            acc[5] = dmax(acc[5], fabs(Ax));
+            const double Px = cc * d * ps[j], Aty = -e * d * y[r];
+            const double dr = Px + Aty, di = 1.0 / d;
+            acc[6] = dmax(acc[6], fabs(dr) * di);
+            acc[8] = dmax(acc[8], fabs(Aty) * di);
+            acc[9] = dmax(acc[9], fabs(Px) * di);
+            acc[10] = dmax(acc[10], fabs(dr));
+            acc[12] = dmax(acc[12], fabs(Aty));
+            acc[13] = dmax(acc[13], fabs(Px));
+        }
+    };
+    const int ntm = (nmeas + 63) >> 6, ntp = (2 * K1 + 63) >> 6, ntd = (K1 + 63) >> 6, ntx = (3 * K + 63) >> 6;
+    const double* qsl = q.tmp + 162;
+    auto wy = [&](int r) { return E[r] * y[r]; };
+    wtiles(ntm + ntp + 2 * ntd + 3 * ntx, [&](int tile, int lane) {
+        if (tile < ntm) {  // Meas leg blocks
+            const int e = tile * 64 + lane;
+            if (e >= nmeas) return;
+            const int k = e / L, leg = e - k * L;
+            const int r0 = q.ix.rm(k, 3 * leg), sv0 = k * SV + 9 + 3 * leg;
+            const double* q6 = q.rec(k) + Rec::qm(NM) + 6 * leg;
+            double p6[6], dx[3], ps[3], ar[3];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) p6[t] = q6[t];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) { dx[a] = D[sv0 + a] * x[sv0 + a]; ar[a] = E[r0 + a] * xd[9 * k + 3 + a]; }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                ps[a] = p6[symidx(0, a, 3)] * dx[0] + p6[1 < a ? symidx(1, a, 3) : symidx(a, 1, 3)] * dx[1] + p6[symidx(a, 2, 3)] * dx[2];
+            block(r0, sv0, ar, ps);
+            return;
+        }
+        int td = tile - ntm;
+        if (td < ntp) {  // Dyn position / velocity rows: lane pair per step (no exchange needed here)
+            const int pl = td * 64 + lane, k = pl >> 1;
+            if (k >= K1) return;
+            const bool vel = pl & 1;
+            const int o = vel ? 3 : 0;
+            const int r0 = q.ix.rd(k, o), sv0 = k * SV + 9 + NM + o, w0 = k * SV + 9 + NM;
+            const double* q21 = q.rec(k) + Rec::QD;
+            double p21[21], dx[6], ps[3], ar[3];
+#pragma unroll
+            for (int t = 0; t < 21; ++t) p21[t] = q21[t];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) dx[t] = D[w0 + t] * x[w0 + t];
+            const double* xk = xd + 9 * k;
+            const double* R = q.R + 9 * k;
+            const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double rb = R[3 * a] * xk[6] + R[3 * a + 1] * xk[7] + R[3 * a + 2] * xk[8];
+                ar[a] = E[r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    s0 += p21[a < t ? symidx(a, t, 6) : symidx(t, a, 6)] * dx[t];
+                    s1 += p21[3 + a < t ? symidx(3 + a, t, 6) : symidx(t, 3 + a, 6)] * dx[t];
+                }
+                ps[a] = vel ? s1 : s0;
+            }
+            block(r0, sv0, ar, ps);
+            return;
+        }
+        td -= ntp;
+        if (td < 2 * ntd) {  // bias rows, then VO rows
+            const bool vo = td >= ntd;
+            const int k = (td - (vo ? ntd : 0)) * 64 + lane;
+            if (k >= K1) return;
+            const double* xk = xd + 9 * k;
+            double ar[3], ps[3];
+            if (!vo) {
+                const int r0 = q.ix.rd(k, 6), sv0 = k * SV + 9 + NM + 6;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    ar[a] = E[r0 + a] * (xk[6 + a] - xk[15 + a]);
+                    ps[a] = q.c.Q_bias_dt2[a] * D[sv0 + a] * x[sv0 + a];
+                }
+                block(r0, sv0, ar, ps);
+            } else {
+                const int r0 = q.ix.rv(k, 0), sv0 = k * SV + 18 + NM;
+                const double* q6 = q.rec(k) + Rec::QC;
+                double p6[6], dx[3];
+#pragma unroll
+                for (int t = 0; t < 6; ++t) p6[t] = q6[t];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) { dx[a] = D[sv0 + a] * x[sv0 + a]; ar[a] = E[r0 + a] * (xk[a] - xk[9 + a]); }
+#pragma unroll
+                for (int a = 0; a < 3; ++a)
+                    ps[a] = p6[symidx(0, a, 3)] * dx[0] + p6[1 < a ? symidx(1, a, 3) : symidx(a, 1, 3)] * dx[1] + p6[symidx(a, 2, 3)] * dx[2];
+                block(r0, sv0, ar, ps);
+            }
+            return;
+        }
+        td -= 2 * ntd;  // x columns: position / velocity / bias tiles
+        const int kind = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2);
+        const int e = (td - kind * ntx) * 64 + lane;
+        if (e >= 3 * K) return;
+        const int k = e / 3, a = e - 3 * k, j = 3 * kind + a, i = k * SV + j;
+        const double d = D[i], qv = k == 0 ? qsl[j] : 0.0;
+        double g;
+        if (kind == 0) g = gather_pcol(q, k, a, wy);
+        else if (kind == 1) g = gather_vcol(q, k, a, wy);
+        else g = gather_bcol(q, k, a, wy);
+        double Px = 0.0;
+        if (k == 0) {  // the arrival cost is the only Hessian on an x block
+            for (int t = 0; t < 9; ++t) Px += (j <= t ? q.Mp[9 * j + t] : q.Mp[9 * t + j]) * xd[t];
+            Px *= cc * d;
+        }
+        const double Aty = d * g, dr = qv + Px + Aty, di = 1.0 / d;
+        acc[6] = dmax(acc[6], fabs(dr) * di);
+        acc[7] = dmax(acc[7], fabs(qv) * di);
+        acc[8] = dmax(acc[8], fabs(Aty) * di);
+        acc[9] = dmax(acc[9], fabs(Px) * di);
+        acc[10] = dmax(acc[10], fabs(dr));
+        acc[11] = dmax(acc[11], fabs(qv));
+        acc[12] = dmax(acc[12], fabs(Aty));
+        acc[13] = dmax(acc[13], fabs(Px));
+    });
+#pragma unroll
+    for (int r = 0; r < 14; ++r) acc[r] = wave_max(acc[r]);
+    group_combine<14, false>(acc);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) ra[r] = acc[r];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) va[r] = acc[6 + r];
+}

@@ -498,6 +498,7 @@ DEKF_FN bool solve_factor(Q& q) {
                     q.Wc[k * 6 + symidx(a, d, 3)] = (a == d ? rr[a] : 0.0) - gv[a] * Si[symidx(a, d, 3)] * gv[d];
         }
     });
+    DEKF_PROF_MARK(q, 6);
     // effective dyn-row weight as a 9x9 accessor
     auto wd_at = [&](int k, int a, int d) -> double {
         const double* wd = q.Wd + k * 24;
@@ -553,6 +554,7 @@ DEKF_FN bool solve_factor(Q& q) {
     });
     // C_k moves to PA[k]; W_k will be written to Wk[k]
     wfor((K - 1) * 81, [&](int e) { q.PA[e] = q.Wk[e]; });
+    DEKF_PROF_MARK(q, 7);
     // 3d. TWO-SIDED block LDL' ("burn at both ends"): blocks 0..mid-1 are eliminated downwards,
     //     blocks K-1..mid+1 upwards, both fronts in the same phases (two 9x9 problems per phase),
     //     and they meet in block mid.  Same storage as a one-sided factorisation, half the depth:
@@ -734,6 +736,7 @@ DEKF_FN bool solve_factor(Q& q) {
         });
     }
 #endif
+    DEKF_PROF_MARK(q, 8);
     return ok;
 }
 
@@ -847,44 +850,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         bool adapt_now = c.adaptive_rho && c.adaptive_rho_interval > 0 && (iter % c.adaptive_rho_interval == 0);
         if (can_check || adapt_now || iter == c.max_iter) {
             double ra[6], va[8];
-            auto xv = [&](int k, int j) { return x[ix.x(k, j)]; };
-            wred_maxn<6>(m, ra, [&](int r, double* acc) {
-                int k, kind, o;
-                q.dec_row(r, k, kind, o);
-                int sv = q.row_slack(k, kind, o);
-                double Ax = q.row_dot_x(k, kind, o, xv) - q.E[r] * q.D[sv] * x[sv];
-                double pr = Ax - z[r];
-                double ei = 1.0 / q.E[r];
-                acc[0] = dmax(acc[0], fabs(pr) * ei);
-                acc[1] = dmax(acc[1], fabs(z[r]) * ei);
-                acc[2] = dmax(acc[2], fabs(Ax) * ei);
-                acc[3] = dmax(acc[3], fabs(pr));
-                acc[4] = dmax(acc[4], fabs(z[r]));
-                acc[5] = dmax(acc[5], fabs(Ax));
-            });
-            wred_maxn<8>(n, va, [&](int i, double* acc) {
-                int k, kind, o;
-                q.dec_var(i, k, kind, o);
-                double Px = q.p_apply(i, x, false);
-                double Aty, qv = 0.0;
-                if (kind == 0) {
-                    Aty = q.gather_x(k, o, y);
-                    if (k == 0) qv = qs[o];
-                } else {
-                    int r = q.slack_row(k, kind, o);
-                    Aty = -q.E[r] * q.D[i] * y[r];
-                }
-                double dr = qv + Px + Aty;
-                double di = 1.0 / q.D[i];
-                acc[0] = dmax(acc[0], fabs(dr) * di);
-                acc[1] = dmax(acc[1], fabs(qv) * di);
-                acc[2] = dmax(acc[2], fabs(Aty) * di);
-                acc[3] = dmax(acc[3], fabs(Px) * di);
-                acc[4] = dmax(acc[4], fabs(dr));
-                acc[5] = dmax(acc[5], fabs(qv));
-                acc[6] = dmax(acc[6], fabs(Aty));
-                acc[7] = dmax(acc[7], fabs(Px));
-            });
+            residual_norms(q, ra, va);
             info.pri_res = ra[0];
             info.dua_res = cinv * va[0];
             if (can_check || iter == c.max_iter) {

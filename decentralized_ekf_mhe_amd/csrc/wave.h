@@ -175,6 +175,9 @@ inline void wred_maxn(int n, double* out, F f) {
     for (int i = 0; i < n; ++i) f(i, acc);
     for (int r = 0; r < NR; ++r) out[r] = acc[r];
 }
+inline double wave_max(double v) { return v; }   // one sequential "lane" has seen every item already
+template <int NR, bool SUM>
+inline void group_combine(double*) {}
 template <class F>
 inline int wred_argmax(int n, F f, double* best_out) {
     double best = -1.0;

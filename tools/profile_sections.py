@@ -22,7 +22,7 @@ from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_dev
 from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
 
 NAMES = ["0 copy R + Ruiz scaling", "1 bounds + first factorisation + restart", "2 X: reduced rhs on x columns",
-         "3 S1: forward legs (2 waves)", "4 S2: meeting block | g_k", "5 S3: outward legs (2 waves)", "6 -", "7 -", "8 -",
+         "3 S1: forward legs (2 waves)", "4 S2: meeting block | g_k", "5 S3: outward legs (2 waves)", "6 factor 3a: slack blocks (both factorisations)", "7 factor 3b-3c: PA, T_kk, C_k", "8 factor 3d: block LDL'",
          "9 R: fused row blocks", "10 residuals + termination", "11 rho update + refactor", "12 epilogue", "13 total"]
 
 
@@ -51,7 +51,6 @@ def main():
         res["sections"][nme] = {"cycles": mean[i], "share": mean[i] / tot if tot else 0.0}
         print(f"{nme:38s} {mean[i]:12.0f} cyc  {100 * mean[i] / max(tot, 1):5.1f} %")
     print(f"{'total':38s} {tot:12.0f} cyc   iters {res['mean_iters']:.1f}  rho updates {res['mean_rho_updates']:.2f}")
-    print("R phase per wavefront (cycles/iteration, waves 0..3):", [round(float(mean[i]) / max(res["mean_iters"], 1)) for i in (6, 7, 8, 14)])
     print(json.dumps(res))
     est.close()
 
