@@ -204,7 +204,7 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
 template <class Q>
 DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
-    const int K = q.K, mid = K / 2;
+    const int K = q.K, mid = mid_block(K);
     double *xs = q.xs, *xd = q.xd, *x = q.x;
     const double* Si = q.Sinv + mid * 45;
 #if DEKF_DEVICE_BUILD
@@ -265,11 +265,11 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
 // W^_k = C_k' S^_{k+1}^-1 in Wk[k] for k >= mid.
 template <class Q>
 DEKF_FN void phase_sweeps(Q& q, double alpha) {
-    const int K = q.K, mid = K / 2;
+    const int K = q.K, mid = mid_block(K);
 #if DEKF_DEVICE_BUILD
     __builtin_amdgcn_s_setprio(3);  // the legs are the critical path and share their SIMDs
 #endif
-    constexpr int NF = Q::NFIXED, FM = NF / 2;  // full window (steady state) of a compile-time horizon
+    constexpr int NF = Q::NFIXED, FM = mid_block(NF);  // full window (steady state) of a compile-time horizon
     const bool fixed = NF >= 4 && K == NF;
     if (fixed)
         two_waves([&] { sweep_chain<false, false, (NF >= 4 ? FM : 1)>(q, 0, 1, FM, -1, alpha); },

@@ -45,6 +45,10 @@ namespace dekf {
 #define DEKF_PROF_MARK(q, sec) ((void)0)
 #endif
 
+// The meeting block of the two-sided block-tridiagonal factorisation / solve.  (K - 1) / 2 makes the
+// two forward legs equally long for an even window (9 + 9 steps at K = 20; K / 2 gave 10 + 8) and the
+// critical path forward + outward 9 + 10 steps instead of 10 + 10.
+DEKF_HD constexpr int mid_block(int K) { return (K - 1) / 2; }
 constexpr int SWS = 25;  // doubles per step of Sw (21 packed 6x6 + 3 bias diagonal + 1 pad: an odd stride keeps one-lane-per-step reads off the same banks)
 constexpr int SOLVE_TMP = 344;  // [162,171) scaled q; at factor time [0,162) and [176,338): two Gauss-Jordan ping-pong pairs
 
@@ -499,61 +503,113 @@ DEKF_FN bool solve_factor(Q& q) {
         }
     });
     DEKF_PROF_MARK(q, 6);
-    // effective dyn-row weight as a 9x9 accessor
-    auto wd_at = [&](int k, int a, int d) -> double {
-        const double* wd = q.Wd + k * 24;
-        if (a < 6 && d < 6) return symget(wd, a, d, 6);
-        return (a == d) ? wd[21 + a - 6] : 0.0;
-    };
-    // 3b. PA_k = Wd_k * (E_D A_dyn D_x)
-    wfor((K - 1) * 81, [&](int e) {
-        int k = e / 81, p = e - 81 * k, i = p / 9, j = p - 9 * i;
-        double acc = 0.0;
-        for (int t = 0; t < 9; ++t) {
-            double w = wd_at(k, i, t);
-            if (w != 0.0) acc += w * q.E[ix.rd(k, t)] * q.adyn(k, t, j);
-        }
-        q.PA[e] = acc * q.D[ix.x(k, j)];
-    });
-    // 3c. T_kk (upper triangle, packed) -> Sinv[k], C_k -> Wk[k]
-    wfor(K * 45 + (K - 1) * 81, [&](int e) {
-        if (e < K * 45) {
-            int k = e / 45, p = e - 45 * k;
-            int i = 0;
-            while (p >= 9 - i) { p -= 9 - i; ++i; }
-            int j = i + p;
-            double di = q.D[ix.x(k, i)], dj = q.D[ix.x(k, j)];
-            double acc = (i == j) ? sigma : 0.0;
-            if (k == 0) acc += cc * di * q.Mp[9 * i + j] * dj;
-            if (i >= 3 && j < 6)
-                for (int leg = 0; leg < L; ++leg)
-                    acc += q.E[ix.rm(k, 3 * leg + i - 3)] * di * symget(q.Wm + (k * L + leg) * 6, i - 3, j - 3, 3) *
-                           q.E[ix.rm(k, 3 * leg + j - 3)] * dj;
-            if (k < K - 1) {
-                if (j < 3) acc += q.E[ix.rv(k, i)] * di * symget(q.Wc + k * 6, i, j, 3) * q.E[ix.rv(k, j)] * dj;
+    // 3b+3c. One lane per column j of block k: column j of PA_k = Wd_k (E A_dyn D) stays in registers and
+    //     yields column j of T_kk (upper part, packed -> Sinv[k]) and column j of C_k (-> PA[k]; W_k goes
+    //     to Wk[k] in 3d).  Tiles by column kind (position / velocity / bias) so that A_dyn's sparsity is
+    //     compile-time structure; only the component a = j mod 3 is a run-time select.  (Was three sweeps
+    //     over 1539 + 2439 + 1539 items with per-item index decoding: 57 k cycles per factorisation.)
+    {
+        const double dt = c.dt, hdt2 = 0.5 * dt * dt;
+        const int K1 = K - 1, ntx = (3 * K + 63) >> 6;
+        wtiles(3 * ntx, [&](int tile, int lane) {
+            const int kind = tile < ntx ? 0 : (tile < 2 * ntx ? 1 : 2);
+            const int e3 = (tile - kind * ntx) * 64 + lane;
+            if (e3 >= 3 * K) return;
+            const int k = e3 / 3, a = e3 - 3 * k, j = 3 * kind + a;
+            const bool hn = k < K1, hp = k > 0;
+            const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;  // clamped: loads stay in bounds, results are selected away
+            double dx[9], tc[9];  // D of x_k; column j of T_kk (rows 0..8, only i <= j is stored)
+#pragma unroll
+            for (int i = 0; i < 9; ++i) { dx[i] = q.D[ix.x(k, i)]; tc[i] = 0.0; }
+            const double dj = q.D[ix.x(k, j)];
+            // ---- this step's Dyn / VO rows
+            {
+                double en[9], ev[3], dn[9], Rk[9], pa[9], at[9];
+                const double* wd = q.Wd + kn * 24;
+                const double* wc = q.Wc + kn * 6;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { en[t] = q.E[ix.rd(kn, t)]; dn[t] = q.D[ix.x(kn + 1 < K ? kn + 1 : kn, t)]; Rk[t] = q.R[9 * kn + t]; }
+#pragma unroll
+                for (int t = 0; t < 3; ++t) ev[t] = q.E[ix.rv(kn, t)];
+                // column j of E A_dyn D
+#pragma unroll
                 for (int t = 0; t < 9; ++t) {
-                    double a = q.adyn(k, t, i);
-                    if (a != 0.0) acc += q.E[ix.rd(k, t)] * a * di * q.PA[k * 81 + 9 * t + j];
+                    double v;
+                    if (kind == 0) v = (t == a) ? 1.0 : 0.0;
+                    else if (kind == 1) v = (t == a) ? dt : (t == 3 + a ? 1.0 : 0.0);
+                    else v = t < 3 ? -hdt2 * Rk[3 * t + a] : (t < 6 ? -dt * Rk[3 * (t - 3) + a] : (t == 6 + a ? 1.0 : 0.0));
+                    at[t] = en[t] * v * dj;
+                }
+                // column j of PA = Wd (E A D): Wd = blkdiag(6x6 symmetric, diag 3)
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int t = 0; t < 6; ++t) acc += wd[i < t ? symidx(i, t, 6) : symidx(t, i, 6)] * at[t];
+                    pa[i] = acc;
+                }
+#pragma unroll
+                for (int i = 6; i < 9; ++i) pa[i] = wd[21 + i - 6] * at[i];
+                // (E A D)' PA, row i of the product: A_dyn's column i has compile-time structure
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    double s;
+                    if (i < 3) s = en[i] * pa[i];
+                    else if (i < 6) s = en[i - 3] * dt * pa[i - 3] + en[i] * pa[i];
+                    else {
+                        s = en[i] * pa[i];
+#pragma unroll
+                        for (int r = 0; r < 3; ++r) s -= Rk[3 * r + i - 6] * (en[r] * hdt2 * pa[r] + en[3 + r] * dt * pa[3 + r]);
+                    }
+                    if (kind == 0 && i < 3) s += ev[i] * symget(wc, i, a, 3) * ev[a] * dj;  // VO rows: +I on x_k[0:3]
+                    tc[i] += hn ? dx[i] * s : 0.0;
+                }
+                // column j of C_k = -(E D_{k+1}) PA  (- the VO coupling on the position block)
+                if (hn) {
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {
+                        double cv = -en[i] * dn[i] * pa[i];
+                        if (kind == 0 && i < 3) cv -= ev[i] * dn[i] * symget(wc, i, a, 3) * ev[a] * dj;
+                        q.PA[k * 81 + 9 * i + j] = cv;
+                    }
                 }
             }
-            if (k > 0) {
-                acc += q.E[ix.rd(k - 1, i)] * di * wd_at(k - 1, i, j) * q.E[ix.rd(k - 1, j)] * dj;
-                if (j < 3)
-                    acc += q.E[ix.rv(k - 1, i)] * di * symget(q.Wc + (k - 1) * 6, i, j, 3) * q.E[ix.rv(k - 1, j)] * dj;
+            // ---- the previous step's Dyn / VO rows carry -I on x_k
+            {
+                const double* wd = q.Wd + kp * 24;
+                const double* wc = q.Wc + kp * 6;
+                const double ej = q.E[ix.rd(kp, j)];
+#pragma unroll
+                for (int i = 0; i < 9; ++i) {
+                    double w;
+                    if (kind == 2) w = (i == 6 + a) ? wd[21 + a] : 0.0;
+                    else if (i < 6) w = symget(wd, i, j, 6);
+                    else w = 0.0;
+                    double s = q.E[ix.rd(kp, i)] * w * ej;
+                    if (kind == 0 && i < 3) s += q.E[ix.rv(kp, i)] * symget(wc, i, a, 3) * q.E[ix.rv(kp, a)];
+                    tc[i] += hp ? dx[i] * s * dj : 0.0;
+                }
             }
-            q.Sinv[e] = acc;
-        } else {
-            int e2 = e - K * 45;
-            int k = e2 / 81, p = e2 - 81 * k, i = p / 9, j = p - 9 * i;
-            double d1 = q.D[ix.x(k + 1, i)];
-            double acc = -q.E[ix.rd(k, i)] * d1 * q.PA[k * 81 + p];
-            if (i < 3 && j < 3)
-                acc -= q.E[ix.rv(k, i)] * d1 * symget(q.Wc + k * 6, i, j, 3) * q.E[ix.rv(k, j)] * q.D[ix.x(k, j)];
-            q.Wk[e2] = acc;
-        }
-    });
-    // C_k moves to PA[k]; W_k will be written to Wk[k]
-    wfor((K - 1) * 81, [&](int e) { q.PA[e] = q.Wk[e]; });
+            // ---- Meas rows (velocity block), arrival cost (block 0), sigma
+            if (kind == 1) {
+#pragma unroll
+                for (int leg = 0; leg < L; ++leg) {
+                    const double* wm = q.Wm + (k * L + leg) * 6;
+                    const double ea = q.E[ix.rm(k, 3 * leg + a)];
+#pragma unroll
+                    for (int i = 3; i < 6; ++i) tc[i] += q.E[ix.rm(k, 3 * leg + i - 3)] * dx[i] * symget(wm, i - 3, a, 3) * ea * dj;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                if (i > j) continue;
+                double v = tc[i] + (i == j ? sigma : 0.0);
+                if (k == 0) v += cc * dx[i] * q.Mp[9 * i + j] * dj;
+                q.Sinv[k * 45 + symidx(i, i, 9) + (j - i)] = v;
+            }
+        });
+        DEKF_SYNC();
+    }
     DEKF_PROF_MARK(q, 7);
     // 3d. TWO-SIDED block LDL' ("burn at both ends"): blocks 0..mid-1 are eliminated downwards,
     //     blocks K-1..mid+1 upwards, both fronts in the same phases (two 9x9 problems per phase),
@@ -563,7 +619,7 @@ DEKF_FN bool solve_factor(Q& q) {
     //       middle  S_m = T_mm - W_{m-1} C_{m-1}' - What_m C_m
     //     W_k lives in Wk[k] for k < mid, What_k in Wk[k] for k >= mid (it couples block k+1 to k).
     bool ok = true;
-    const int mid = K / 2;
+    const int mid = mid_block(K);
     const int nph = (mid > K - 1 - mid ? mid : K - 1 - mid);
     double* bufs[2][2] = {{q.tmp, q.tmp + 81}, {q.tmp + 176, q.tmp + 257}};
     // S of block k into dst; use_top / use_bot select the Schur terms
