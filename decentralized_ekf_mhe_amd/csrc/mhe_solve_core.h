@@ -289,131 +289,170 @@ DEKF_FN void stage_p(Q& q) {
 
 template <class Q>
 DEKF_FN void solve_scale(Q& q) {
-    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM, SC = 12 + NM, PS = 6 * L + 27;
-    const int n = q.n, m = q.m, K = q.K, K1 = q.K - 1;
+    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM, PS = 6 * L + 27;
+    const int n = q.n, m = q.m, K = q.K, K1 = q.K - 1, nmeas = K * L;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-    double *D = q.D, *E = q.E, *Pst = q.Pst, *pc = q.x, *Dt = q.xt, *Et = q.zt;
+    double *D = q.D, *E = q.E, *Pst = q.Pst, *pc = q.x, *Dn = q.xt, *En = q.zt;
     const double* g = q.np;
     const auto& ix = q.ix;
     stage_p(q);
-    wfor(n + m, [&](int e) { if (e < n) D[e] = 1.0; else E[e - n] = 1.0; });
+    wfor(n + m, [&](int e) { if (e < n) { D[e] = 1.0; Dn[e] = 1.0; } else { E[e - n] = 1.0; En[e - n] = 1.0; } });
     q.cc = 1.0;
     const double* Mst = Pst + K * PS;
-    // inf-norm of every column of c D P D -> pc[] (cc excluded: multiplied in where it is used)
-    auto pnorms = [&]() {
-        wfor_nosync(K * 9, [&](int e) {  // x columns: only x_0 carries a Hessian (the arrival cost)
-            int k = e / 9, j = e - 9 * k;
+    // Lane ownership is the row phase's: a lane owns one 3-row block and its 3 slack variables (Meas leg
+    // block, Dyn position or velocity rows as a lane pair, Dyn bias, VO), or one x entry (tiles by column
+    // kind).  One Ruiz pass is two tile phases:
+    //   equil  new E of the owned rows, new D of the owned variables from the OLD D, E -> En, Dn
+    //   adopt  D = Dn, E = En on the owned entries; inf-norms of the owned columns of D P D (read from Dn, so
+    //          no lane reads an entry another lane is overwriting) -> pc; their sum for the cost scaling
+    // i.e. 3 workgroup barriers per pass (one after equil, two in the sum) where the item-per-lane sweeps
+    // with per-item kind decoding needed 6 and about 17 k cycles.
+    const int ntm = (nmeas + 63) >> 6, ntp = (2 * K1 + 63) >> 6, ntd = (K1 + 63) >> 6, ntx = (3 * K + 63) >> 6;
+    const int ntiles = ntm + ntp + 2 * ntd + 3 * ntx;
+    // decode a tile/lane into an owned block: kind 0 Meas, 1 Dyn p/v, 2 bias, 3 VO, 4..6 x columns
+    auto decode = [&](int tile, int lane, int& kind, int& k, int& sub) -> bool {
+        if (tile < ntm) { int e = tile * 64 + lane; kind = 0; k = e / L; sub = e - k * L; return e < nmeas; }
+        int td = tile - ntm;
+        if (td < ntp) { int pl = td * 64 + lane; kind = 1; k = pl >> 1; sub = pl & 1; return k < K1; }
+        td -= ntp;
+        if (td < 2 * ntd) { bool vo = td >= ntd; kind = vo ? 3 : 2; k = (td - (vo ? ntd : 0)) * 64 + lane; sub = 0; return k < K1; }
+        td -= 2 * ntd;
+        int ck = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2);
+        int e = (td - ck * ntx) * 64 + lane;
+        kind = 4 + ck; k = e / 3; sub = e - 3 * k;
+        return e < 3 * K;
+    };
+    auto row_base = [&](int kind, int k, int sub, int& r0, int& sv0) {
+        if (kind == 0) { r0 = ix.rm(k, 3 * sub); sv0 = k * SV + 9 + 3 * sub; }
+        else if (kind == 1) { r0 = ix.rd(k, 3 * sub); sv0 = k * SV + 9 + NM + 3 * sub; }
+        else if (kind == 2) { r0 = ix.rd(k, 6); sv0 = k * SV + 9 + NM + 6; }
+        else { r0 = ix.rv(k, 0); sv0 = k * SV + 18 + NM; }
+    };
+    // inf-norms of the owned columns of D P D (cc excluded) from the new scaling Dn; returns their sum
+    auto adopt = [&](int tile, int lane) -> double {
+        int kind, k, sub;
+        if (!decode(tile, lane, kind, k, sub)) return 0.0;
+        double sum = 0.0;
+        if (kind >= 4) {
+            const int j = 3 * (kind - 4) + sub, i = k * SV + j;
+            const double dj = Dn[i];
+            D[i] = dj;
             double v = 0.0;
             if (k == 0)
-                for (int t = 0; t < 9; ++t) v = dmax(v, fabs(D[j] * symget(Mst, j, t, 9) * D[t]));
-            pc[k * SV + j] = v;
-        });
-        wfor_nosync(K * NM, [&](int e) {  // v columns
-            int k = e / NM, o = e - k * NM, leg = o / 3, a = o - 3 * leg;
-            const double* q6 = Pst + k * PS + 6 * leg;
-            const double* d = D + k * SV + 9 + 3 * leg;
-            double v = dmax(fabs(symget(q6, a, 0, 3) * d[0]), dmax(fabs(symget(q6, a, 1, 3) * d[1]), fabs(symget(q6, a, 2, 3) * d[2])));
-            pc[k * SV + 9 + o] = v * d[a];
-        });
-        wfor_nosync(K1 * 9, [&](int e) {  // w columns
-            int k = e / 9, o = e - 9 * k;
-            const double* d = D + k * SV + 9 + NM;
-            double v;
-            if (o < 6) {
-                const double* q21 = Pst + k * PS + 6 * L;
-                v = 0.0;
+                for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * symget(Mst, j, t, 9) * Dn[t]));
+            pc[i] = v;
+            return v;
+        }
+        int r0, sv0;
+        row_base(kind, k, sub, r0, sv0);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { E[r0 + a] = En[r0 + a]; D[sv0 + a] = Dn[sv0 + a]; }
+        if (kind == 1) {
+            const double* q21 = Pst + k * PS + 6 * L;
+            const double* d = Dn + k * SV + 9 + NM;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int o = 3 * sub + a;
+                double v = 0.0;
                 for (int t = 0; t < 6; ++t) v = dmax(v, fabs(symget(q21, o, t, 6) * d[t]));
                 v *= d[o];
-            } else v = d[o] * q.c.Q_bias_dt2[o - 6] * d[o];
-            pc[k * SV + 9 + NM + o] = v;
-        });
-        wfor(K1 * 3, [&](int e) {  // c columns
-            int k = e / 3, a = e - 3 * k;
-            const double* q6 = Pst + k * PS + 6 * L + 21;
-            const double* d = D + k * SV + 18 + NM;
-            double v = dmax(fabs(symget(q6, a, 0, 3) * d[0]), dmax(fabs(symget(q6, a, 1, 3) * d[1]), fabs(symget(q6, a, 2, 3) * d[2])));
-            pc[k * SV + 18 + NM + a] = v * d[a];
-        });
+                pc[sv0 + a] = v;
+                sum += v;
+            }
+        } else if (kind == 2) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const double d = Dn[sv0 + a], v = d * q.c.Q_bias_dt2[a] * d;
+                pc[sv0 + a] = v;
+                sum += v;
+            }
+        } else {
+            const double* q6 = Pst + k * PS + (kind == 0 ? 6 * sub : 6 * L + 21);
+            const double* d = Dn + sv0;
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double v = dmax(fabs(symget(q6, a, 0, 3) * d[0]), dmax(fabs(symget(q6, a, 1, 3) * d[1]), fabs(symget(q6, a, 2, 3) * d[2])));
+                v *= d[a];
+                pc[sv0 + a] = v;
+                sum += v;
+            }
+        }
+        return sum;
     };
-    pnorms();
+    auto equil = [&](int tile, int lane, double cc) {
+        int kind, k, sub;
+        if (!decode(tile, lane, kind, k, sub)) return;
+        if (kind >= 4) {  // x column: inf-norm over the rows that touch it
+            const int a = sub, i = k * SV + 3 * (kind - 4) + a;
+            const bool hn = k < K1, hp = k > 0;
+            const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
+            double an = 0.0;
+            if (kind == 4) {
+                const double n0 = E[ix.rd(kn, a)], n1 = E[ix.rv(kn, a)], p0 = E[ix.rd(kp, a)], p1 = E[ix.rv(kp, a)];
+                if (hn) an = dmax(n0, n1);
+                if (hp) an = dmax(an, dmax(p0, p1));
+            } else if (kind == 5) {
+                const double n0 = E[ix.rd(kn, 3 + a)], n1 = E[ix.rd(kn, a)], p0 = E[ix.rd(kp, 3 + a)];
+#pragma unroll
+                for (int leg = 0; leg < L; ++leg) an = dmax(an, E[ix.rm(k, 3 * leg + a)]);
+                if (hn) an = dmax(an, dmax(n0, dt * n1));
+                if (hp) an = dmax(an, p0);
+            } else {
+                const double* R = q.R + 9 * kn;
+                double bn = E[ix.rd(kn, 6 + a)];
+                const double p0 = E[ix.rd(kp, 6 + a)];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double ra = fabs(R[3 * r + a]);
+                    bn = dmax(bn, dmax(hdt2 * ra * E[ix.rd(kn, r)], dt * ra * E[ix.rd(kn, 3 + r)]));
+                }
+                if (hn) an = bn;
+                if (hp) an = dmax(an, p0);
+            }
+            Dn[i] = D[i] * (1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i]))));
+            return;
+        }
+        int r0, sv0;
+        row_base(kind, k, sub, r0, sv0);
+        const double* d = D + k * SV;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const int r = r0 + a, i = sv0 + a;
+            double v;  // inf-norm of row r of A D (the row scaling E[r] is applied below)
+            if (kind == 0) v = dmax(D[i], d[3 + a]);
+            else if (kind == 1) {
+                const double* R = q.R + 9 * k + 3 * a;
+                if (sub == 0) {
+                    v = dmax(dmax(D[i], d[a]), dmax(dt * d[3 + a], d[SV + a]));
+                    for (int j = 0; j < 3; ++j) v = dmax(v, hdt2 * fabs(R[j]) * d[6 + j]);
+                } else {
+                    v = dmax(dmax(D[i], d[3 + a]), d[SV + 3 + a]);
+                    for (int j = 0; j < 3; ++j) v = dmax(v, dt * fabs(R[j]) * d[6 + j]);
+                }
+            } else if (kind == 2) v = dmax(D[i], dmax(d[6 + a], d[SV + 6 + a]));
+            else v = dmax(D[i], dmax(d[a], d[SV + a]));
+            En[r] = E[r] * (1.0 / sqrt(limit_scaling(E[r] * v)));
+            Dn[i] = D[i] * (1.0 / sqrt(limit_scaling(dmax(cc * pc[i], E[r] * D[i]))));  // slack column: one entry, in row r
+        }
+    };
+    wtiles(ntiles, [&](int tile, int lane) { (void)adopt(tile, lane); });  // column norms of P for D = 1
+    DEKF_SYNC();
     for (int it = 0; it < q.c.scaling; ++it) {
         const double cc = q.cc;
-        // ---- column norms of [P; A] -> Dt, row norms of A -> Et
-        wfor_nosync(K * 3, [&](int e) {  // position columns
-            int k = e / 3, a = e - 3 * k, i = k * SV + a;
-            double an = 0.0;
-            if (k < K1) an = dmax(E[ix.rd(k, a)], E[ix.rv(k, a)]);
-            if (k > 0) an = dmax(an, dmax(E[ix.rd(k - 1, a)], E[ix.rv(k - 1, a)]));
-            Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i])));
-        });
-        wfor_nosync(K * 3, [&](int e) {  // velocity columns
-            int k = e / 3, a = e - 3 * k, i = k * SV + 3 + a;
-            double an = 0.0;
-            for (int leg = 0; leg < L; ++leg) an = dmax(an, E[ix.rm(k, 3 * leg + a)]);
-            if (k < K1) an = dmax(an, dmax(E[ix.rd(k, 3 + a)], dt * E[ix.rd(k, a)]));
-            if (k > 0) an = dmax(an, E[ix.rd(k - 1, 3 + a)]);
-            Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i])));
-        });
-        wfor_nosync(K * 3, [&](int e) {  // bias columns
-            int k = e / 3, a = e - 3 * k, i = k * SV + 6 + a;
-            double an = 0.0;
-            if (k < K1) {
-                const double* R = q.R + 9 * k;
-                an = E[ix.rd(k, 6 + a)];
-                for (int r = 0; r < 3; ++r) {
-                    double ra = fabs(R[3 * r + a]);
-                    an = dmax(an, dmax(hdt2 * ra * E[ix.rd(k, r)], dt * ra * E[ix.rd(k, 3 + r)]));
-                }
-            }
-            if (k > 0) an = dmax(an, E[ix.rd(k - 1, 6 + a)]);
-            Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i])));
-        });
-        wfor_nosync(m, [&](int r) {  // slack columns: one entry -1 in their own row
-            int k, kind, o;
-            q.dec_row(r, k, kind, o);
-            int i = q.row_slack(k, kind, o);
-            Dt[i] = 1.0 / sqrt(limit_scaling(dmax(cc * pc[i], E[r] * D[i])));
-        });
-        wfor_nosync(K * NM, [&](int e) {  // Meas rows
-            int k = e / NM, o = e - k * NM, r = ix.rm(k, o);
-            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * dmax(D[k * SV + 9 + o], D[k * SV + 3 + o % 3])));
-        });
-        wfor_nosync(K1 * 3, [&](int e) {  // Dyn position rows
-            int k = e / 3, a = e - 3 * k, r = ix.rd(k, a);
-            const double* R = q.R + 9 * k + 3 * a;
-            const double* d = D + k * SV;
-            double v = dmax(dmax(d[9 + NM + a], d[a]), dmax(dt * d[3 + a], d[SV + a]));
-            for (int j = 0; j < 3; ++j) v = dmax(v, hdt2 * fabs(R[j]) * d[6 + j]);
-            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * v));
-        });
-        wfor_nosync(K1 * 3, [&](int e) {  // Dyn velocity rows
-            int k = e / 3, a = e - 3 * k, r = ix.rd(k, 3 + a);
-            const double* R = q.R + 9 * k + 3 * a;
-            const double* d = D + k * SV;
-            double v = dmax(dmax(d[9 + NM + 3 + a], d[3 + a]), d[SV + 3 + a]);
-            for (int j = 0; j < 3; ++j) v = dmax(v, dt * fabs(R[j]) * d[6 + j]);
-            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * v));
-        });
-        wfor_nosync(K1 * 3, [&](int e) {  // Dyn bias rows
-            int k = e / 3, a = e - 3 * k, r = ix.rd(k, 6 + a);
-            const double* d = D + k * SV;
-            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * dmax(d[9 + NM + 6 + a], dmax(d[6 + a], d[SV + 6 + a]))));
-        });
-        wfor(K1 * 3, [&](int e) {  // VO rows
-            int k = e / 3, a = e - 3 * k, r = ix.rv(k, a);
-            const double* d = D + k * SV;
-            Et[r] = 1.0 / sqrt(limit_scaling(E[r] * dmax(d[18 + NM + a], dmax(d[a], d[SV + a]))));
-        });
-        wfor(n + m, [&](int e) { if (e < n) D[e] *= Dt[e]; else E[e - n] *= Et[e - n]; });
+        wtiles(ntiles, [&](int tile, int lane) { equil(tile, lane, cc); });
+        DEKF_SYNC();
+        double psum = 0.0;
+        wtiles(ntiles, [&](int tile, int lane) { psum += adopt(tile, lane); });
+        psum = wave_sum(psum);
+        group_combine<1, true>(&psum);  // two barriers: D, E, pc of this pass are visible afterwards
+        psum *= cc;
         // ---- cost normalisation: mean column norm of the re-scaled P against |q|_inf
-        pnorms();
-        double psum = cc * wred_sum(n, [&](int i) { return pc[i]; });
         double qn = 0.0;
         for (int j = 0; j < 9; ++j) qn = dmax(qn, fabs(cc * D[j] * g[j]));
         double ct = 1.0 / limit_scaling(dmax(psum / (double)n, limit_scaling(qn)));
         q.cc = cc * ct;
-        DEKF_SYNC();
     }
+    DEKF_SYNC();
 }
 
 // numeric factorisation for the current rho: slack-block inverses, effective row weights,

@@ -176,6 +176,7 @@ inline void wred_maxn(int n, double* out, F f) {
     for (int r = 0; r < NR; ++r) out[r] = acc[r];
 }
 inline double wave_max(double v) { return v; }   // one sequential "lane" has seen every item already
+inline double wave_sum(double v) { return v; }
 template <int NR, bool SUM>
 inline void group_combine(double*) {}
 template <class F>
