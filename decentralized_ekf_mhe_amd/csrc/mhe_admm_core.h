@@ -362,7 +362,7 @@ DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM&
             zn[j] = lo[j];
         } else {
             rv = q.rho_of(lo[j], hi[j]);
-            zn[j] = dmin(dmax(zh + (1.0 / rv) * y0[j], lo[j]), hi[j]);
+            zn[j] = dmin(dmax(zh + rcp_fast(rv) * y0[j], lo[j]), hi[j]);
         }
         yn[j] = y0[j] + rv * (zh - zn[j]);
         un[j] = rv * zn[j] - yn[j];
@@ -602,7 +602,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             const int r = r0 + j, sv = sv0 + j;
             const double e = E[r], d = D[sv];
             const double Ax = ar[j] - e * d * x[sv];
-            const double pr = Ax - z[r], ei = 1.0 / e;
+            const double pr = Ax - z[r], ei = rcp_fast(e);
             acc[0] = dmax(acc[0], fabs(pr) * ei);
             acc[1] = dmax(acc[1], fabs(z[r]) * ei);
             acc[2] = dmax(acc[2], fabs(Ax) * ei);
@@ -610,7 +610,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             acc[4] = dmax(acc[4], fabs(z[r]));
             acc[5] = dmax(acc[5], fabs(Ax));
             const double Px = cc * d * ps[j], Aty = -e * d * y[r];
-            const double dr = Px + Aty, di = 1.0 / d;
+            const double dr = Px + Aty, di = rcp_fast(d);
             acc[6] = dmax(acc[6], fabs(dr) * di);
             acc[8] = dmax(acc[8], fabs(Aty) * di);
             acc[9] = dmax(acc[9], fabs(Px) * di);
@@ -716,7 +716,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             for (int t = 0; t < 9; ++t) Px += (j <= t ? q.Mp[9 * j + t] : q.Mp[9 * t + j]) * xd[t];
             Px *= cc * d;
         }
-        const double Aty = d * g, dr = qv + Px + Aty, di = 1.0 / d;
+        const double Aty = d * g, dr = qv + Px + Aty, di = rcp_fast(d);
         acc[6] = dmax(acc[6], fabs(dr) * di);
         acc[7] = dmax(acc[7], fabs(qv) * di);
         acc[8] = dmax(acc[8], fabs(Aty) * di);

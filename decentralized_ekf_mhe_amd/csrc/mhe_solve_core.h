@@ -409,7 +409,7 @@ DEKF_FN void solve_scale(Q& q) {
                 if (hn) an = bn;
                 if (hp) an = dmax(an, p0);
             }
-            Dn[i] = D[i] * (1.0 / sqrt(limit_scaling(dmax(cc * pc[i], an * D[i]))));
+            Dn[i] = D[i] * rsqrt_fast(limit_scaling(dmax(cc * pc[i], an * D[i])));
             return;
         }
         int r0, sv0;
@@ -431,8 +431,8 @@ DEKF_FN void solve_scale(Q& q) {
                 }
             } else if (kind == 2) v = dmax(D[i], dmax(d[6 + a], d[SV + 6 + a]));
             else v = dmax(D[i], dmax(d[a], d[SV + a]));
-            En[r] = E[r] * (1.0 / sqrt(limit_scaling(E[r] * v)));
-            Dn[i] = D[i] * (1.0 / sqrt(limit_scaling(dmax(cc * pc[i], E[r] * D[i]))));  // slack column: one entry, in row r
+            En[r] = E[r] * rsqrt_fast(limit_scaling(E[r] * v));
+            Dn[i] = D[i] * rsqrt_fast(limit_scaling(dmax(cc * pc[i], E[r] * D[i])));  // slack column: one entry, in row r
         }
     };
     wtiles(ntiles, [&](int tile, int lane) { (void)adopt(tile, lane); });  // column norms of P for D = 1
@@ -722,7 +722,7 @@ DEKF_FN bool solve_factor(Q& q) {
             for (int i = 0; i < 9; ++i) col[i] = readlane_f64(a[i], pv);
             const double piv = col[pv];
             good = good && (fabs(piv) > 0.0) && (fabs(piv) < 1e300);
-            const double d = 1.0 / piv;
+            const double d = rcp_fast(piv);
             const bool own = lane == pv;
             const double m = a[pv] * d;
 #pragma unroll
