@@ -703,12 +703,36 @@ DEKF_FN bool solve_factor(Q& q) {
     // 9x9 inversion is a Gauss-Jordan sweep on registers (lane j < 9 holds column j, the pivot column is
     // broadcast with v_readlane), so a block costs three LDS round trips instead of eleven workgroup
     // barriers.  The host build below keeps the phase-per-pivot form (same arithmetic up to rounding).
-    (void)nph; (void)bufs; (void)gj_step; (void)pivot_ok; (void)store_sinv;
+    (void)nph; (void)bufs; (void)gj_step; (void)pivot_ok; (void)store_sinv; (void)build_s;
+    // S of block k, element p (device form: three independent accumulators per sum, no symmetrisation —
+    // W C' = C S^-1 C' is symmetric up to rounding and the Gauss-Jordan sweep does not need more)
+    auto build_s3 = [&](int k, bool use_top, bool use_bot, int p, double* dst) {
+        const int i = p / 9, j = p - 9 * i;
+        const int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
+        double acc = q.Sinv[k * 45 + symidx(lo_, hi_, 9)];
+        if (use_top) {
+            const double* Wp = q.Wk + (k - 1) * 81 + 9 * i;
+            const double* Cp = q.PA + (k - 1) * 81 + 9 * j;
+            double s0 = Wp[0] * Cp[0] + Wp[3] * Cp[3] + Wp[6] * Cp[6];
+            double s1 = Wp[1] * Cp[1] + Wp[4] * Cp[4] + Wp[7] * Cp[7];
+            double s2 = Wp[2] * Cp[2] + Wp[5] * Cp[5] + Wp[8] * Cp[8];
+            acc -= s0 + (s1 + s2);
+        }
+        if (use_bot) {
+            const double* Wh = q.Wk + k * 81 + 9 * i;
+            const double* Ck = q.PA + k * 81 + j;
+            double s0 = Wh[0] * Ck[0] + Wh[3] * Ck[27] + Wh[6] * Ck[54];
+            double s1 = Wh[1] * Ck[9] + Wh[4] * Ck[36] + Wh[7] * Ck[63];
+            double s2 = Wh[2] * Ck[18] + Wh[5] * Ck[45] + Wh[8] * Ck[72];
+            acc -= s0 + (s1 + s2);
+        }
+        dst[p] = acc;
+    };
     auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, double* tb) -> bool {
         // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]
         const int lane = DEKF_LANE() & 63;
         double* ts = tb;        // S, then the full inverse
-        for (int p = lane; p < 81; p += WAVE) build_s(k, use_top, use_bot, p, ts);
+        for (int p = lane; p < 81; p += WAVE) build_s3(k, use_top, use_bot, p, ts);
         wave_sync();
         const int j = lane < 9 ? lane : 8;
         double a[9];
@@ -733,28 +757,26 @@ DEKF_FN bool solve_factor(Q& q) {
         }
         wave_sync();  // every lane has read its column of S
         if (lane < 9) {
+            // column j of the inverse: the full matrix for the W product, its upper part as the packed S^-1
 #pragma unroll
-            for (int i = 0; i < 9; ++i) ts[9 * i + j] = a[i];
+            for (int i = 0; i < 9; ++i) {
+                ts[9 * i + j] = a[i];
+                if (i <= j) q.Sinv[k * 45 + symidx(i, i, 9) + (j - i)] = a[i];
+            }
         }
         wave_sync();
-        if (lane < 45) store_sinv(k, ts, lane);
-        if (wmode == 1) {
-            const double* Ck = q.PA + k * 81;
+        if (wmode != 0) {
+            const int kw = wmode == 1 ? k : k - 1;
+            const double* Ck = q.PA + kw * 81;
             for (int p = lane; p < 81; p += WAVE) {
-                int i = p / 9, jj = p - 9 * i;
-                double acc = 0.0;
-#pragma unroll
-                for (int u = 0; u < 9; ++u) acc += Ck[9 * i + u] * ts[9 * u + jj];
-                q.Wk[k * 81 + p] = acc;
-            }
-        } else if (wmode == 2) {
-            const double* Ck = q.PA + (k - 1) * 81;
-            for (int p = lane; p < 81; p += WAVE) {
-                int i = p / 9, jj = p - 9 * i;
-                double acc = 0.0;
-#pragma unroll
-                for (int u = 0; u < 9; ++u) acc += Ck[9 * u + i] * ts[9 * u + jj];
-                q.Wk[(k - 1) * 81 + p] = acc;
+                const int i = p / 9, jj = p - 9 * i;
+                const double* cr = wmode == 1 ? Ck + 9 * i : Ck + i;  // row i of C, or column i (C')
+                const int cs = wmode == 1 ? 1 : 9;
+                const double* tc = ts + jj;
+                double s0 = cr[0] * tc[0] + cr[3 * cs] * tc[27] + cr[6 * cs] * tc[54];
+                double s1 = cr[cs] * tc[9] + cr[4 * cs] * tc[36] + cr[7 * cs] * tc[63];
+                double s2 = cr[2 * cs] * tc[18] + cr[5 * cs] * tc[45] + cr[8 * cs] * tc[72];
+                q.Wk[kw * 81 + p] = s0 + (s1 + s2);
             }
         }
         wave_sync();
