@@ -206,7 +206,7 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
     const int K = q.K, mid = mid_block(K);
     double *xs = q.xs, *xd = q.xd, *x = q.x;
-    const double* Si = q.Sinv + mid * 45;
+    const double* Si = q.Sinv + mid * 81;
 #if DEKF_DEVICE_BUILD
     const int i = lane < 9 ? lane : 8;
     double f = xs[9 * mid + i];
@@ -220,7 +220,7 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
     }
     double s[9], ft[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) s[t] = Si[symrow_idx(i, symrow_start(i, 9), t, 9)];
+    for (int t = 0; t < 9; ++t) s[t] = Si[9 * i + t];
 #pragma unroll
     for (int t = 0; t < 9; ++t) ft[t] = readlane_f64(f, t);
     double a0 = s[0] * ft[0] + s[3] * ft[3] + s[6] * ft[6];
@@ -248,9 +248,9 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
         }
     }
     for (int i = 0; i < 9; ++i) {
-        double a0 = symget(Si, i, 0, 9) * f[0] + symget(Si, i, 3, 9) * f[3] + symget(Si, i, 6, 9) * f[6];
-        double a1 = symget(Si, i, 1, 9) * f[1] + symget(Si, i, 4, 9) * f[4] + symget(Si, i, 7, 9) * f[7];
-        double a2 = symget(Si, i, 2, 9) * f[2] + symget(Si, i, 5, 9) * f[5] + symget(Si, i, 8, 9) * f[8];
+        double a0 = Si[9 * i + 0] * f[0] + Si[9 * i + 3] * f[3] + Si[9 * i + 6] * f[6];
+        double a1 = Si[9 * i + 1] * f[1] + Si[9 * i + 4] * f[4] + Si[9 * i + 7] * f[7];
+        double a2 = Si[9 * i + 2] * f[2] + Si[9 * i + 5] * f[5] + Si[9 * i + 8] * f[8];
         const double u = a0 + a1 + a2;
         const int xi = mid * SV + i;
         xs[9 * mid + i] = u;
@@ -288,12 +288,11 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
         if (tile == 0) { sweep_mid_block(q, lane, alpha); return; }
         const int blk = lane / 9, i = lane - 9 * blk, k = (tile - 1) * 7 + blk;
         if (blk >= 7 || k >= K || k == mid) return;
-        const double* Si = q.Sinv + k * 45;
+        const double* Si = q.Sinv + k * 81 + 9 * i;
         const double* f = q.xs + 9 * k;
-        const int rs = symrow_start(i, 9);
         double sv[9], fv[9];
 #pragma unroll
-        for (int t = 0; t < 9; ++t) { sv[t] = Si[symrow_idx(i, rs, t, 9)]; fv[t] = f[t]; }
+        for (int t = 0; t < 9; ++t) { sv[t] = Si[t]; fv[t] = f[t]; }
         double a0 = sv[0] * fv[0] + sv[3] * fv[3] + sv[6] * fv[6];
         double a1 = sv[1] * fv[1] + sv[4] * fv[4] + sv[7] * fv[7];
         double a2 = sv[2] * fv[2] + sv[5] * fv[5] + sv[8] * fv[8];
@@ -341,7 +340,7 @@ DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM&
         z0[j] = q.z[r];
         y0[j] = q.y[r];
         lo[j] = q.lo[r];
-        hi[j] = EQ ? 0.0 : q.hi[r];
+        hi[j] = EQ ? 0.0 : q.hi[r - q.ix.rvb];
     }
     double v[NR], sl[NR], xn[NR], zn[NR], yn[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll

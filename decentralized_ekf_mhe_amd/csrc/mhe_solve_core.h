@@ -56,14 +56,14 @@ constexpr int SOLVE_TMP = 344;  // [162,171) scaled q; at factor time [0,162) an
 struct SolveLayout {
     int n_pad, m_pad, K;
     int vec;        // iterates: x z y xt zt at xs xd tmp
-    int resident;   // D E lo hi Sv Sw Sc Sinv Wk R
+    int resident;   // D E lo hi(VO rows) Sv Sw Sc Sinv(full 9x9) Wk R
     DEKF_HD void init(int N, int L) {
         int nm = 3 * L;
         K = N;
         n_pad = N * (9 + nm + 12);
         m_pad = N * (nm + 12);
         vec = 2 * n_pad + 4 * m_pad + 18 * N + SOLVE_TMP;
-        resident = n_pad + 3 * m_pad + N * (6 * L + SWS + 6) + N * (45 + 81) + 9 * N;
+        resident = n_pad + 2 * m_pad + 3 * N + N * (6 * L + SWS + 6) + N * (81 + 81) + 9 * N;
     }
     // LDS-resident factor only if two workgroups still fit in one CU's 160 KiB
     DEKF_HD bool factor_in_lds() const { return (size_t)(vec + resident) * 8 <= 80 * 1024; }
@@ -125,7 +125,9 @@ struct SolveCtx {
         if (lb < -OSQP_INFTY * MIN_SCALING && ub > OSQP_INFTY * MIN_SCALING) return RHO_MIN;
         return (ub - lb < RHO_TOL) ? RHO_EQ_OVER_RHO_INEQ * rho : rho;
     }
-    DEKF_FN double rho_at(int r) const { return rho_of(lo[r], hi[r]); }
+    // Meas and Dyn rows are equalities by construction (l == u): only the VO rows keep an upper bound
+    // (hi is indexed from the first VO row; the full-length vector was 3.3 KiB of LDS for nothing)
+    DEKF_FN double rho_at(int r) const { return r < ix.rvb ? RHO_EQ_OVER_RHO_INEQ * rho : rho_of(lo[r], hi[r - ix.rvb]); }
     // unscaled bound of row (k, kind, o): kind 0 Meas, 1 Dyn, 2 VO
     DEKF_FN void bounds(int k, int kind, int o, double& lb, double& ub) const {
         const double* r = rec(k);
@@ -644,7 +646,8 @@ DEKF_FN bool solve_factor(Q& q) {
                 if (i > j) continue;
                 double v = tc[i] + (i == j ? sigma : 0.0);
                 if (k == 0) v += cc * dx[i] * q.Mp[9 * i + j] * dj;
-                q.Sinv[k * 45 + symidx(i, i, 9) + (j - i)] = v;
+                q.Sinv[k * 81 + 9 * i + j] = v;  // full 9x9 storage, both triangles
+                q.Sinv[k * 81 + 9 * j + i] = v;
             }
         });
         DEKF_SYNC();
@@ -665,7 +668,7 @@ DEKF_FN bool solve_factor(Q& q) {
     auto build_s = [&](int k, bool use_top, bool use_bot, int p, double* dst) {
         int i = p / 9, j = p - 9 * i;
         int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
-        double acc = q.Sinv[k * 45 + symidx(lo_, hi_, 9)];
+        double acc = q.Sinv[k * 81 + 9 * lo_ + hi_];
         if (use_top) {
             const double* Wp = q.Wk + (k - 1) * 81;
             const double* Cp = q.PA + (k - 1) * 81;
@@ -696,7 +699,9 @@ DEKF_FN bool solve_factor(Q& q) {
         int p = e, i = 0;
         while (p >= 9 - i) { p -= 9 - i; ++i; }
         int j = i + p;
-        q.Sinv[k * 45 + e] = 0.5 * (src[9 * i + j] + src[9 * j + i]);
+        const double sv = 0.5 * (src[9 * i + j] + src[9 * j + i]);
+        q.Sinv[k * 81 + 9 * i + j] = sv;
+        q.Sinv[k * 81 + 9 * j + i] = sv;
     };
 #if DEKF_DEVICE_BUILD
     // Device: each side is ONE wavefront working through its blocks with wave-level syncs only; the
@@ -709,7 +714,7 @@ DEKF_FN bool solve_factor(Q& q) {
     auto build_s3 = [&](int k, bool use_top, bool use_bot, int p, double* dst) {
         const int i = p / 9, j = p - 9 * i;
         const int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
-        double acc = q.Sinv[k * 45 + symidx(lo_, hi_, 9)];
+        double acc = q.Sinv[k * 81 + 9 * lo_ + hi_];
         if (use_top) {
             const double* Wp = q.Wk + (k - 1) * 81 + 9 * i;
             const double* Cp = q.PA + (k - 1) * 81 + 9 * j;
@@ -757,11 +762,12 @@ DEKF_FN bool solve_factor(Q& q) {
         }
         wave_sync();  // every lane has read its column of S
         if (lane < 9) {
-            // column j of the inverse: the full matrix for the W product, its upper part as the packed S^-1
+            // column j of the inverse: to the scratch copy for the W product and to S^-1[k] (full 9x9: a row is
+            // contiguous, so the solve phases address it with immediates instead of packed-index arithmetic)
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
                 ts[9 * i + j] = a[i];
-                if (i <= j) q.Sinv[k * 45 + symidx(i, i, 9) + (j - i)] = a[i];
+                q.Sinv[k * 81 + 9 * i + j] = a[i];
             }
         }
         wave_sync();
@@ -893,11 +899,11 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
             q.D = p; p += lay.n_pad;
             q.E = p; p += lay.m_pad;
             q.lo = p; p += lay.m_pad;
-            q.hi = p; p += lay.m_pad;
+            q.hi = p; p += 3 * NH;
             q.Sv = p; p += NH * 6 * L;
             q.Sw = p; p += NH * SWS;
             q.Sc = p; p += NH * 6;
-            q.Sinv = p; p += NH * 45;
+            q.Sinv = p; p += NH * 81;
             q.Wk = p; p += NH * 81;
             q.R = p; p += NH * 9;
         } else {
@@ -941,7 +947,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         double lb, ub;
         q.bounds(k, kind, o, lb, ub);
         q.lo[r] = lb * q.E[r];
-        q.hi[r] = ub * q.E[r];
+        if (kind == 2) q.hi[r - q.ix.rvb] = ub * q.E[r];
         z[r] = 0.0;
         y[r] = 0.0;
         at[r] = 0.0;  // u = rho z - y of the cold start
