@@ -262,7 +262,7 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
             Am[q] = i < 9 ? adyn_entry(R, dt, i, j) : ((i - 9) == j ? 1.0 : 0.0);
         }
     });
-    bool ok = winverse(Minv, 9, wsc, false);
+    bool ok = winverse_definite(Minv, 9, wsc);
     wmatmul<false, false>(AmMi, 9, Am, 9, Minv, 9, na, 9, 9);
     wfor(dim * dim + 9, [&](int e) {
         if (e >= dim * dim) {
@@ -327,7 +327,8 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
         }
         u[i] = v;
     });
-    ok = winverse(S, dim, wsc, true) && ok;
+    // S = -([A; H] M^-1 [A; H]' + blkdiag(Q^-1, R^-1)) is negative definite: no pivoting needed
+    ok = winverse_definite(S, dim, wsc) && ok;
     wfor(dim, [&](int i) {
         double sacc = 0;
         for (int t = 0; t < dim; ++t) sacc += S[i * dim + t] * u[t];

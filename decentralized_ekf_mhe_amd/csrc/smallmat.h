@@ -154,4 +154,32 @@ DEKF_FN bool winverse(double* A, int n, double* scratch, bool pivoting) {
     return ok;
 }
 
+// In-place inverse of a DEFINITE symmetric matrix (positive or negative: no pivoting needed) by the
+// Gauss-Jordan sweep: n pivots, each one copy of the pivot row / column and one pass over the n*n
+// elements — half the elements of the augmented [A | I] form above, and no pivot search.
+// scratch: 2n (pivot row, pivot column).
+DEKF_FN bool winverse_definite(double* A, int n, double* scratch) {
+    double* rowp = scratch;
+    double* colp = scratch + n;
+    bool ok = true;
+    for (int p = 0; p < n; ++p) {
+        const double piv = A[p * n + p];
+        if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) { ok = false; break; }  // group-uniform
+        wfor(2 * n, [&](int e) {
+            if (e < n) rowp[e] = A[p * n + e];
+            else colp[e - n] = A[(e - n) * n + p];
+        });
+        const double d = 1.0 / piv;
+        wfor(n * n, [&](int e) {
+            int i = e / n, j = e - i * n;
+            double v;
+            if (i == p) v = (j == p) ? d : rowp[j] * d;
+            else if (j == p) v = -colp[i] * d;
+            else v = A[e] - colp[i] * rowp[j] * d;
+            A[e] = v;
+        });
+    }
+    return ok;
+}
+
 }  // namespace dekf
