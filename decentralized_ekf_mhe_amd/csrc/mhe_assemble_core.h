@@ -53,7 +53,7 @@ DEKF_FN void step_gains(const DevCfg& c, const double* R, double* qd21, double* 
             G[6 * (3 + i) + j] = 0.5 * dt * dt * dt * RCa[3 * j + i];
             G[6 * (3 + i) + 3 + j] = dt * dt * RCa[3 * i + j];
         }
-    inv_small<6>(G, 6);
+    inv_spd_unrolled<6>(G);  // G C G' is SPD; static indices keep G in registers (no scratch memory)
     int p = 0;
     for (int i = 0; i < 6; ++i)
         for (int j = i; j < 6; ++j) qd21[p++] = G[6 * i + j];
@@ -68,11 +68,14 @@ DEKF_FN void step_gains(const DevCfg& c, const double* R, double* qd21, double* 
 
 // b_meas and the 3x3 gain (as_gain) or covariance of leg `leg` at the latched sample (one lane)
 // (DecentralEst.cpp:513-547 / :807-837)
-DEKF_FN void leg_terms(const DevCfg& c, const double* R, const double* gyro, const double* p_foot, const double* J,
+template <int NJ>
+DEKF_FN void leg_terms_nj(const DevCfg& c, const double* R, const double* gyro, const double* p_foot, const double* J,
                        const double* qdot, double contact, bool as_gain, double* bm3, double* w6) {
-    int nj = c.nj;
+    const int nj = NJ > 0 ? NJ : c.nj;  // NJ > 0: every loop below unrolls and the local arrays stay in registers
     double Jq[3] = {0, 0, 0};
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < nj; ++j) Jq[i] += J[i * nj + j] * qdot[j];
     double wxp[3], t1[3], t2[3];
     cross3(gyro, p_foot, wxp);
@@ -85,7 +88,8 @@ DEKF_FN void leg_terms(const DevCfg& c, const double* R, const double* gyro, con
         return;
     }
     // G C G' with G = [-J, -w^x J, p^x], C = diag(C_enc_vel, C_enc_pos, C_gyro)
-    double WJ[3 * DEKF_MAX_JOINTS];
+    double WJ[3 * (NJ > 0 ? NJ : DEKF_MAX_JOINTS)];
+#pragma unroll
     for (int j = 0; j < nj; ++j) {
         double col[3] = {J[0 * nj + j], J[1 * nj + j], J[2 * nj + j]}, o[3];
         cross3(gyro, col, o);
@@ -93,9 +97,12 @@ DEKF_FN void leg_terms(const DevCfg& c, const double* R, const double* gyro, con
     }
     double Px[9] = {0, -p_foot[2], p_foot[1], p_foot[2], 0, -p_foot[0], -p_foot[1], p_foot[0], 0};
     double Cb[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int k = 0; k < 3; ++k) {
             double s = 0;
+#pragma unroll
             for (int j = 0; j < nj; ++j) s += J[i * nj + j] * c.C_enc_vel[j] * J[k * nj + j] + WJ[i * nj + j] * c.C_enc_pos[j] * WJ[k * nj + j];
             for (int t = 0; t < 3; ++t) s += Px[3 * i + t] * c.C_gyro[t] * Px[3 * k + t];
             Cb[3 * i + k] = s;
@@ -113,8 +120,15 @@ DEKF_FN void leg_terms(const DevCfg& c, const double* R, const double* gyro, con
             for (int t = 0; t < 3; ++t) s += RC[3 * i + t] * R[3 * k + t];
             Cw[3 * i + k] = s;
         }
-    if (as_gain) inv_small<3>(Cw, 3);
+    const double cs[6] = {Cw[0], 0.5 * (Cw[1] + Cw[3]), 0.5 * (Cw[2] + Cw[6]), Cw[4], 0.5 * (Cw[5] + Cw[7]), Cw[8]};
+    if (as_gain) { inv3_sym(cs, w6); return; }
     w6[0] = Cw[0]; w6[1] = Cw[1]; w6[2] = Cw[2]; w6[3] = Cw[4]; w6[4] = Cw[5]; w6[5] = Cw[8];
+}
+DEKF_FN void leg_terms(const DevCfg& c, const double* R, const double* gyro, const double* p_foot, const double* J,
+                       const double* qdot, double contact, bool as_gain, double* bm3, double* w6) {
+    if (c.nj == 3) leg_terms_nj<3>(c, R, gyro, p_foot, J, qdot, contact, as_gain, bm3, w6);       // Go1, PogoX
+    else if (c.nj == 5) leg_terms_nj<5>(c, R, gyro, p_foot, J, qdot, contact, as_gain, bm3, w6);  // Cassie
+    else leg_terms_nj<0>(c, R, gyro, p_foot, J, qdot, contact, as_gain, bm3, w6);
 }
 
 // GetMeasurement(T): returns through LDS/HBM; `pushes` = samples already on the stack.
@@ -155,18 +169,22 @@ DEKF_FN void get_measurement(const DevCfg& c, const DevState& s, int b, int T, i
             double P[4][3], tw[4];
             int nw = wcnt < 4 ? wcnt + 1 : 4;
             int shift = wcnt < 4 ? 0 : 1;
-            for (int i = 0; i < nw - 1; ++i) {
-                for (int a = 0; a < 3; ++a) P[i][a] = wp[3 * (i + shift) + a];
-                tw[i] = wpt[i + shift];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {  // static indices: P and tw stay in registers
+                const int src = i + shift < 3 ? i + shift : 3;
+#pragma unroll
+                for (int a = 0; a < 3; ++a) P[i][a] = i < nw - 1 ? wp[3 * src + a] : (i == nw - 1 ? acc[a] : 0.0);
+                tw[i] = i < nw - 1 ? wpt[src] : (i == nw - 1 ? t_now : 0.0);
             }
-            for (int a = 0; a < 3; ++a) P[nw - 1][a] = acc[a];
-            tw[nw - 1] = t_now;
             DEKF_SYNC();
             if (DEKF_LANE() == 0) {
-                for (int i = 0; i < nw; ++i) {
-                    for (int a = 0; a < 3; ++a) wp[3 * i + a] = P[i][a];
-                    wpt[i] = tw[i];
-                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < nw) {
+#pragma unroll
+                        for (int a = 0; a < 3; ++a) wp[3 * i + a] = P[i][a];
+                        wpt[i] = tw[i];
+                    }
                 s.wp_count[b] = nw;
                 for (int a = 0; a < 3; ++a) pv[a] = acc[a];
             }
@@ -289,25 +307,27 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
     // minus the inverse gains on the diagonal blocks: one lane per block
     wfor(L + 2, [&](int blk) {
         if (blk < L) {
-            const double* q6 = r + Rec::qm(nm) + 6 * blk;
-            double Q[9] = {q6[0], q6[1], q6[2], q6[1], q6[3], q6[4], q6[2], q6[4], q6[5]};
-            inv_small<3>(Q, 3);
+            double qi[6];
+            inv3_sym(r + Rec::qm(nm) + 6 * blk, qi);
             for (int a = 0; a < 3; ++a)
-                for (int d = 0; d < 3; ++d) S[(na + 3 * blk + a) * dim + na + 3 * blk + d] -= Q[3 * a + d];
+                for (int d = 0; d < 3; ++d) S[(na + 3 * blk + a) * dim + na + 3 * blk + d] -= symget(qi, a, d, 3);
         } else if (blk == L) {
             double Q[36];
+#pragma unroll
             for (int i = 0; i < 6; ++i)
+#pragma unroll
                 for (int j = 0; j < 6; ++j) Q[6 * i + j] = symget(r + Rec::QD, i, j, 6);
-            inv_small<6>(Q, 6);
+            inv_spd_unrolled<6>(Q);
+#pragma unroll
             for (int i = 0; i < 6; ++i)
+#pragma unroll
                 for (int j = 0; j < 6; ++j) S[i * dim + j] -= Q[6 * i + j];
             for (int i = 0; i < 3; ++i) S[(6 + i) * dim + 6 + i] -= 1.0 / c.Q_bias_dt2[i];
         } else if (vo) {
-            const double* q6 = r + Rec::QC;
-            double Q[9] = {q6[0], q6[1], q6[2], q6[1], q6[3], q6[4], q6[2], q6[4], q6[5]};
-            inv_small<3>(Q, 3);
+            double qi[6];
+            inv3_sym(r + Rec::QC, qi);
             for (int a = 0; a < 3; ++a)
-                for (int d = 0; d < 3; ++d) S[(9 + a) * dim + 9 + d] -= Q[3 * a + d];
+                for (int d = 0; d < 3; ++d) S[(9 + a) * dim + 9 + d] -= symget(qi, a, d, 3);
         }
     });
     // u = [ b_dyn ; vo bound ] + Am M^-1 n   |   b_meas + H M^-1 n
