@@ -330,56 +330,68 @@ DEKF_FN void solve_scale(Q& q) {
         else if (kind == 2) { r0 = ix.rd(k, 6); sv0 = k * SV + 9 + NM + 6; }
         else { r0 = ix.rv(k, 0); sv0 = k * SV + 18 + NM; }
     };
+    // Both lambdas read everything they need BEFORE their first store (a store through one pointer pins
+    // every later load behind it: interleaved, a block cost one LDS round trip per row).
     // inf-norms of the owned columns of D P D (cc excluded) from the new scaling Dn; returns their sum
     auto adopt = [&](int tile, int lane) -> double {
         int kind, k, sub;
         if (!decode(tile, lane, kind, k, sub)) return 0.0;
-        double sum = 0.0;
         if (kind >= 4) {
             const int j = 3 * (kind - 4) + sub, i = k * SV + j;
             const double dj = Dn[i];
-            D[i] = dj;
             double v = 0.0;
-            if (k == 0)
-                for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * symget(Mst, j, t, 9) * Dn[t]));
+            if (k == 0) {
+                double mj[9], dt9[9];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { mj[t] = symget(Mst, j, t, 9); dt9[t] = Dn[t]; }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * mj[t] * dt9[t]));
+            }
+            D[i] = dj;
             pc[i] = v;
             return v;
         }
         int r0, sv0;
         row_base(kind, k, sub, r0, sv0);
+        double en[3], dn[3], v[3];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) { E[r0 + a] = En[r0 + a]; D[sv0 + a] = Dn[sv0 + a]; }
+        for (int a = 0; a < 3; ++a) { en[a] = En[r0 + a]; dn[a] = Dn[sv0 + a]; }
         if (kind == 1) {
             const double* q21 = Pst + k * PS + 6 * L;
             const double* d = Dn + k * SV + 9 + NM;
+            double d6[6], p[3][6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) d6[t] = d[t];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const double p0 = q21[a < t ? symidx(a, t, 6) : symidx(t, a, 6)];
+                    const double p1 = q21[3 + a < t ? symidx(3 + a, t, 6) : symidx(t, 3 + a, 6)];
+                    p[a][t] = sub ? p1 : p0;
+                }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
-                const int o = 3 * sub + a;
-                double v = 0.0;
-                for (int t = 0; t < 6; ++t) v = dmax(v, fabs(symget(q21, o, t, 6) * d[t]));
-                v *= d[o];
-                pc[sv0 + a] = v;
-                sum += v;
+                double m = 0.0;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) m = dmax(m, fabs(p[a][t] * d6[t]));
+                v[a] = m * dn[a];
             }
         } else if (kind == 2) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double d = Dn[sv0 + a], v = d * q.c.Q_bias_dt2[a] * d;
-                pc[sv0 + a] = v;
-                sum += v;
-            }
+            for (int a = 0; a < 3; ++a) v[a] = dn[a] * q.c.Q_bias_dt2[a] * dn[a];
         } else {
             const double* q6 = Pst + k * PS + (kind == 0 ? 6 * sub : 6 * L + 21);
-            const double* d = Dn + sv0;
+            double p6[6];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                double v = dmax(fabs(symget(q6, a, 0, 3) * d[0]), dmax(fabs(symget(q6, a, 1, 3) * d[1]), fabs(symget(q6, a, 2, 3) * d[2])));
-                v *= d[a];
-                pc[sv0 + a] = v;
-                sum += v;
-            }
+            for (int t = 0; t < 6; ++t) p6[t] = q6[t];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                v[a] = dmax(fabs(p6[symidx(0, a, 3)] * dn[0]), dmax(fabs(p6[1 < a ? symidx(1, a, 3) : symidx(a, 1, 3)] * dn[1]), fabs(p6[symidx(a, 2, 3)] * dn[2]))) * dn[a];
         }
-        return sum;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { E[r0 + a] = en[a]; D[sv0 + a] = dn[a]; pc[sv0 + a] = v[a]; }
+        return v[0] + v[1] + v[2];
     };
     auto equil = [&](int tile, int lane, double cc) {
         int kind, k, sub;
@@ -388,6 +400,7 @@ DEKF_FN void solve_scale(Q& q) {
             const int a = sub, i = k * SV + 3 * (kind - 4) + a;
             const bool hn = k < K1, hp = k > 0;
             const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
+            const double di = D[i], pci = pc[i];
             double an = 0.0;
             if (kind == 4) {
                 const double n0 = E[ix.rd(kn, a)], n1 = E[ix.rv(kn, a)], p0 = E[ix.rd(kp, a)], p1 = E[ix.rv(kp, a)];
@@ -411,31 +424,51 @@ DEKF_FN void solve_scale(Q& q) {
                 if (hn) an = bn;
                 if (hp) an = dmax(an, p0);
             }
-            Dn[i] = D[i] * rsqrt_fast(limit_scaling(dmax(cc * pc[i], an * D[i])));
+            Dn[i] = di * rsqrt_fast(limit_scaling(dmax(cc * pci, an * di)));
             return;
         }
         int r0, sv0;
         row_base(kind, k, sub, r0, sv0);
         const double* d = D + k * SV;
+        double e3[3], d3[3], p3[3], v[3];  // own rows / slacks; v = inf-norm of the row of A D (before E)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { e3[a] = E[r0 + a]; d3[a] = D[sv0 + a]; p3[a] = pc[sv0 + a]; }
+        if (kind == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], d[3 + a]);
+        } else if (kind == 1) {
+            const double* R = q.R + 9 * k;
+            double dk[9], dnx[6], Ra[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { dk[t] = d[t]; Ra[t] = fabs(R[t]); }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) dnx[t] = d[SV + t];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double vp = dmax(dmax(d3[a], dk[a]), dmax(dt * dk[3 + a], dnx[a]));
+                double vv = dmax(dmax(d3[a], dk[3 + a]), dnx[3 + a]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    vp = dmax(vp, hdt2 * Ra[3 * a + j] * dk[6 + j]);
+                    vv = dmax(vv, dt * Ra[3 * a + j] * dk[6 + j]);
+                }
+                v[a] = sub ? vv : vp;
+            }
+        } else if (kind == 2) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], dmax(d[6 + a], d[SV + 6 + a]));
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], dmax(d[a], d[SV + a]));
+        }
+        double eo[3], dout[3];
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const int r = r0 + a, i = sv0 + a;
-            double v;  // inf-norm of row r of A D (the row scaling E[r] is applied below)
-            if (kind == 0) v = dmax(D[i], d[3 + a]);
-            else if (kind == 1) {
-                const double* R = q.R + 9 * k + 3 * a;
-                if (sub == 0) {
-                    v = dmax(dmax(D[i], d[a]), dmax(dt * d[3 + a], d[SV + a]));
-                    for (int j = 0; j < 3; ++j) v = dmax(v, hdt2 * fabs(R[j]) * d[6 + j]);
-                } else {
-                    v = dmax(dmax(D[i], d[3 + a]), d[SV + 3 + a]);
-                    for (int j = 0; j < 3; ++j) v = dmax(v, dt * fabs(R[j]) * d[6 + j]);
-                }
-            } else if (kind == 2) v = dmax(D[i], dmax(d[6 + a], d[SV + 6 + a]));
-            else v = dmax(D[i], dmax(d[a], d[SV + a]));
-            En[r] = E[r] * rsqrt_fast(limit_scaling(E[r] * v));
-            Dn[i] = D[i] * rsqrt_fast(limit_scaling(dmax(cc * pc[i], E[r] * D[i])));  // slack column: one entry, in row r
+            eo[a] = e3[a] * rsqrt_fast(limit_scaling(e3[a] * v[a]));
+            dout[a] = d3[a] * rsqrt_fast(limit_scaling(dmax(cc * p3[a], e3[a] * d3[a])));  // slack column: one entry, in its row
         }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { En[r0 + a] = eo[a]; Dn[sv0 + a] = dout[a]; }
     };
     wtiles(ntiles, [&](int tile, int lane) { (void)adopt(tile, lane); });  // column norms of P for D = 1
     DEKF_SYNC();
