@@ -117,11 +117,11 @@ struct Timed {  // brackets one launch with events when timing is on
         if (!h->timing) return;
         if (!h->ev_pool.empty()) { a = h->ev_pool.back().first; b = h->ev_pool.back().second; h->ev_pool.pop_back(); }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
-        hipEventRecord(a, h->stream);
+        (void)hipEventRecord(a, h->stream);
     }
     ~Timed() {
         if (!a) return;
-        hipEventRecord(b, h->stream);
+        (void)hipEventRecord(b, h->stream);
         h->ev[cls].push_back({a, b});
     }
 };
@@ -192,7 +192,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
         return fail(DEKF_ERR_INVALID, "window too large: ADMM iterates exceed the 160 KiB LDS of one CU");
     }
     if (h->lds_solve > 64 * 1024)
-        hipFuncSetAttribute((const void*)h->solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
+        (void)hipFuncSetAttribute((const void*)h->solve_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve);
     int per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h->solve_kernel, DEKF_SOLVE_THREADS, h->lds_solve) != hipSuccess || per_cu < 1)
         per_cu = 1;
@@ -220,14 +220,14 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
 
 dekf_status dekf_destroy(dekf_handle h) {
     if (!h) return DEKF_OK;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
     if (h->comm) rccl_destroy(h->comm);
-    for (auto& v : h->ev) for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    for (auto& pr : h->ev_pool) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
-    for (void* q : h->blocks) hipFree(q);
-    if (h->stage) hipFree(h->stage);
-    if (h->own_stream) hipStreamDestroy(h->stream);
+    for (auto& v : h->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (auto& pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
+    for (void* q : h->blocks) (void)hipFree(q);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->own_stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return DEKF_OK;
 }
