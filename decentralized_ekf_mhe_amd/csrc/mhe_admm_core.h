@@ -326,7 +326,7 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
 // Every LDS load of the block is issued before the first store (the compiler cannot move a load
 // across a store through another pointer, so interleaving them serialises one LDS round trip per row).
 template <int NR, bool EQ, class Q, class SM>
-DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM& S, double alpha, double sigma) {
+DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM& S, double alpha, double sigma, bool has_hi = true) {
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
     double e[NR], cf[NR], c2[NR], t0[NR], x0[NR], z0[NR], y0[NR], lo[NR], hi[NR];
 #pragma unroll
@@ -340,11 +340,12 @@ DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM&
         z0[j] = q.z[r];
         y0[j] = q.y[r];
         lo[j] = q.lo[r];
-        hi[j] = EQ ? 0.0 : q.hi[r - q.ix.rvb];
+        hi[j] = EQ ? 0.0 : q.hi[has_hi ? r - q.ix.rvb : 0];  // !has_hi: an equality block on the generic path (hi = lo below)
     }
     double v[NR], sl[NR], xn[NR], zn[NR], yn[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
+        if (!EQ && !has_hi) hi[j] = lo[j];
         c2[j] *= e[j];
         v[j] = cf[j] * ar[j];
     }
@@ -419,6 +420,22 @@ struct SymMat {  // symmetric N x N, packed upper triangle, held in registers
         }
     }
 };
+// 3x3 slack-block inverse of a VO block (packed symmetric) or of a Dyn bias block (diagonal) through ONE code
+// path, so that both kinds share a tile: the diagonal goes into the packed slots 0, 3, 5, the rest is zero
+struct VoOrBiasMat {
+    double p[6];
+    DEKF_FN VoOrBiasMat(const double* sc6, const double* diag3, bool vo) {
+        const double* sp = vo ? sc6 : diag3;
+        const double s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5];  // in bounds for both
+        p[0] = s0; p[1] = vo ? s1 : 0.0; p[2] = vo ? s2 : 0.0;
+        p[3] = vo ? s3 : s1; p[4] = vo ? s4 : 0.0; p[5] = vo ? s5 : s2;
+    }
+    DEKF_FN void apply(const double* in, double* out) const {
+        out[0] = p[0] * in[0] + p[1] * in[1] + p[2] * in[2];
+        out[1] = p[1] * in[0] + p[3] * in[1] + p[4] * in[2];
+        out[2] = p[2] * in[0] + p[4] * in[1] + p[5] * in[2];
+    }
+};
 struct DiagMat3 {
     double p[3];
     DEKF_FN explicit DiagMat3(const double* s) {
@@ -473,30 +490,24 @@ struct DynPairMat {
 #endif
 
 // RESTART = false: one iteration's row work (needs xd from phase_sweeps).  RESTART = true: rebuild
-// cf, t, w from (x, z, y).  Tiles: [Meas leg blocks][Dyn p+v 6-blocks][VO][Dyn bias].
+// cf, t, w from (x, z, y).  Tiles: [Meas leg blocks][Dyn p+v 6-blocks][VO and Dyn bias blocks].
 template <bool RESTART, class Q>
 DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
     constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
-    const int ntm = (nmeas + 63) >> 6, ntd = (K1 + 63) >> 6;
+    const int ntm = (nmeas + 63) >> 6;
 #if DEKF_DEVICE_BUILD
     const int ntp = (2 * K1 + 63) >> 6;  // Dyn p+v blocks: a lane pair per block
 #else
-    const int ntp = ntd;                 // host build: one (sequential) lane per 6-block
+    const int ntp = (K1 + 63) >> 6;      // host build: one (sequential) lane per 6-block
 #endif
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
     const double *xd = q.xd, *E = q.E;
-    // Tile order [Meas | Dyn pairs | VO | (empty) | bias]: the bias tiles (cheapest kind) start on the wavefront
-    // that got the LAST Meas tile (the least full one) instead of piling onto wavefront 0 behind a full Meas
-    // tile — measured 1 % of the whole solve on Go1 (tools/ab_bench.sh).
-    const int nw = wave_count();
-    const int npad = (((ntm - 1) - (ntm + ntp + ntd)) % nw + nw) % nw;
-    const int tbias = ntm + ntp + ntd + npad;
-    wtiles(tbias + ntd, [&](int tile, int lane) {
-        if (tile >= ntm + ntp + ntd) {
-            if (tile < tbias) return;
-            tile -= npad;
-        }
+    // Tile order [Meas | Dyn | VO + bias].  VO blocks and Dyn bias blocks share tiles and ONE code path (3 rows,
+    // a 3x3 symmetric slack-block inverse that is diagonal for the bias rows, the generic projection):
+    // as separate kinds they were two tile bodies run one after the other by some wavefront.
+    const int nvb = (2 * K1 + 63) >> 6;
+    wtiles(ntm + ntp + nvb, [&](int tile, int lane) {
         if (tile < ntm) {  // Meas: leg block (k, leg), A_meas = [0 I 0]
             const int e = tile * 64 + lane;
             if (e >= nmeas) return;
@@ -533,11 +544,10 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             return;
         }
 #endif
-        const int kind = td < ntp ? 0 : (td < ntp + ntd ? 1 : 2);
-        const int k = (td - (kind == 0 ? 0 : ntp + (kind - 1) * ntd)) * 64 + lane;
-        if (k >= K1) return;
-        const double* xk = xd + 9 * k;
-        if (kind == 0) {  // Dyn position + velocity rows: 6x6 slack block (host build)
+        if (td < ntp) {  // Dyn position + velocity rows: 6x6 slack block on one lane (host build)
+            const int k = td * 64 + lane;
+            if (k >= K1) return;
+            const double* xk = xd + 9 * k;
             const int r0 = q.ix.rd(k, 0), sv0 = k * SV + 9 + NM;
             const SymMat<6> S(q.Sw + k * SWS);
             if (RESTART) { row_block_restart<6, true>(q, r0, sv0, S, sigma); return; }
@@ -550,22 +560,21 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
                 ar[3 + a] = E[r0 + 3 + a] * (xk[3 + a] - dt * rb - xk[12 + a]);
             }
             row_block_update<6, true>(q, r0, sv0, ar, S, alpha, sigma);
-        } else if (kind == 1) {  // VO rows: +-inf box or equality, per-row rho
-            const int r0 = q.ix.rv(k, 0), sv0 = k * SV + 18 + NM;
-            const SymMat<3> S(q.Sc + k * 6);
+            return;
+        }
+        {   // VO rows (+-inf box or equality, per-row rho) and Dyn bias rows (equalities, diagonal slack block)
+            const int idx = (td - ntp) * 64 + lane;
+            if (idx >= 2 * K1) return;
+            const bool vo = idx < K1;
+            const int k = vo ? idx : idx - K1, o = vo ? 0 : 6;
+            const int r0 = vo ? q.ix.rv(k, 0) : q.ix.rd(k, 6), sv0 = k * SV + (vo ? 18 + NM : 9 + NM + 6);
+            const VoOrBiasMat S(q.Sc + k * 6, q.Sw + k * SWS + 21, vo);
             if (RESTART) { row_block_restart<3, false>(q, r0, sv0, S, sigma); return; }
+            const double* xk = xd + 9 * k;
             double ar[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[a] - xk[9 + a]);
-            row_block_update<3, false>(q, r0, sv0, ar, S, alpha, sigma);
-        } else {  // Dyn bias rows: diagonal slack block
-            const int r0 = q.ix.rd(k, 6), sv0 = k * SV + 9 + NM + 6;
-            const DiagMat3 S(q.Sw + k * SWS + 21);
-            if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
-            double ar[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[6 + a] - xk[15 + a]);
-            row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma);
+            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[o + a] - xk[9 + o + a]);
+            row_block_update<3, false>(q, r0, sv0, ar, S, alpha, sigma, vo);
         }
     });
     DEKF_SYNC();
