@@ -65,12 +65,6 @@ DEKF_FN double symget(const double* s, int i, int j, int n) {
     return s[(lo * (2 * n - 1 - lo)) / 2 + hi];
 }
 
-// the same element for a RUN-TIME row i and a COMPILE-TIME column t: one select between two affine
-// forms (t < i: column i of row t, a constant plus i; else row i, symrow_start(i) plus a constant)
-// instead of min / max / multiply per element
-DEKF_FN int symrow_start(int i, int n) { return (i * (2 * n - 1 - i)) / 2; }
-DEKF_FN int symrow_idx(int i, int row_start, int t, int n) { return t < i ? (t * (2 * n - 1 - t)) / 2 + i : row_start + t; }
-
 // variable / row indices of the QP in the reference's own order
 // (x_k v_k w_k c_k per step; Meas_k Dyn_k VO_k per step — SURVEY.md Appendix A)
 struct Idx {

@@ -436,17 +436,6 @@ struct VoOrBiasMat {
         out[2] = p[2] * in[0] + p[4] * in[1] + p[5] * in[2];
     }
 };
-struct DiagMat3 {
-    double p[3];
-    DEKF_FN explicit DiagMat3(const double* s) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) p[i] = s[i];
-    }
-    DEKF_FN void apply(const double* in, double* out) const {
-#pragma unroll
-        for (int i = 0; i < 3; ++i) out[i] = p[i] * in[i];
-    }
-};
 
 #if DEKF_DEVICE_BUILD
 // The Dyn 6x6 slack block on a PAIR of adjacent lanes (even lane: position rows, odd lane: velocity

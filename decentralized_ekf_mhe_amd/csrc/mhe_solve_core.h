@@ -136,124 +136,14 @@ struct SolveCtx {
         else if (r[Rec::VOF] != 0.0) lb = ub = r[Rec::VOB + o];
         else { lb = -OSQP_INFTY; ub = OSQP_INFTY; }
     }
-    DEKF_FN void dec_var(int i, int& k, int& kind, int& o) const {
-        k = i / ix.SV;
-        int q = i - k * ix.SV;
-        if (q < 9) { kind = 0; o = q; }
-        else if (q < 9 + ix.nm) { kind = 1; o = q - 9; }
-        else if (q < 18 + ix.nm) { kind = 2; o = q - 9 - ix.nm; }
-        else { kind = 3; o = q - 18 - ix.nm; }
-    }
     DEKF_FN void dec_row(int r, int& k, int& kind, int& o) const {
         if (r < ix.rdb) { kind = 0; k = r / ix.nm; o = r - k * ix.nm; }
         else if (r < ix.rvb) { kind = 1; int t = r - ix.rdb; k = t / 9; o = t - 9 * k; }
         else { kind = 2; int t = r - ix.rvb; k = t / 3; o = t - 3 * k; }
     }
-    // row that slack variable (k, kind 1..3, o) lives in, and vice versa
-    DEKF_FN int slack_row(int k, int kind, int o) const { return kind == 1 ? ix.rm(k, o) : (kind == 2 ? ix.rd(k, o) : ix.rv(k, o)); }
+    // slack variable of row (k, kind, o)
     DEKF_FN int row_slack(int k, int kind, int o) const { return kind == 0 ? ix.v(k, o) : (kind == 1 ? ix.w(k, o) : ix.c(k, o)); }
 
-    // (scaled A restricted to the x blocks)' * vec, component x_k[j]
-    DEKF_FN double gather_x(int k, int j, const double* vec) const {
-        double dj = D[ix.x(k, j)];
-        double acc = 0.0;
-        if (j >= 3 && j < 6)
-            for (int leg = 0; leg < L; ++leg) { int r = ix.rm(k, 3 * leg + j - 3); acc += E[r] * vec[r]; }
-        if (k < K - 1) {
-            for (int rr = 0; rr < 9; ++rr) {
-                double a = adyn(k, rr, j);
-                if (a != 0.0) { int r = ix.rd(k, rr); acc += E[r] * a * vec[r]; }
-            }
-            if (j < 3) { int r = ix.rv(k, j); acc += E[r] * vec[r]; }
-        }
-        if (k > 0) {
-            int r = ix.rd(k - 1, j);
-            acc -= E[r] * vec[r];
-            if (j < 3) { int r2 = ix.rv(k - 1, j); acc -= E[r2] * vec[r2]; }
-        }
-        return acc * dj;
-    }
-    // (scaled A restricted to the x blocks) * xv, row (k, kind, o); xv(k, j) returns x_k[j]
-    template <class XF>
-    DEKF_FN double row_dot_x(int k, int kind, int o, XF xv) const {
-        double acc;
-        if (kind == 0) {
-            acc = D[ix.x(k, 3 + o % 3)] * xv(k, 3 + o % 3);
-        } else if (kind == 1) {
-            acc = 0.0;
-            for (int j = 0; j < 9; ++j) {
-                double a = adyn(k, o, j);
-                if (a != 0.0) acc += a * D[ix.x(k, j)] * xv(k, j);
-            }
-            acc -= D[ix.x(k + 1, o)] * xv(k + 1, o);
-        } else {
-            acc = D[ix.x(k, o)] * xv(k, o) - D[ix.x(k + 1, o)] * xv(k + 1, o);
-        }
-        int r = kind == 0 ? ix.rm(k, o) : (kind == 1 ? ix.rd(k, o) : ix.rv(k, o));
-        return E[r] * acc;
-    }
-    // (P_scaled x)_i for variable i, or the inf-norm of column i of P_scaled (reads HBM records)
-    DEKF_FN double p_apply(int i, const double* xv, bool norm_only) const {
-        int k, kind, o;
-        dec_var(i, k, kind, o);
-        double di = D[i];
-        double acc = 0.0;
-        auto term = [&](double pij, int i2) {
-            double v = cc * di * pij * D[i2];
-            if (norm_only) acc = dmax(acc, fabs(v));
-            else acc += v * xv[i2];
-        };
-        if (kind == 0) {
-            if (k == 0)
-                for (int t = 0; t < 9; ++t) term(o <= t ? Mp[9 * o + t] : Mp[9 * t + o], ix.x(0, t));
-        } else if (kind == 1) {
-            int leg = o / 3, a = o - 3 * leg;
-            const double* q6 = rec(k) + Rec::qm(ix.nm) + 6 * leg;
-            for (int t = 0; t < 3; ++t) term(symget(q6, a, t, 3), ix.v(k, 3 * leg + t));
-        } else if (kind == 2) {
-            if (o < 6) {
-                const double* q21 = rec(k) + Rec::QD;
-                for (int t = 0; t < 6; ++t) term(symget(q21, o, t, 6), ix.w(k, t));
-            } else term(c.Q_bias_dt2[o - 6], i);
-        } else {
-            const double* q6 = rec(k) + Rec::QC;
-            for (int t = 0; t < 3; ++t) term(symget(q6, o, t, 3), ix.c(k, t));
-        }
-        return acc;
-    }
-    // inf-norm of column i of the scaled A
-    DEKF_FN double a_colnorm(int i) const {
-        int k, kind, o;
-        dec_var(i, k, kind, o);
-        double di = D[i];
-        if (kind != 0) return E[slack_row(k, kind, o)] * di;
-        double acc = 0.0;
-        if (o >= 3 && o < 6)
-            for (int leg = 0; leg < L; ++leg) acc = dmax(acc, E[ix.rm(k, 3 * leg + o - 3)]);
-        if (k < K - 1) {
-            for (int rr = 0; rr < 9; ++rr) acc = dmax(acc, E[ix.rd(k, rr)] * fabs(adyn(k, rr, o)));
-            if (o < 3) acc = dmax(acc, E[ix.rv(k, o)]);
-        }
-        if (k > 0) {
-            acc = dmax(acc, E[ix.rd(k - 1, o)]);
-            if (o < 3) acc = dmax(acc, E[ix.rv(k - 1, o)]);
-        }
-        return acc * di;
-    }
-    // inf-norm of row r of the scaled A
-    DEKF_FN double a_rownorm(int r) const {
-        int k, kind, o;
-        dec_row(r, k, kind, o);
-        double acc = D[row_slack(k, kind, o)];
-        if (kind == 0) acc = dmax(acc, D[ix.x(k, 3 + o % 3)]);
-        else if (kind == 1) {
-            for (int j = 0; j < 9; ++j) acc = dmax(acc, fabs(adyn(k, o, j)) * D[ix.x(k, j)]);
-            acc = dmax(acc, D[ix.x(k + 1, o)]);
-        } else {
-            acc = dmax(acc, dmax(D[ix.x(k, o)], D[ix.x(k + 1, o)]));
-        }
-        return acc * E[r];
-    }
 };
 
 DEKF_FN double limit_scaling(double v) {
