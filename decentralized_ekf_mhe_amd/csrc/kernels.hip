@@ -2,9 +2,10 @@
 //   k_ekf_tick        one lane per instance              (ekf_core.h)
 //   k_mhe_initialize  one wavefront per instance         (mhe_assemble_core.h)
 //   k_mhe_assemble    one wavefront per instance         (mhe_assemble_core.h)
-//   k_mhe_solve_*     persistent one-wave workgroups, grid-stride over instances; each
+//   k_mhe_solve_*     persistent four-wavefront workgroups, grid-stride over instances; each
 //                     workgroup owns one scratch slab in HBM, so a slab is only ever touched
-//                     from one XCD (its L2 is the only one that caches it)  (mhe_solve_core.h)
+//                     from one XCD (its L2 is the only one that caches it)
+//                     (mhe_solve_core.h, mhe_admm_core.h)
 //   k_kf_*            KF alternative                      (kf_core.h)
 //   k_latch_vo        masked VO latch (robotSub::vo_callback for a batch)
 #include <hip/hip_runtime.h>

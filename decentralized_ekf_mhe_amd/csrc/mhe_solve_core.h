@@ -1,4 +1,6 @@
-// mhe_solve_core.h — per-instance (one wavefront) OSQP-style ADMM solve of the MHE window QP.
+// mhe_solve_core.h — per-instance (one workgroup of four wavefronts) OSQP-style ADMM solve of the MHE
+// window QP: Ruiz scaling, factorisation and the solve driver; the phases of an ADMM iteration and the
+// residual norms are in mhe_admm_core.h.
 //
 // Replaces  MHEproblem::initQP + solveQP + getsolution  (src/decentral_legged_est/src/MheSrb.cpp:
 // 272-349, 715-723), i.e. osqp_setup + osqp_solve on
@@ -15,7 +17,8 @@
 //     (P + sigma I + A' diag(rho) A) xt = sigma x - q + A'(diag(rho) z - y),   zt = A xt
 // (OSQP's KKT system with nu eliminated) therefore reduces, after eliminating the slack blocks
 // (3x3 per leg, 6x6+3 for w, 3x3 for c), to a block-tridiagonal SPD system in the x_k with
-// 9x9 blocks — a fixed-interval smoother — solved by block LDL': S_k^-1 and W_k = C_k S_k^-1
+// 9x9 blocks — a fixed-interval smoother — solved by a TWO-SIDED block LDL' (blocks eliminated from both
+// ends of the window towards block (K-1)/2): S_k^-1 (full 9x9) and W_k = C_k S_k^-1 / W^_k = C_k' S_{k+1}^-1
 // are the "banded KKT factor", refreshed whenever rho changes.
 //
 // Memory (SolveMem): when it fits 2 workgroups per CU (Go1/Cassie at N = 20: <= 80 KiB) the
