@@ -86,14 +86,35 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
 
 // ---------------------------------------------------------------- S: block-tridiagonal solve
 
+#if DEKF_DEVICE_BUILD
+// rhs - W v for the chain: lane i < 9 holds row i of W in w[0..8] and component i of v; component t of v
+// is taken straight from lane t of the 16-lane row by the FMA itself (v_fmac_f64_dpp ... row_newbcast:t,
+// gfx950): 9 instructions instead of 18 v_readlane + 9 FMA.  Alone on a CU the step is 169 against 204
+// cycles (tools/probes/dpp_chain_probe.hip); in the kernel, where the legs share their SIMDs with the
+// other resident workgroup, halving the instruction count of the step is worth 10 % of the whole solve.
+// Inline assembly gets no hazard handling from the compiler: a VALU write of v followed by a DPP read of
+// it needs two wait states, hence the s_nop inside the first statement (which has v as an input, so the
+// nop cannot be scheduled before the instruction that produces v).
+DEKF_FN double chain_matvec_dpp(double v, const double* w, double rhs) {
+    double a0 = rhs, a1 = 0.0, a2 = 0.0;
+#define DEKF_DPP_FMAC(pre, acc, wt, T) \
+    asm volatile(pre "v_fmac_f64_dpp %0, %1, -%2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(v), "v"(wt))
+    DEKF_DPP_FMAC("s_nop 1\n\t", a0, w[0], 0); DEKF_DPP_FMAC("", a1, w[1], 1); DEKF_DPP_FMAC("", a2, w[2], 2);
+    DEKF_DPP_FMAC("", a0, w[3], 3); DEKF_DPP_FMAC("", a1, w[4], 4); DEKF_DPP_FMAC("", a2, w[5], 5);
+    DEKF_DPP_FMAC("", a0, w[6], 6); DEKF_DPP_FMAC("", a1, w[7], 7); DEKF_DPP_FMAC("", a2, w[8], 8);
+#undef DEKF_DPP_FMAC
+    return a0 + (a1 + a2);
+}
+#endif
+
 // One leg of the two-sided block-tridiagonal solve: a chain of `steps` dependent 9x9 mat-vecs
 //     v_new = rhs[k_new] - M v_prev,   k_new = k_prev + dk,   M = Wk[k_new + wofs] (TR: transposed)
 // starting from the vector stored in xs at block k0.  Forward legs (BWD = false) read rhs from xs
 // and overwrite it with f; outward legs (BWD = true) read rhs = g from xd, and leave
 // x <- alpha u + (1-alpha) x (the ADMM relaxation of the x blocks) and xd = D .* u.
-// Device: the running vector sits in registers of lanes 0..8 of the calling wavefront and is
-// broadcast with v_readlane (18 per step), so the dependent chain never touches LDS or a barrier;
-// all 64 lanes execute it (lanes >= 9 mirror lane 8 and never store).  Host build: plain loops.
+// Device: the running vector sits in registers of lanes 0..8 of the calling wavefront and is broadcast
+// inside the FMAs (chain_matvec_dpp), so the dependent chain never touches LDS or a barrier; all 64 lanes
+// execute it (lanes >= 9 mirror lane 8 and never store).  Host build: plain loops.
 template <bool TR, bool BWD, int STEPS = 0, class Q>
 DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
@@ -118,14 +139,7 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
     auto step = [&](const Ops& c, Ops& n, int s) {
         const int kn = k0 + s * dk;
         if (s < steps) load(kn + dk, n);
-        double vt[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) vt[t] = readlane_f64(v, t);
-        double a0 = c.rhs - c.w[0] * vt[0];   // 5 dependent f64 operations per step
-        double a1 = c.w[1] * vt[1], a2 = c.w[2] * vt[2];
-        a0 -= c.w[3] * vt[3]; a1 += c.w[4] * vt[4]; a2 += c.w[5] * vt[5];
-        a0 -= c.w[6] * vt[6]; a1 += c.w[7] * vt[7]; a2 += c.w[8] * vt[8];
-        v = a0 - (a1 + a2);
+        v = chain_matvec_dpp(v, c.w, c.rhs);  // 5 dependent f64 operations per step
         if (act) {
             if (BWD) {
                 xd[9 * kn + i] = c.dsc * v;
@@ -146,14 +160,7 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
             const int kn = k0 + s * dk;
             const Ops& c = o[(s - 1) & 1];
             if (s < STEPS) load(kn + dk, o[s & 1]);
-            double vt[9];
-#pragma unroll
-            for (int t = 0; t < 9; ++t) vt[t] = readlane_f64(v, t);
-            double a0 = c.rhs - c.w[0] * vt[0];
-            double a1 = c.w[1] * vt[1], a2 = c.w[2] * vt[2];
-            a0 -= c.w[3] * vt[3]; a1 += c.w[4] * vt[4]; a2 += c.w[5] * vt[5];
-            a0 -= c.w[6] * vt[6]; a1 += c.w[7] * vt[7]; a2 += c.w[8] * vt[8];
-            v = a0 - (a1 + a2);
+            v = chain_matvec_dpp(v, c.w, c.rhs);
             if (act) {
                 if (BWD) {
                     xd[9 * kn + i] = c.dsc * v;
