@@ -225,15 +225,10 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
         double a2 = W[2] * fh[2] + W[5] * fh[5] + W[8] * fh[8];
         f -= a0 + a1 + a2;
     }
-    double s[9], ft[9];
+    double s[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) s[t] = Si[9 * i + t];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) ft[t] = readlane_f64(f, t);
-    double a0 = s[0] * ft[0] + s[3] * ft[3] + s[6] * ft[6];
-    double a1 = s[1] * ft[1] + s[4] * ft[4] + s[7] * ft[7];
-    double a2 = s[2] * ft[2] + s[5] * ft[5] + s[8] * ft[8];
-    const double u = a0 + a1 + a2;
+    const double u = -chain_matvec_dpp(f, s, 0.0);  // S_m^-1 f_m, f_m broadcast inside the FMAs
     if (lane < 9) {
         const int xi = mid * SV + i;
         xs[9 * mid + i] = u;

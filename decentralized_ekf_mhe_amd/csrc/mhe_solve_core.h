@@ -670,22 +670,31 @@ DEKF_FN bool solve_factor(Q& q) {
 #pragma unroll
         for (int i = 0; i < 9; ++i) a[i] = ts[9 * i + j];
         bool good = true;
-#pragma unroll
-        for (int pv = 0; pv < 9; ++pv) {
-            double col[9];
-#pragma unroll
-            for (int i = 0; i < 9; ++i) col[i] = readlane_f64(a[i], pv);
-            const double piv = col[pv];
-            good = good && (fabs(piv) > 0.0) && (fabs(piv) < 1e300);
-            const double d = rcp_fast(piv);
-            const bool own = lane == pv;
-            const double m = a[pv] * d;
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                if (i == pv) a[i] = own ? d : m;
-                else a[i] = own ? -col[i] * d : a[i] - col[i] * m;
-            }
+        // pivot pv: every lane needs column pv (lane pv's registers).  The pivot itself goes through one
+        // v_readlane pair; the other eight entries are consumed straight from lane pv by the update FMA
+        // (v_fmac_f64_dpp row_newbcast:pv), with base = 0, multiplier = d on lane pv itself, whose new
+        // column is -col * d.  Two wait states between the VALU write of a[i] and its DPP read: the s_nop.
+#define DEKF_GJ_DPP(acc, src, mul, PV) \
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:" #PV " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul))
+#define DEKF_GJ_PIVOT(PV)                                                        \
+        {                                                                        \
+            const double piv = readlane_f64(a[PV], PV);                          \
+            good = good && (fabs(piv) > 0.0) && (fabs(piv) < 1e300);             \
+            const double d = rcp_fast(piv);                                      \
+            const bool own = lane == PV;                                         \
+            const double m = own ? d : a[PV] * d;                                \
+            _Pragma("unroll") for (int i = 0; i < 9; ++i) {                      \
+                if (i == PV) continue;                                           \
+                double t = own ? 0.0 : a[i];                                     \
+                DEKF_GJ_DPP(t, a[i], m, PV);                                     \
+                a[i] = t;                                                        \
+            }                                                                    \
+            a[PV] = m;                                                           \
         }
+        DEKF_GJ_PIVOT(0) DEKF_GJ_PIVOT(1) DEKF_GJ_PIVOT(2) DEKF_GJ_PIVOT(3) DEKF_GJ_PIVOT(4)
+        DEKF_GJ_PIVOT(5) DEKF_GJ_PIVOT(6) DEKF_GJ_PIVOT(7) DEKF_GJ_PIVOT(8)
+#undef DEKF_GJ_PIVOT
+#undef DEKF_GJ_DPP
         wave_sync();  // every lane has read its column of S
         if (lane < 9) {
             // column j of the inverse: to the scratch copy for the W product and to S^-1[k] (full 9x9: a row is
