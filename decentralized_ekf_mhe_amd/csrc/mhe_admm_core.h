@@ -78,7 +78,12 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
         double g;
         if (kind == 0) g = gather_pcol(q, k, a, w);
         else if (kind == 1) g = gather_vcol(q, k, a, w);
-        else g = gather_bcol(q, k, a, w);
+        else {  // gather_bcol with R' (dt^2/2 w_p + dt w_v) already formed by the row phase (q.gb)
+            const bool hn = k < K - 1, hp = k > 0;
+            const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
+            const double n0 = w(q.ix.rd(kn, 6 + a)), n1 = q.gb[3 * kn + a], p0 = w(q.ix.rd(kp, 6 + a));
+            g = (hn ? n0 - n1 : 0.0) - (hp ? p0 : 0.0);
+        }
         q.xs[9 * k + j] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
     });
     DEKF_SYNC();
@@ -328,7 +333,8 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
 // Every LDS load of the block is issued before the first store (the compiler cannot move a load
 // across a store through another pointer, so interleaving them serialises one LDS round trip per row).
 template <int NR, bool EQ, class Q, class SM>
-DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM& S, double alpha, double sigma, bool has_hi = true) {
+DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM& S, double alpha, double sigma, bool has_hi = true,
+                              double* wout = nullptr) {
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
     double e[NR], cf[NR], c2[NR], t0[NR], x0[NR], z0[NR], y0[NR], lo[NR], hi[NR];
 #pragma unroll
@@ -378,12 +384,14 @@ DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM&
         q.y[r] = yn[j];
         q.z[r] = zn[j];
         q.zt[r] = t[j];
-        q.at[r] = e[j] * (un[j] + cf[j] * t[j]);
+        const double wj = e[j] * (un[j] + cf[j] * t[j]);
+        q.at[r] = wj;
+        if (wout) wout[j] = wj;
     }
 }
 // the same block from (x, z, y) alone: after a (re)factorisation, and for the cold start
 template <int NR, bool EQ, class Q, class SM>
-DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma) {
+DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma, double* wout = nullptr) {
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
     double e[NR], cf[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll
@@ -401,7 +409,9 @@ DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma)
     for (int j = 0; j < NR; ++j) {
         q.cf[r0 + j] = cf[j];
         q.zt[r0 + j] = t[j];
-        q.at[r0 + j] = e[j] * (un[j] + cf[j] * t[j]);
+        const double wj = e[j] * (un[j] + cf[j] * t[j]);
+        q.at[r0 + j] = wj;
+        if (wout) wout[j] = wj;
     }
 }
 
@@ -520,18 +530,35 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             if (k >= K1) return;
             const int r0 = q.ix.rd(k, vel ? 3 : 0), sv0 = k * SV + 9 + NM + (vel ? 3 : 0);
             const DynPairMat S(q.Sw + k * SWS, vel);
-            if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
-            const double* xk = xd + 9 * k;
             const double* R = q.R + 9 * k;
-            const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
-            const int o = vel ? 3 : 0;
-            double ar[3];
+            double Rk[9], wo[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double rb = R[3 * a] * xk[6] + R[3 * a + 1] * xk[7] + R[3 * a + 2] * xk[8];
-                ar[a] = E[r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+            for (int t = 0; t < 9; ++t) Rk[t] = R[t];
+            if (RESTART) row_block_restart<3, true>(q, r0, sv0, S, sigma, wo);
+            else {
+                const double* xk = xd + 9 * k;
+                const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
+                const int o = vel ? 3 : 0;
+                double ar[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const double rb = Rk[3 * a] * xk[6] + Rk[3 * a + 1] * xk[7] + Rk[3 * a + 2] * xk[8];
+                    ar[a] = E[r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+                }
+                row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma, true, wo);
             }
-            row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma);
+            // what the bias columns of x_k gather from these six rows: R' (dt^2/2 w_p + dt w_v), formed here where
+            // w_p and w_v are in registers (the x-column phase then reads 3 values instead of 6 w and 9 R)
+            double u[3];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const double pw = pair_swap(wo[r]);
+                u[r] = vel ? hdt2 * pw + dt * wo[r] : hdt2 * wo[r] + dt * pw;
+            }
+            if (!vel) {
+#pragma unroll
+                for (int a = 0; a < 3; ++a) q.gb[3 * k + a] = Rk[a] * u[0] + Rk[3 + a] * u[1] + Rk[6 + a] * u[2];
+            }
             return;
         }
 #endif
@@ -541,16 +568,24 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             const double* xk = xd + 9 * k;
             const int r0 = q.ix.rd(k, 0), sv0 = k * SV + 9 + NM;
             const SymMat<6> S(q.Sw + k * SWS);
-            if (RESTART) { row_block_restart<6, true>(q, r0, sv0, S, sigma); return; }
             const double* R = q.R + 9 * k;
-            double ar[6];
+            double wo[6];
+            if (RESTART) row_block_restart<6, true>(q, r0, sv0, S, sigma, wo);
+            else {
+                double ar[6];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                const double rb = R[3 * a] * xk[6] + R[3 * a + 1] * xk[7] + R[3 * a + 2] * xk[8];
-                ar[a] = E[r0 + a] * (xk[a] + dt * xk[3 + a] - hdt2 * rb - xk[9 + a]);
-                ar[3 + a] = E[r0 + 3 + a] * (xk[3 + a] - dt * rb - xk[12 + a]);
+                for (int a = 0; a < 3; ++a) {
+                    const double rb = R[3 * a] * xk[6] + R[3 * a + 1] * xk[7] + R[3 * a + 2] * xk[8];
+                    ar[a] = E[r0 + a] * (xk[a] + dt * xk[3 + a] - hdt2 * rb - xk[9 + a]);
+                    ar[3 + a] = E[r0 + 3 + a] * (xk[3 + a] - dt * rb - xk[12 + a]);
+                }
+                row_block_update<6, true>(q, r0, sv0, ar, S, alpha, sigma, true, wo);
             }
-            row_block_update<6, true>(q, r0, sv0, ar, S, alpha, sigma);
+            for (int a = 0; a < 3; ++a) {
+                double g = 0.0;
+                for (int r = 0; r < 3; ++r) g += R[3 * r + a] * (hdt2 * wo[r] + dt * wo[3 + r]);
+                q.gb[3 * k + a] = g;
+            }
             return;
         }
         {   // VO rows (+-inf box or equality, per-row rho) and Dyn bias rows (equalities, diagonal slack block)

@@ -107,6 +107,7 @@ struct SolveCtx {
     // LDS always
     double *x, *z, *y, *xt, *zt, *at, *xs, *xd, *tmp;
     double* cf;  // per row rho E D (aliases xt, which only the factorisation uses otherwise)
+    double* gb;  // per step R' (dt^2/2 w_p + dt w_v): the Dyn rows' contribution to the bias columns (tail of xt)
     // LDS or HBM scratch
     double *D, *E, *lo, *hi, *Sv, *Sw, *Sc, *Sinv, *Wk, *R;
     // factor-time temporaries
@@ -825,6 +826,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         q.y = p; p += lay.m_pad;
         q.xt = p; p += lay.n_pad;
         q.cf = q.xt;
+        q.gb = q.xt + lay.m_pad;  // 3 (N - 1) <= n_pad - m_pad = 9 N
         q.zt = p; p += lay.m_pad;
         q.at = p; p += lay.m_pad;
         q.xs = p; p += 9 * NH;

@@ -44,7 +44,7 @@ __device__ __forceinline__ double step_readlane(double v, const double* w, doubl
     return a0 + (a1 + a2);
 }
 
-template <int DPP, int STEPS>
+template <int DPP, int STEPS, bool ROW0 = false>
 __global__ void __launch_bounds__(256) chain(double* out, long long* cyc, int reps) {
     extern __shared__ double lds[];
     double* Wk = lds;
@@ -65,6 +65,7 @@ __global__ void __launch_bounds__(256) chain(double* out, long long* cyc, int re
         o.rhs = x[9 * s + i];
     };
     long long t0 = clock64();
+    if (!ROW0 || lane < 16)  // ROW0: only lanes 0..15 are in EXEC during the chain
     for (int r = 0; r < reps; ++r) {
         Ops o[2];
         load(1, o[0]);
@@ -99,6 +100,16 @@ int main() {
             printf("waves %d  %-10s %.1f cycles per step   v[0..2] = %.15g %.15g %.15g\n", nw, dpp == 1 ? "dpp fmac" : (dpp == 2 ? "dpp x9" : "readlane"), (double)hc[0] / 2000.0,
                    h[dpp][0], h[dpp][1], h[dpp][2]);
         }
+    for (int dpp = 0; dpp < 2; ++dpp) {
+        for (int rep = 0; rep < 2; ++rep) {
+            if (dpp) chain<1, 10, true><<<1, 64, lds>>>(d, c, 200);
+            else chain<0, 10, true><<<1, 64, lds>>>(d, c, 200);
+            (void)hipDeviceSynchronize();
+        }
+        long long hc[4];
+        (void)hipMemcpy(hc, c, 32, hipMemcpyDeviceToHost);
+        printf("EXEC = lanes 0..15 only   %-10s %.1f cycles per step\n", dpp ? "dpp fmac" : "readlane", (double)hc[0] / 2000.0);
+    }
     double md = 0.0;
     for (int l = 0; l < 9; ++l) md = fmax(md, fabs(h[0][l] - h[1][l]) / (fabs(h[0][l]) + 1e-300));
     printf("max relative difference dpp vs readlane over lanes 0..8: %.3e\n", md);
