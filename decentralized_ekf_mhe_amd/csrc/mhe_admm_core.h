@@ -358,6 +358,10 @@ DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM&
         v[j] = cf[j] * ar[j];
     }
     S.apply(v, sl);
+    // the rows of a VO block switch between the +-inf box and an equality TOGETHER (DecentralEst.cpp:995-1005:
+    // the three bounds of a step are written at once), so rho is decided once per block, from its first row
+    const double rv_blk = EQ ? rho_eq : q.rho_of(lo[0], hi[0]);
+    const double rinv_blk = EQ ? 0.0 : rcp_fast(rv_blk);
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const double sj = t0[j] + sl[j];         // slack solution
@@ -369,8 +373,8 @@ DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM&
             rv = rho_eq;
             zn[j] = lo[j];
         } else {
-            rv = q.rho_of(lo[j], hi[j]);
-            zn[j] = dmin(dmax(zh + rcp_fast(rv) * y0[j], lo[j]), hi[j]);
+            rv = rv_blk;
+            zn[j] = dmin(dmax(zh + rinv_blk * y0[j], lo[j]), hi[j]);
         }
         yn[j] = y0[j] + rv * (zh - zn[j]);
         un[j] = rv * zn[j] - yn[j];
