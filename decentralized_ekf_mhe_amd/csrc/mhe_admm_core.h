@@ -267,17 +267,152 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
 #endif
 }
 
+#if DEKF_DEVICE_BUILD
+// ---- cross-row moves inside one wavefront (gfx950 v_permlane16_swap / v_permlane32_swap); row = 16 lanes
+DEKF_FN double rows23_from_rows01(double v) {  // [r0 r1 r2 r3] -> [r0 r1 r0 r1]
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
+DEKF_FN double row1_from_row0(double v) {  // [r0 r1 r2 r3] -> [r0 r0 r2 r2]
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[0], (int)a[0]);
+}
+DEKF_FN double all_rows_from_row1(double v) {  // [r0 r1 r2 r3] -> [r1 r1 r1 r1]
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // second result: [r1 r1 r3 r3]
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    auto c = __builtin_amdgcn_permlane32_swap(a[1], a[1], false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(b[1], b[1], false, false);
+    return __hiloint2double((int)d[0], (int)c[0]);
+}
+
+// The whole two-sided block-tridiagonal solve on ONE wavefront, its four 16-lane rows in lock step, with no
+// workgroup barrier inside (the two-wavefront form needs three: legs | meeting block + g | legs):
+//   row 0  top leg        f_k = b_k - W_{k-1} f_{k-1}          row 2  g_{k-1} = S_{k-1}^-1 f_{k-1} (top half)
+//   row 1  bottom leg     f^_k = b_k - W^_k f^_{k+1}           row 3  g of the bottom half
+// One DPP-broadcast mat-vec (9 v_fmac_f64_dpp row_newbcast) per step serves all four rows: the rows differ
+// only in the operand matrix a lane has loaded (a row of W or of S^-1).  Rows 2 and 3 take their broadcast
+// source from rows 0 and 1 through v_permlane32_swap.  Then the meeting block in row 0 (f^_{m+1} comes over
+// from row 1 by v_permlane16_swap), u_m is copied to row 1, and rows 0 and 1 substitute outwards.
+// Needs an even compile-time horizon (both forward legs equally long) and the full window.
+template <int NF, class Q>
+DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
+    constexpr int SV = 21 + 3 * Q::LEGS, K = NF, M = mid_block(NF), NOUT = K - 1 - M;
+    static_assert(NF % 2 == 0 && K - 2 - M == M, "equal forward legs");
+    const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15;
+    const int i = li < 9 ? li : 8;
+    const bool act = li < 9, leg = row < 2, top = (row & 1) == 0;
+    double *xs = q.xs, *xd = q.xd, *x = q.x;
+    struct Ops { double w[9], rhs; };
+    // ---------------- forward: step s = 1..M
+    const double* fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
+    const int fstep = top ? 81 : -81;
+    const double* fr = xs + (top ? 9 : 9 * (K - 2)) + i;  // rhs of step 1 (legs)
+    const int rstep = top ? 9 : -9;
+    double* gst = xd + (top ? 0 : 9 * (K - 1)) + i;       // where rows 2, 3 put -g of step 1
+    auto fload = [&](int s, Ops& o) {
+        const double* W = fm + (s - 1) * fstep;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o.w[t] = W[t];
+        const double r = fr[(s - 1) * rstep];
+        o.rhs = leg ? r : 0.0;
+    };
+    double v = xs[(top ? 0 : 9 * (K - 1)) + i];  // f_0 = b_0 / f^_{K-1} = b_{K-1}
+    {
+        Ops o[2];
+        fload(1, o[0]);
+#pragma unroll
+        for (int s = 1; s <= M; ++s) {
+            const Ops& c = o[(s - 1) & 1];
+            if (s < M) fload(s + 1, o[s & 1]);
+            // (letting rows 2, 3 lag one step, so that this cross-row move leaves the dependent path, was
+            // measured 1.4 % slower: one more live register and a select per step)
+            const double src = rows23_from_rows01(v);
+            const double r = chain_matvec_dpp(src, c.w, c.rhs);
+            if (leg) v = r;
+            else if (act) gst[(s - 1) * rstep] = r;  // -g_{s-1} (row 2) / -g_{K-s} (row 3)
+        }
+    }
+    // ---------------- meeting block (row 0) and the last g of the bottom half (row 3)
+    {
+        double w[9];
+        const double* W = row == 0 ? q.Wk + M * 81 + 9 * i : q.Sinv + (M + 1) * 81 + 9 * i;
+        const double z = (row == 0 || row == 3) ? 1.0 : 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = z * W[t];
+        double s9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s9[t] = q.Sinv[M * 81 + 9 * i + t];
+        const double dm = q.D[M * SV + i], xm = x[M * SV + i];
+        const double src = all_rows_from_row1(v);                 // f^_{M+1} everywhere
+        const double r = chain_matvec_dpp(src, w, row == 0 ? v : 0.0);
+        if (row == 3 && act) xd[9 * (M + 1) + i] = r;              // -g_{M+1}
+        const double um = -chain_matvec_dpp(r, s9, 0.0);           // row 0: S_M^-1 (f_M - W^_M f^_{M+1})
+        if (row == 0 && act) {
+            xd[9 * M + i] = dm * um;
+            x[M * SV + i] = alpha * um + (1.0 - alpha) * xm;
+        }
+        v = row1_from_row0(um);                                    // rows 0 and 1 start from u_M
+    }
+    // ---------------- outward: step s = 1..NOUT, row 0 block M - s (s <= M), row 1 block M + s
+    {
+        struct Bops { double w[9], ng, dsc, xo; };
+        auto bload = [&](int s, Bops& o) {
+            int kn = top ? M - s : M + s;
+            kn = kn < 0 ? 0 : kn;  // row 0 has one step less: its last load is a dummy
+            const double* W = q.Wk + (top ? kn : kn - 1) * 81 + i;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
+            o.ng = xd[9 * kn + i];
+            o.dsc = q.D[kn * SV + i];
+            o.xo = x[kn * SV + i];
+        };
+        Bops o[2];
+        bload(1, o[0]);
+#pragma unroll
+        for (int s = 1; s <= NOUT; ++s) {
+            const Bops& c = o[(s - 1) & 1];
+            if (s < NOUT) bload(s + 1, o[s & 1]);
+            const double r = chain_matvec_dpp(v, c.w, -c.ng);
+            const bool live = leg && (!top || s <= M);
+            if (live) v = r;
+            if (live && act) {
+                const int kn = top ? M - s : M + s;
+                xd[9 * kn + i] = c.dsc * r;
+                x[kn * SV + i] = alpha * r + (1.0 - alpha) * c.xo;
+            }
+        }
+    }
+}
+#endif
+
 // In: xs = reduced right-hand side.  Out: x blocks relaxed, xd = D .* (solution).  The
 // factorisation is two-sided (solve_factor 3d): W_k = C_k S_k^-1 in Wk[k] for k < mid,
 // W^_k = C_k' S^_{k+1}^-1 in Wk[k] for k >= mid.
 template <class Q>
 DEKF_FN void phase_sweeps(Q& q, double alpha) {
     const int K = q.K, mid = mid_block(K);
-#if DEKF_DEVICE_BUILD
-    __builtin_amdgcn_s_setprio(3);  // the legs are the critical path and share their SIMDs
-#endif
     constexpr int NF = Q::NFIXED, FM = mid_block(NF);  // full window (steady state) of a compile-time horizon
     const bool fixed = NF >= 4 && K == NF;
+#if DEKF_DEVICE_BUILD
+    if constexpr (NF >= 4 && NF % 2 == 0) {
+        if (fixed) {  // one wavefront, four rows, no barrier inside
+            if (__builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6) == 0) {
+                __builtin_amdgcn_s_setprio(3);
+                sweeps_one_wave<NF>(q, alpha);
+                __builtin_amdgcn_s_setprio(0);
+            }
+            DEKF_SYNC();
+            DEKF_PROF_MARK(q, 5);
+            return;
+        }
+    }
+    __builtin_amdgcn_s_setprio(3);  // the legs are the critical path and share their SIMDs
+#endif
     if (fixed)
         two_waves([&] { sweep_chain<false, false, (NF >= 4 ? FM : 1)>(q, 0, 1, FM, -1, alpha); },
                   [&] { sweep_chain<false, false, (NF >= 4 ? NF - 2 - FM : 1)>(q, NF - 1, -1, NF - 2 - FM, 0, alpha); });
