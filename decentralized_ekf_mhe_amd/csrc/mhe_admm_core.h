@@ -313,7 +313,12 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
     const int fstep = top ? 81 : -81;
     const double* fr = xs + (top ? 9 : 9 * (K - 2)) + i;  // rhs of step 1 (legs)
     const int rstep = top ? 9 : -9;
-    double* gst = xd + (top ? 0 : 9 * (K - 1)) + i;       // where rows 2, 3 put -g of step 1
+    // Stores go through per-lane pointers and strides, lanes with nothing to store aim at a private dummy slot
+    // (tmp[176 + lane], free between factorisations): no EXEC juggling and no select inside a step.
+    double* dummy = q.tmp + 176 + lane;
+    const bool gown = !leg && act;
+    double* gst = gown ? xd + (top ? 0 : 9 * (K - 1)) + i : dummy;  // where rows 2, 3 put -g of step 1
+    const int gstep = gown ? rstep : 0;
     auto fload = [&](int s, Ops& o) {
         const double* W = fm + (s - 1) * fstep;
 #pragma unroll
@@ -333,8 +338,8 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
             // measured 1.4 % slower: one more live register and a select per step)
             const double src = rows23_from_rows01(v);
             const double r = chain_matvec_dpp(src, c.w, c.rhs);
-            if (leg) v = r;
-            else if (act) gst[(s - 1) * rstep] = r;  // -g_{s-1} (row 2) / -g_{K-s} (row 3)
+            v = r;                        // rows 2, 3 never read their own v
+            gst[(s - 1) * gstep] = r;     // -g_{s-1} (row 2) / -g_{K-s} (row 3)
         }
     }
     // ---------------- meeting block (row 0) and the last g of the bottom half (row 3)
@@ -371,6 +376,10 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
             o.dsc = q.D[kn * SV + i];
             o.xo = x[kn * SV + i];
         };
+        const bool own = leg && act;
+        double* xdp = own ? xd + 9 * M + i : dummy;       // block M; step s is at +- s blocks
+        double* xp = own ? x + M * SV + i : dummy;
+        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -SV : SV) : 0;
         Bops o[2];
         bload(1, o[0]);
 #pragma unroll
@@ -378,12 +387,13 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
             const Bops& c = o[(s - 1) & 1];
             if (s < NOUT) bload(s + 1, o[s & 1]);
             const double r = chain_matvec_dpp(v, c.w, -c.ng);
-            const bool live = leg && (!top || s <= M);
-            if (live) v = r;
-            if (live && act) {
-                const int kn = top ? M - s : M + s;
-                xd[9 * kn + i] = c.dsc * r;
-                x[kn * SV + i] = alpha * r + (1.0 - alpha) * c.xo;
+            v = r;
+            if (s <= M) {
+                xdp[s * xdstep] = c.dsc * r;
+                xp[s * xstep] = alpha * r + (1.0 - alpha) * c.xo;
+            } else if (!top && own) {  // the bottom leg is one block longer
+                xdp[s * xdstep] = c.dsc * r;
+                xp[s * xstep] = alpha * r + (1.0 - alpha) * c.xo;
             }
         }
     }
