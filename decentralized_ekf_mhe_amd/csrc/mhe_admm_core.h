@@ -311,8 +311,10 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
     // ---------------- forward: step s = 1..M
     const double* fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
     const int fstep = top ? 81 : -81;
-    const double* fr = xs + (top ? 9 : 9 * (K - 2)) + i;  // rhs of step 1 (legs)
+    q.tmp[260 + lane] = 0.0;  // a zero the rows without a right-hand side can load (tmp[257..338) is free on the device)
     const int rstep = top ? 9 : -9;
+    const double* fr = leg ? xs + (top ? 9 : 9 * (K - 2)) + i : q.tmp + 260 + lane;  // rhs of step 1 (legs) | 0
+    const int frstep = leg ? rstep : 0;
     // Stores go through per-lane pointers and strides, lanes with nothing to store aim at a private dummy slot
     // (tmp[176 + lane], free between factorisations): no EXEC juggling and no select inside a step.
     double* dummy = q.tmp + 176 + lane;
@@ -323,8 +325,7 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
         const double* W = fm + (s - 1) * fstep;
 #pragma unroll
         for (int t = 0; t < 9; ++t) o.w[t] = W[t];
-        const double r = fr[(s - 1) * rstep];
-        o.rhs = leg ? r : 0.0;
+        o.rhs = fr[(s - 1) * frstep];
     };
     double v = xs[(top ? 0 : 9 * (K - 1)) + i];  // f_0 = b_0 / f^_{K-1} = b_{K-1}
     {
