@@ -367,20 +367,22 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
     // ---------------- outward: step s = 1..NOUT, row 0 block M - s (s <= M), row 1 block M + s
     {
         struct Bops { double w[9], ng, dsc, xo; };
-        auto bload = [&](int s, Bops& o) {
-            int kn = top ? M - s : M + s;
-            kn = kn < 0 ? 0 : kn;  // row 0 has one step less: its last load is a dummy
-            const double* W = q.Wk + (top ? kn : kn - 1) * 81 + i;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
-            o.ng = xd[9 * kn + i];
-            o.dsc = q.D[kn * SV + i];
-            o.xo = x[kn * SV + i];
-        };
         const bool own = leg && act;
         double* xdp = own ? xd + 9 * M + i : dummy;       // block M; step s is at +- s blocks
         double* xp = own ? x + M * SV + i : dummy;
+        const double* Dp = own ? q.D + M * SV + i : dummy;
         const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -SV : SV) : 0;
+        const double* Wp = q.Wk + (top ? M : M - 1) * 81 + i;  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
+        const int wstep = top ? -81 : 81;
+        auto bload = [&](int s, Bops& o) {
+            const int sl = s <= M ? s : (top ? M : s);  // row 0 has one step less: its last load repeats block 0
+            const double* W = Wp + sl * wstep;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
+            o.ng = xdp[sl * xdstep];
+            o.dsc = Dp[sl * xstep];
+            o.xo = xp[sl * xstep];
+        };
         Bops o[2];
         bload(1, o[0]);
 #pragma unroll
