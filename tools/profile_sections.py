@@ -22,7 +22,7 @@ from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_dev
 from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
 
 NAMES = ["0 copy R + Ruiz scaling", "1 bounds + first factorisation + restart", "2 X: reduced rhs on x columns",
-         "3 S1: forward legs (2 waves)", "4 S2: meeting block | g_k", "5 S3: outward legs (2 waves)", "6 factor 3a: slack blocks (both factorisations)", "7 factor 3b-3c: PA, T_kk, C_k", "8 factor 3d: block LDL'",
+         "3 S1: forward legs (two-wavefront form only)", "4 S2: meeting block | g_k (two-wavefront form only)", "5 S: block-tridiagonal solve on one wavefront (or S3: outward legs)", "6 factor 3a: slack blocks (both factorisations)", "7 factor 3b-3c: PA, T_kk, C_k", "8 factor 3d: block LDL'",
          "9 R: fused row blocks", "10 residuals + termination", "11 rho update + refactor", "12 epilogue", "13 total"]
 
 
