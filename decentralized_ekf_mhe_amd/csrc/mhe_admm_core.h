@@ -858,9 +858,9 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             return;
         }
         td -= ntp;
-        if (td < 2 * ntd) {  // bias rows, then VO rows
-            const bool vo = td >= ntd;
-            const int k = (td - (vo ? ntd : 0)) * 64 + lane;
+        if (td < 2 * ntd) {  // VO rows, then bias rows: the four kinds that fetch P from HBM come first, one per wavefront
+            const bool vo = td < ntd;
+            const int k = (td - (vo ? 0 : ntd)) * 64 + lane;
             if (k >= K1) return;
             const double* xk = xd + 9 * k;
             double ar[3], ps[3];
