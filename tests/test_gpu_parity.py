@@ -160,3 +160,28 @@ def test_large_batch_properties():
     # the estimate is pulled from its tight zero prior towards the synthetic truth (0.5 m/s forward)
     v_err = np.abs(o["x"][:64, 3:6] - s["gt_v_s"][K - 1]).max()
     assert v_err < 0.45 and o["x"][:64, 3].mean() > 0.15, v_err
+
+
+def test_rccl_allgather_single_rank():
+    """dekf_comm_unique_id / dekf_comm_init / dekf_allgather_vb on a communicator of ONE rank: RCCL is found
+    through dlopen, the communicator comes up on the estimator's device, and the all-gather (on the
+    estimator's stream, after the step) returns exactly the v_b the step produced.  (World sizes > 1 need
+    more GPUs than a test box has; the layout for them is covered on CPU by tests/test_distributed_gloo.py.)"""
+    import torch
+    from decentralized_ekf_mhe_amd.estimator import new_unique_id
+    p = _params(go1_params)
+    B, K = 32, 24
+    s = make_streams(p, B, K)
+    est = BatchedEstimator(p, B)
+    est.comm_init(1, 0, new_unique_id())
+    sd = streams_host(s)
+    vb_all = torch.full((1, B, 3), float("nan"), dtype=torch.float64, device="cuda")
+    for k in range(K):
+        est.push_stream_step(sd, k)
+        est.step(k)
+        est.allgather_vb(vb_all)
+    est.sync()
+    o = est.get()
+    est.close()
+    assert np.array_equal(vb_all.cpu().numpy()[0], o["v_b"])
+    assert np.isfinite(o["v_b"]).all() and np.abs(o["v_b"]).max() > 1e-3
