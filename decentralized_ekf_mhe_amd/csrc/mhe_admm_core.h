@@ -480,51 +480,57 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
 // next phase X gathers), q.cf[r] = rho E D (refreshed by rows_restart after every factorisation).
 // Every LDS load of the block is issued before the first store (the compiler cannot move a load
 // across a store through another pointer, so interleaving them serialises one LDS round trip per row).
-template <int NR, bool EQ, class Q, class SM>
-DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM& S, double alpha, double sigma, bool has_hi = true,
-                              double* wout = nullptr) {
-    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
-    double e[NR], cf[NR], c2[NR], t0[NR], x0[NR], z0[NR], y0[NR], lo[NR], hi[NR];
+template <int NR>
+struct RowPre {  // what a row block needs that does not depend on the solve of this iteration
+    double e[NR], cf[NR], d[NR], t0[NR], x0[NR], z0[NR], y0[NR], lo[NR], hi[NR];
+};
+template <int NR, bool EQ, class Q>
+DEKF_FN void row_block_load(const Q& q, int r0, int sv0, bool has_hi, RowPre<NR>& p) {
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const int r = r0 + j, sv = sv0 + j;
-        e[j] = q.E[r];
-        cf[j] = q.cf[r];
-        c2[j] = q.D[sv];
-        t0[j] = q.zt[r];
-        x0[j] = q.x[sv];
-        z0[j] = q.z[r];
-        y0[j] = q.y[r];
-        lo[j] = q.lo[r];
-        hi[j] = EQ ? 0.0 : q.hi[has_hi ? r - q.ix.rvb : 0];  // !has_hi: an equality block on the generic path (hi = lo below)
+        p.e[j] = q.E[r];
+        p.cf[j] = q.cf[r];
+        p.d[j] = q.D[sv];
+        p.t0[j] = q.zt[r];
+        p.x0[j] = q.x[sv];
+        p.z0[j] = q.z[r];
+        p.y0[j] = q.y[r];
+        p.lo[j] = q.lo[r];
+        p.hi[j] = EQ ? 0.0 : q.hi[has_hi ? r - q.ix.rvb : 0];  // !has_hi: an equality block on the generic path (hi = lo)
     }
-    double v[NR], sl[NR], xn[NR], zn[NR], yn[NR], un[NR], rhs[NR], t[NR];
+}
+template <int NR, bool EQ, class Q, class SM>
+DEKF_FN void row_block_compute(Q& q, int r0, int sv0, const double* ar, const SM& S, const RowPre<NR>& p, double alpha, double sigma,
+                               bool has_hi = true, double* wout = nullptr) {
+    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+    double c2[NR], hi[NR], v[NR], sl[NR], xn[NR], zn[NR], yn[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        if (!EQ && !has_hi) hi[j] = lo[j];
-        c2[j] *= e[j];
-        v[j] = cf[j] * ar[j];
+        hi[j] = (!EQ && !has_hi) ? p.lo[j] : p.hi[j];
+        c2[j] = p.d[j] * p.e[j];
+        v[j] = p.cf[j] * ar[j];
     }
     S.apply(v, sl);
     // the rows of a VO block switch between the +-inf box and an equality TOGETHER (DecentralEst.cpp:995-1005:
     // the three bounds of a step are written at once), so rho is decided once per block, from its first row
-    const double rv_blk = EQ ? rho_eq : q.rho_of(lo[0], hi[0]);
+    const double rv_blk = EQ ? rho_eq : q.rho_of(p.lo[0], hi[0]);
     const double rinv_blk = EQ ? 0.0 : rcp_fast(rv_blk);
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
-        const double sj = t0[j] + sl[j];         // slack solution
+        const double sj = p.t0[j] + sl[j];       // slack solution
         const double ztn = ar[j] - c2[j] * sj;   // (A xt)(r)
-        xn[j] = alpha * sj + (1.0 - alpha) * x0[j];
-        const double zh = alpha * ztn + (1.0 - alpha) * z0[j];
+        xn[j] = alpha * sj + (1.0 - alpha) * p.x0[j];
+        const double zh = alpha * ztn + (1.0 - alpha) * p.z0[j];
         double rv;
         if (EQ) {
             rv = rho_eq;
-            zn[j] = lo[j];
+            zn[j] = p.lo[j];
         } else {
             rv = rv_blk;
-            zn[j] = dmin(dmax(zh + rinv_blk * y0[j], lo[j]), hi[j]);
+            zn[j] = dmin(dmax(zh + rinv_blk * p.y0[j], p.lo[j]), hi[j]);
         }
-        yn[j] = y0[j] + rv * (zh - zn[j]);
+        yn[j] = p.y0[j] + rv * (zh - zn[j]);
         un[j] = rv * zn[j] - yn[j];
         rhs[j] = sigma * xn[j] - c2[j] * un[j];
     }
@@ -536,10 +542,17 @@ DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM&
         q.y[r] = yn[j];
         q.z[r] = zn[j];
         q.zt[r] = t[j];
-        const double wj = e[j] * (un[j] + cf[j] * t[j]);
+        const double wj = p.e[j] * (un[j] + p.cf[j] * t[j]);
         q.at[r] = wj;
         if (wout) wout[j] = wj;
     }
+}
+template <int NR, bool EQ, class Q, class SM>
+DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM& S, double alpha, double sigma, bool has_hi = true,
+                              double* wout = nullptr) {
+    RowPre<NR> p;
+    row_block_load<NR, EQ>(q, r0, sv0, has_hi, p);
+    row_block_compute<NR, EQ>(q, r0, sv0, ar, S, p, alpha, sigma, has_hi, wout);
 }
 // the same block from (x, z, y) alone: after a (re)factorisation, and for the cold start
 template <int NR, bool EQ, class Q, class SM>
@@ -756,6 +769,151 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
         }
     });
     DEKF_SYNC();
+}
+
+#if DEKF_DEVICE_BUILD
+// ---------------------------------------------------------------- S + R with the row operands prefetched
+// When every row tile has its own wavefront (Go1: Meas | Meas | Dyn pairs | VO + bias on four wavefronts) the
+// wavefronts that do not run the solve use that time to bring their row blocks' operands into registers
+// (scaling, bounds, slack state, block inverse: everything but xd), so after the barrier the row phase starts
+// with its arithmetic instead of an LDS round trip of ~45 loads.
+struct RowTile {
+    int kind;  // 0 Meas leg block, 1 Dyn position / velocity half (lane pair), 2 VO or bias block; -1 nothing
+    int k, r0, sv0;
+    bool vel, vo;  // kind 1: velocity half; kind 2: VO block (else bias)
+    RowPre<3> pre;
+    double a[6], b[9];  // slack-block inverse: symmetric own part; coupling to the partner lane (kind 1)
+    DEKF_FN void apply(const double* in, double* out) const {
+        double pin[3] = {0.0, 0.0, 0.0};
+        if (kind == 1) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pin[j] = pair_swap(in[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc += a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)] * in[j];
+            if (kind == 1) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc += b[3 * i + j] * pin[j];
+            }
+            out[i] = acc;
+        }
+    }
+};
+template <class Q>
+DEKF_FN void row_tile_load(const Q& q, int tile, int lane, RowTile& t) {
+    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
+    const int K = q.K, K1 = K - 1, nmeas = K * L;
+    const int ntm = (nmeas + 63) >> 6, ntp = (2 * K1 + 63) >> 6;
+    t.kind = -1; t.k = 0; t.r0 = 0; t.sv0 = 0; t.vel = false; t.vo = false;
+    if (tile < ntm) {
+        const int e = tile * 64 + lane;
+        if (e >= nmeas) return;
+        const int k = e / L, leg = e - k * L;
+        t.kind = 0; t.k = k; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg;
+        const double* sp = q.Sv + e * 6;
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t.a[i] = sp[i];
+        row_block_load<3, true>(q, t.r0, t.sv0, true, t.pre);
+    } else if (tile < ntm + ntp) {
+        const int pl = (tile - ntm) * 64 + lane, k = pl >> 1;
+        if (k >= K1) return;
+        const bool vel = pl & 1;
+        t.kind = 1; t.k = k; t.vel = vel; t.r0 = q.ix.rd(k, vel ? 3 : 0); t.sv0 = k * SV + 9 + NM + (vel ? 3 : 0);
+        const DynPairMat S(q.Sw + k * SWS, vel);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t.a[i] = S.a[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.b[i] = S.b[i];
+        row_block_load<3, true>(q, t.r0, t.sv0, true, t.pre);
+    } else {
+        const int idx = (tile - ntm - ntp) * 64 + lane;
+        if (idx >= 2 * K1) return;
+        const bool vo = idx < K1;
+        const int k = vo ? idx : idx - K1;
+        t.kind = 2; t.k = k; t.vo = vo; t.r0 = vo ? q.ix.rv(k, 0) : q.ix.rd(k, 6); t.sv0 = k * SV + (vo ? 18 + NM : 9 + NM + 6);
+        const VoOrBiasMat S(q.Sc + k * 6, q.Sw + k * SWS + 21, vo);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t.a[i] = S.p[i];
+        row_block_load<3, false>(q, t.r0, t.sv0, vo, t.pre);
+    }
+}
+template <class Q>
+DEKF_FN void row_tile_finish(Q& q, const RowTile& t, double alpha, double sigma) {
+    if (t.kind < 0) return;
+    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double* xk = q.xd + 9 * t.k;
+    const double* E = q.E;
+    double ar[3];
+    if (t.kind == 0) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ar[a] = E[t.r0 + a] * xk[3 + a];
+        row_block_compute<3, true>(q, t.r0, t.sv0, ar, t, t.pre, alpha, sigma);
+    } else if (t.kind == 1) {
+        const double* R = q.R + 9 * t.k;
+        double Rk[9], wo[3];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rk[i] = R[i];
+        const bool vel = t.vel;
+        const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
+        const int o = vel ? 3 : 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double rb = Rk[3 * a] * xk[6] + Rk[3 * a + 1] * xk[7] + Rk[3 * a + 2] * xk[8];
+            ar[a] = E[t.r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+        }
+        row_block_compute<3, true>(q, t.r0, t.sv0, ar, t, t.pre, alpha, sigma, true, wo);
+        double u[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double pw = pair_swap(wo[r]);
+            u[r] = vel ? hdt2 * pw + dt * wo[r] : hdt2 * wo[r] + dt * pw;
+        }
+        if (!vel) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) q.gb[3 * t.k + a] = Rk[a] * u[0] + Rk[3 + a] * u[1] + Rk[6 + a] * u[2];
+        }
+    } else {
+        const int o = t.vo ? 0 : 6;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ar[a] = E[t.r0 + a] * (xk[o + a] - xk[9 + o + a]);
+        row_block_compute<3, false>(q, t.r0, t.sv0, ar, t, t.pre, alpha, sigma, t.vo);
+    }
+}
+#endif
+
+// one ADMM iteration after phase X: the block-tridiagonal solve, then the rows
+template <class Q>
+DEKF_FN void phase_sweeps_rows(Q& q, double alpha, double sigma) {
+#if DEKF_DEVICE_BUILD
+    constexpr int NF = Q::NFIXED, L = Q::LEGS;
+    if constexpr (NF >= 4 && NF % 2 == 0) {
+        const int K = q.K;
+        const int ntiles = ((K * L + 63) >> 6) + 2 * ((2 * (K - 1) + 63) >> 6);
+        if (K == NF && ntiles <= wave_count()) {
+            const int w = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), lane = DEKF_LANE() & 63;
+            RowTile t;
+            t.kind = -1;
+            if (w == 0) {
+                __builtin_amdgcn_s_setprio(3);
+                sweeps_one_wave<NF>(q, alpha);
+                __builtin_amdgcn_s_setprio(0);
+            } else if (w < ntiles) {
+                row_tile_load(q, w, lane, t);
+            }
+            DEKF_SYNC();
+            DEKF_PROF_MARK(q, 5);
+            if (w == 0) row_tile_load(q, 0, lane, t);
+            row_tile_finish(q, t, alpha, sigma);
+            DEKF_SYNC();
+            return;
+        }
+    }
+#endif
+    phase_sweeps(q, alpha);
+    phase_rows<false>(q, alpha, sigma);
 }
 
 // ---------------------------------------------------------------- residual norms

@@ -903,8 +903,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         ++iter;
         phase_xcols(q, sigma);
         DEKF_PROF_MARK(q, 2);
-        phase_sweeps(q, alpha);
-        phase_rows<false>(q, alpha, sigma);
+        phase_sweeps_rows(q, alpha, sigma);
         DEKF_PROF_MARK(q, 9);
         bool can_check = c.check_termination > 0 && (iter % c.check_termination == 0);
         bool adapt_now = c.adaptive_rho && c.adaptive_rho_interval > 0 && (iter % c.adaptive_rho_interval == 0);
