@@ -25,6 +25,18 @@ __device__ __forceinline__ double step_dpp(double v, const double* w, double rhs
     DPP_FMAC(a0, v, w[6], 6); DPP_FMAC(a1, v, w[7], 7); DPP_FMAC(a2, v, w[8], 8);
     return a0 + (a1 + a2);
 }
+// broadcast with v_mov_b64_dpp row_newbcast, multiply with a plain (full-rate) v_fma_f64
+#define DPP_MOV(dst, v, T) asm volatile("v_mov_b64_dpp %0, %1 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(v))
+__device__ __forceinline__ double step_movdpp(double v, const double* w, double rhs) {
+    double b0, b1, b2, b3, b4, b5, b6, b7, b8;
+    asm volatile("s_nop 1");
+    DPP_MOV(b0, v, 0); DPP_MOV(b1, v, 1); DPP_MOV(b2, v, 2); DPP_MOV(b3, v, 3); DPP_MOV(b4, v, 4);
+    DPP_MOV(b5, v, 5); DPP_MOV(b6, v, 6); DPP_MOV(b7, v, 7); DPP_MOV(b8, v, 8);
+    double a0 = rhs - w[0] * b0, a1 = -(w[1] * b1), a2 = -(w[2] * b2);
+    a0 -= w[3] * b3; a1 -= w[4] * b4; a2 -= w[5] * b5;
+    a0 -= w[6] * b6; a1 -= w[7] * b7; a2 -= w[8] * b8;
+    return a0 + (a1 + a2);
+}
 // nine independent DPP products, then an addition tree (depth 1 + 4 instead of 3 + 2)
 __device__ __forceinline__ double step_dpp9(double v, const double* w, double rhs) {
     double a0 = rhs, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0, a8 = 0.0;
@@ -73,7 +85,7 @@ __global__ void __launch_bounds__(256) chain(double* out, long long* cyc, int re
         for (int s = 1; s <= STEPS; ++s) {
             const Ops& c = o[(s - 1) & 1];
             if (s < STEPS) load(s + 1, o[s & 1]);
-            v = DPP == 1 ? step_dpp(v, c.w, c.rhs) : (DPP == 2 ? step_dpp9(v, c.w, c.rhs) : step_readlane(v, c.w, c.rhs));
+            v = DPP == 1 ? step_dpp(v, c.w, c.rhs) : (DPP == 2 ? step_dpp9(v, c.w, c.rhs) : (DPP == 3 ? step_movdpp(v, c.w, c.rhs) : step_readlane(v, c.w, c.rhs)));
             if (act) x[9 * s + i] = v;
         }
     }
@@ -83,21 +95,22 @@ __global__ void __launch_bounds__(256) chain(double* out, long long* cyc, int re
 }
 
 int main() {
-    double *d, h[3][256]; long long* c;
+    double *d, h[4][256]; long long* c;
     (void)hipMalloc(&d, 256 * 8); (void)hipMalloc(&c, 4 * 8);
     const size_t lds = (20 * 81 + 4 * 180) * 8;
     for (int nw = 1; nw <= 4; nw *= 4)
-        for (int dpp = 0; dpp < 3; ++dpp) {
+        for (int dpp = 0; dpp < 4; ++dpp) {
             for (int rep = 0; rep < 2; ++rep) {
                 if (dpp == 1) chain<1, 10><<<1, 64 * nw, lds>>>(d, c, 200);
                 else if (dpp == 2) chain<2, 10><<<1, 64 * nw, lds>>>(d, c, 200);
+                else if (dpp == 3) chain<3, 10><<<1, 64 * nw, lds>>>(d, c, 200);
                 else chain<0, 10><<<1, 64 * nw, lds>>>(d, c, 200);
                 (void)hipDeviceSynchronize();
             }
             long long hc[4];
             (void)hipMemcpy(hc, c, 32, hipMemcpyDeviceToHost);
             (void)hipMemcpy(h[dpp], d, 256 * 8, hipMemcpyDeviceToHost);
-            printf("waves %d  %-10s %.1f cycles per step   v[0..2] = %.15g %.15g %.15g\n", nw, dpp == 1 ? "dpp fmac" : (dpp == 2 ? "dpp x9" : "readlane"), (double)hc[0] / 2000.0,
+            printf("waves %d  %-10s %.1f cycles per step   v[0..2] = %.15g %.15g %.15g\n", nw, dpp == 1 ? "dpp fmac" : (dpp == 2 ? "dpp x9" : (dpp == 3 ? "mov_dpp+fma" : "readlane")), (double)hc[0] / 2000.0,
                    h[dpp][0], h[dpp][1], h[dpp][2]);
         }
     for (int dpp = 0; dpp < 2; ++dpp) {
