@@ -26,6 +26,7 @@ __global__ void k_mhe_assemble(DevCfg c, DevState s, int T, int pushes);
     __global__ void k_mhe_solve_lg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);     \
     __global__ void k_mhe_solve_gg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);
 __global__ void k_mhe_solve_ll_4_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
+__global__ void k_mhe_solve_lg_2_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
 DEKF_DECL_SOLVE(1)
 DEKF_DECL_SOLVE(2)
 DEKF_DECL_SOLVE(3)
@@ -176,6 +177,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             {k_mhe_solve_ll_3, k_mhe_solve_lg_3, k_mhe_solve_gg_3}, {k_mhe_solve_ll_4, k_mhe_solve_lg_4, k_mhe_solve_gg_4}};
         h->solve_kernel = table[c.L - 1][lay.pa_in_lds() ? 0 : (lay.factor_in_lds() ? 1 : 2)];
         if (c.L == 4 && c.N == 20 && lay.pa_in_lds()) h->solve_kernel = k_mhe_solve_ll_4_n20;
+        if (c.L == 2 && c.N == 20 && lay.factor_in_lds() && !lay.pa_in_lds()) h->solve_kernel = k_mhe_solve_lg_2_n20;
 #ifdef DEKF_PROFILE
         // diagnostic build only: DEKF_DEBUG_PLACEMENT=1|2 forces the _lg / _gg placement (2 also shrinks the LDS request)
         if (const char* pl = getenv("DEKF_DEBUG_PLACEMENT")) {

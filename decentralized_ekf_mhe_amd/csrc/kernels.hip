@@ -62,6 +62,13 @@ extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) k_mhe_solve_
     double* gws = s.gws + (size_t)blockIdx.x * gws_len;
     for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<4, true, true, 20>(c, s, b, kstart, K, lds, gws);
 }
+// Cassie (2 legs, N = 20; its factor-time temporary does not fit next to the vectors: _lg placement)
+extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) k_mhe_solve_lg_2_n20(DevCfg c, DevState s, int kstart, int K,
+                                                                                   int gws_len) {
+    extern __shared__ double lds[];
+    double* gws = s.gws + (size_t)blockIdx.x * gws_len;
+    for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<2, true, false, 20>(c, s, b, kstart, K, lds, gws);
+}
 DEKF_SOLVE_KERNELS(1)
 DEKF_SOLVE_KERNELS(2)
 DEKF_SOLVE_KERNELS(3)

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configurations (they are parity cases, not the bench line):
+Cassie (2 legs, 5 joints) B=4096 N=20, PogoX (1 leg) B=1024 N=100, Go1 at the 8-GPU per-rank batch 8192.
+Same loop as bench.py (device-resident synthetic logs, steady state), one JSON line per shape."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+from decentralized_ekf_mhe_amd import cassie_params, go1_params, pogox_params  # noqa: E402
+from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_device  # noqa: E402
+from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
+
+
+def run(name, maker, B, steps, **kw):
+    p = maker()
+    p.ekf_rate = p.rate
+    for k, v in kw.items():
+        setattr(p, k, v)
+    W = p.N + 10
+    s = make_streams(p, B, W + steps)
+    sd = streams_to_device(s)
+    est = BatchedEstimator(p, B)
+    for k in range(W):
+        est.push_stream_step(sd, k)
+        est.step(k)
+    est.sync()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(W, W + steps):
+        est.push_stream_step(sd, k)
+        est.step(k)
+    est.sync()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    info = est.solver_info()
+    o = est.get()
+    est.close()
+    print(json.dumps({"shape": name, "legs": p.num_legs, "N": p.N, "batch": B, "steps": steps,
+                      "estimator_steps_per_s": B * steps / dt, "ms_per_step": 1e3 * dt / steps,
+                      "mean_iters": float(info["iters"].mean()), "solved_frac": float((o["status"] == 1).mean())}), flush=True)
+
+
+if __name__ == "__main__":
+    run("go1 N=20 (bench line shape)", go1_params, 4096, 100)
+    run("go1 N=20, per-rank batch of the 8-GPU config", go1_params, 8192, 60)
+    run("cassie N=20", cassie_params, 4096, 100)
+    run("pogox N=100", pogox_params, 1024, 60)
