@@ -141,9 +141,9 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
         o.xo = BWD ? x[kn * SV + i] : 0.0;
     };
     double v = xs[9 * k0 + i];
-    auto step = [&](const Ops& c, Ops& n, int s) {
+    auto step = [&](const Ops& c, Ops& n, int s, int ahead = 1) {
         const int kn = k0 + s * dk;
-        if (s < steps) load(kn + dk, n);
+        if (s + ahead <= steps) load(kn + ahead * dk, n);
         v = chain_matvec_dpp(v, c.w, c.rhs);  // 5 dependent f64 operations per step
         if (act) {
             if (BWD) {
@@ -176,11 +176,24 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
             }
         }
     } else {
-        Ops A, B;
-        if (steps >= 1) load(k0 + dk, A);
+        // run-time step count: a ring of four operand sets, three steps of prefetch in flight.  The compiler waits
+        // for every outstanding load at the loop back-edge, so one latency is exposed per four steps (it was per
+        // two with two sets) — what matters when W streams from the HBM slab (N = 100: 50-step legs).
+        Ops r0, r1, r2, r3;
+        if (steps >= 1) load(k0 + dk, r0);
+        if (steps >= 2) load(k0 + 2 * dk, r1);
+        if (steps >= 3) load(k0 + 3 * dk, r2);
         int s = 1;
-        for (; s + 1 <= steps; s += 2) { step(A, B, s); step(B, A, s + 1); }
-        if (s <= steps) step(A, B, s);
+        for (; s + 3 <= steps; s += 4) {
+            step(r0, r3, s, 3);
+            step(r1, r0, s + 1, 3);
+            step(r2, r1, s + 2, 3);
+            step(r3, r2, s + 3, 3);
+        }
+        // here r0, r1, r2 hold the operands of steps s, s+1, s+2 (as far as they exist)
+        if (s <= steps) step(r0, r3, s, 4);
+        if (s + 1 <= steps) step(r1, r3, s + 1, 4);
+        if (s + 2 <= steps) step(r2, r3, s + 2, 4);
     }
 #else
     double v[9], nv[9];
