@@ -195,6 +195,9 @@ class DecentralizedEstimation {
     MatrixXd C_KF_ = MatrixXd(9, 9);
     Vector3d v_KF_b_;
     int solver_status_ = DEKF_SOLVE_NONE, solver_iters_ = 0;  // new: the reference ignores OSQP's flag
+    // new: take raw Go1 joint states from robot_store (joint_states_position_/velocity_) instead of
+    // p_imu_2_foot_/J_imu_2_foot_/contact_; set before initialize()  
+    bool go1_raw_joints_ = false;
 
   private:
     std::shared_ptr<robot_store> robot_sub_ptr_;
@@ -212,13 +215,23 @@ class DecentralizedEstimation {
         double q[4] = {s.quaternion_.w(), s.quaternion_.x(), s.quaternion_.y(), s.quaternion_.z()};
         dekf_shim::check(dekf_push_quaternion(h_, q, DEKF_HOST));
         std::vector<double> p(3 * L), J(9 * L), qd(3 * L), c(L);
-        for (int i = 0; i < 3 * L; ++i) {
-            p[(size_t)i] = s.p_imu_2_foot_(i, 0);
-            for (int j = 0; j < 3; ++j) J[(size_t)(3 * i + j)] = s.J_imu_2_foot_(i, j);
-            qd[(size_t)i] = s.joint_states_velocity_(i);
+        if (go1_raw_joints_) {
+            // /unitree/joint_state as go1Sub::lo_callback receives it (go1Sub.cpp:66-76): position = 12 joint
+            // angles followed by the 4 foot forces; kinematics and the contact threshold run on the device
+            if (s.joint_states_position_.size() < 16 || s.joint_states_velocity_.size() < 12)
+                throw std::invalid_argument("go1_raw_joints_: joint_states_position_ needs 16 entries, joint_states_velocity_ 12");
+            for (int i = 0; i < 12; ++i) { p[(size_t)i] = s.joint_states_position_(i); qd[(size_t)i] = s.joint_states_velocity_(i); }
+            for (int i = 0; i < 4; ++i) c[(size_t)i] = s.joint_states_position_(12 + i);
+            dekf_shim::check(dekf_push_go1_joints(h_, p.data(), qd.data(), c.data(), DEKF_HOST));
+        } else {
+            for (int i = 0; i < 3 * L; ++i) {
+                p[(size_t)i] = s.p_imu_2_foot_(i, 0);
+                for (int j = 0; j < 3; ++j) J[(size_t)(3 * i + j)] = s.J_imu_2_foot_(i, j);
+                qd[(size_t)i] = s.joint_states_velocity_(i);
+            }
+            for (int i = 0; i < L; ++i) c[(size_t)i] = s.contact_(i);
+            dekf_shim::check(dekf_push_leg(h_, p.data(), J.data(), qd.data(), c.data(), DEKF_HOST));
         }
-        for (int i = 0; i < L; ++i) c[(size_t)i] = s.contact_(i);
-        dekf_shim::check(dekf_push_leg(h_, p.data(), J.data(), qd.data(), c.data(), DEKF_HOST));
         if (s.vo_new_) {
             int one = 1;
             double dp[3] = {s.vo_p_body_pre_2_body_(0), s.vo_p_body_pre_2_body_(1), s.vo_p_body_pre_2_body_(2)};

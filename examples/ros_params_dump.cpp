@@ -1,0 +1,54 @@
+// ros_params_dump.cpp — reads a ROS2 parameter file the way the est_sub / orien_sub node cores do and
+// prints the resulting dekf_params block, one "field v0 v1 ..." line each (tests/test_node_cores.py
+// compares it with the Python reader).
+//   g++ -std=c++17 examples/ros_params_dump.cpp -o ros_params_dump -Ldecentralized_ekf_mhe_amd/csrc -ldekf
+#include <cstdio>
+
+#include "../decentralized_ekf_mhe_amd/cpp/est_node_core.hpp"
+#include "../decentralized_ekf_mhe_amd/cpp/orien_node_core.hpp"
+#include "../decentralized_ekf_mhe_amd/cpp/ros_params.hpp"
+
+static void row(const char* name, const double* v, int n) {
+    std::printf("%s", name);
+    for (int i = 0; i < n; ++i) std::printf(" %.17g", v[i]);
+    std::printf("\n");
+}
+static void row(const char* name, double v) { row(name, &v, 1); }
+
+int main(int argc, char** argv) {
+    if (argc < 2) { std::fprintf(stderr, "usage: %s params.yaml\n", argv[0]); return 2; }
+    try {
+        dekf_ros::ParamNode est = dekf_ros::ParamNode::from_file(argv[1], "est_sub");
+        dekf_ros::ParamNode orien = dekf_ros::ParamNode::from_file(argv[1], "orien_sub");
+        robot_params rp;
+        std::string log_name;
+        int interval = 0;
+        robotSub::paramsWrapper(est, rp, log_name, interval);
+        dekf_params d = dekf_shim::to_dekf_params(rp);
+        orien_ekf::paramsWrapper(orien, d);
+        std::printf("log_name %s\ninterval_ms %d\n", log_name.c_str(), interval);
+        row("p_init_std", d.p_init_std, 3); row("v_init_std", d.v_init_std, 3); row("foot_init_std", d.foot_init_std, 3);
+        row("accel_bias_init_std", d.accel_bias_init_std, 3); row("p_process_std", d.p_process_std, 3);
+        row("accel_input_std", d.accel_input_std, 3); row("gyro_input_std", d.gyro_input_std, 3);
+        row("accel_bias_std", d.accel_bias_std, 3); row("quaternion_ib", d.quaternion_ib, 4); row("p_ib", d.p_ib, 3);
+        row("num_legs", d.num_legs); row("joints_per_leg", d.joints_per_leg); row("leg_odom_type", d.leg_odom_type);
+        row("joint_position_std", d.joint_position_std, DEKF_MAX_JOINTS); row("joint_velocity_std", d.joint_velocity_std, DEKF_MAX_JOINTS);
+        row("foot_slide_std", d.foot_slide_std, 3); row("foot_swing_std", d.foot_swing_std, 3);
+        row("contact_effort_threshold", d.contact_effort_threshold); row("vo_p_std", d.vo_p_std, 3);
+        row("rate", d.rate); row("N", d.N); row("est_type", d.est_type);
+        row("rho", d.rho); row("alpha", d.alpha); row("delta", d.delta); row("sigma", d.sigma);
+        row("verbose", d.verbose); row("adapt_rho", d.adapt_rho); row("polish", d.polish); row("max_qp_iter", d.max_qp_iter);
+        row("rel_tol", d.rel_tol); row("abs_tol", d.abs_tol); row("prim_tol", d.prim_tol); row("dual_tol", d.dual_tol);
+        row("time_limit", d.time_limit);
+        row("scaling_iters", d.scaling_iters); row("check_termination", d.check_termination);
+        row("adaptive_rho_interval", d.adaptive_rho_interval); row("adaptive_rho_tolerance", d.adaptive_rho_tolerance);
+        row("ekf_init_std", d.ekf_init_std, 4); row("ekf_process_std", d.ekf_process_std, 3);
+        row("ekf_gravity_meas_std", d.ekf_gravity_meas_std, 3); row("ekf_vo_meas_std", d.ekf_vo_meas_std, 4);
+        row("ekf_quaternion_init", d.ekf_quaternion_init, 4); row("ekf_rate", d.ekf_rate); row("ekf_history", d.ekf_history);
+        for (const std::string& n : est.undeclared_overrides()) std::printf("undeclared %s\n", n.c_str());
+    } catch (const std::exception& ex) {
+        std::fprintf(stderr, "error: %s\n", ex.what());
+        return 1;
+    }
+    return 0;
+}
