@@ -47,6 +47,7 @@ PROTOTYPES = {
     "dekf_comm_unique_id": (C.c_int, [_vp]),
     "dekf_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dekf_allgather_vb": (C.c_int, [_vp, _vp]),
+    "dekf_allgather_wait": (C.c_int, [_vp]),
 }
 
 _lib = None

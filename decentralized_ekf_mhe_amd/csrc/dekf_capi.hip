@@ -67,9 +67,13 @@ struct dekf_handle_s {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DEKF_TIMING_CLASSES];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
-    // RCCL
+    // RCCL: the all-gather runs on its own stream out of a snapshot of v_b, so that it overlaps the next step
     void* comm = nullptr;
     int world = 1, rank = 0;
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_vb_ready = nullptr, ev_ag_done = nullptr;
+    double* vb_snapshot = nullptr;
+    bool ag_pending = false;
 };
 
 namespace {
@@ -224,7 +228,12 @@ dekf_status dekf_destroy(dekf_handle h) {
     if (!h) return DEKF_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) rccl_destroy(h->comm);
+    if (h->ev_vb_ready) (void)hipEventDestroy(h->ev_vb_ready);
+    if (h->ev_ag_done) (void)hipEventDestroy(h->ev_ag_done);
+    if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+    if (h->vb_snapshot) (void)hipFree(h->vb_snapshot);
     for (auto& v : h->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (auto& pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (void* q : h->blocks) (void)hipFree(q);
@@ -249,6 +258,7 @@ dekf_status dekf_reset(dekf_handle h) {
 dekf_status dekf_sync(dekf_handle h) {
     if (!h) return fail(DEKF_ERR_INVALID, "null handle");
     HIPCHK(hipStreamSynchronize(h->stream));
+    if (h->comm_stream) HIPCHK(hipStreamSynchronize(h->comm_stream));
     return DEKF_OK;
 }
 int dekf_batch(dekf_handle h) { return h ? h->c.B : 0; }
@@ -479,18 +489,37 @@ dekf_status dekf_comm_unique_id(void* id_out) {
 }
 dekf_status dekf_comm_init(dekf_handle h, int world, int rank, const void* id) {
     if (!h || !id || world < 1 || rank < 0 || rank >= world) return fail(DEKF_ERR_INVALID, "bad communicator arguments");
+    if (h->comm) return fail(DEKF_ERR_ORDER, "dekf_comm_init was already called on this handle");
     HIPCHK(hipSetDevice(h->device));
     const char* e = rccl_init_rank(&h->comm, world, rank, id);
     if (e) return fail(DEKF_ERR_COMM, e);
     h->world = world;
     h->rank = rank;
+    HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_vb_ready, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&h->ev_ag_done, hipEventDisableTiming));
+    HIPCHK(hipMalloc((void**)&h->vb_snapshot, 3 * (size_t)h->c.B * sizeof(double)));
     return DEKF_OK;
 }
 dekf_status dekf_allgather_vb(dekf_handle h, double* v_b_all_dev) {
     if (!h || !v_b_all_dev) return fail(DEKF_ERR_INVALID, "null argument");
     if (!h->comm) return fail(DEKF_ERR_ORDER, "dekf_comm_init has not been called");
-    const char* e = rccl_allgather_f64(h->comm, h->s.v_b, v_b_all_dev, 3 * (size_t)h->c.B, h->stream);
+    HIPCHK(hipSetDevice(h->device));
+    const size_t n = 3 * (size_t)h->c.B;
+    // the previous all-gather must have read the snapshot before it is overwritten (it finished a step ago)
+    if (h->ag_pending) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ag_done, 0));
+    HIPCHK(hipMemcpyAsync(h->vb_snapshot, h->s.v_b, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    HIPCHK(hipEventRecord(h->ev_vb_ready, h->stream));
+    HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_vb_ready, 0));
+    const char* e = rccl_allgather_f64(h->comm, h->vb_snapshot, v_b_all_dev, n, h->comm_stream);
     if (e) return fail(DEKF_ERR_COMM, e);
+    HIPCHK(hipEventRecord(h->ev_ag_done, h->comm_stream));
+    h->ag_pending = true;
+    return DEKF_OK;
+}
+dekf_status dekf_allgather_wait(dekf_handle h) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    if (h->ag_pending) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ag_done, 0));
     return DEKF_OK;
 }
 

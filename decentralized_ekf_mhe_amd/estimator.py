@@ -161,7 +161,12 @@ class BatchedEstimator:
         capi.check(self.lib.dekf_comm_init(self.h, world, rank, buf))
 
     def allgather_vb(self, out_tensor):
+        """asynchronous (own stream, overlaps the next step); complete after sync() or allgather_wait()"""
         capi.check(self.lib.dekf_allgather_vb(self.h, C.c_void_p(out_tensor.data_ptr())))
+
+    def allgather_wait(self):
+        """the estimator's stream waits for the last all-gather (no host block)"""
+        capi.check(self.lib.dekf_allgather_wait(self.h))
 
 
 def new_unique_id() -> bytes:

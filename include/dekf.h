@@ -200,11 +200,20 @@ dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches);
 /* ---- multi-GPU (new: the reference is single-robot) ------------------------------ */
 /* All-gather of the fused base velocity over RCCL: every rank contributes its
  * v_b[B][3] and receives v_b_all[world][B][3] (device pointer). The communicator is
- * created from an ncclUniqueId distributed by the caller (torch.distributed, MPI, ...). */
+ * created from an ncclUniqueId distributed by the caller (torch.distributed, MPI, ...).
+ *
+ * dekf_allgather_vb is asynchronous twice over: it snapshots v_b in stream order (after
+ * the step that produced it) and runs the collective on a second stream owned by the
+ * handle, so the exchange of step T overlaps the kernels of step T+1 and a slow rank
+ * delays the others by at most one step of slack. v_b_all is complete after dekf_sync,
+ * or in stream order after dekf_allgather_wait (which makes dekf_stream() wait for the
+ * last all-gather without blocking the host). Use a different v_b_all buffer while the
+ * previous one is still being read on another stream. */
 #define DEKF_UNIQUE_ID_BYTES 128
 dekf_status dekf_comm_unique_id(void* id_out);
 dekf_status dekf_comm_init(dekf_handle h, int world, int rank, const void* id);
 dekf_status dekf_allgather_vb(dekf_handle h, double* v_b_all_dev);
+dekf_status dekf_allgather_wait(dekf_handle h);
 
 #ifdef __cplusplus
 }

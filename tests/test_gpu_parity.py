@@ -164,24 +164,34 @@ def test_large_batch_properties():
 
 def test_rccl_allgather_single_rank():
     """dekf_comm_unique_id / dekf_comm_init / dekf_allgather_vb on a communicator of ONE rank: RCCL is found
-    through dlopen, the communicator comes up on the estimator's device, and the all-gather (on the
-    estimator's stream, after the step) returns exactly the v_b the step produced.  (World sizes > 1 need
-    more GPUs than a test box has; the layout for them is covered on CPU by tests/test_distributed_gloo.py.)"""
+    through dlopen, the communicator comes up on the estimator's device, and every step's all-gather — issued
+    without any host synchronisation, running on the handle's second stream while the next step computes —
+    returns exactly the v_b that step produced.  (World sizes > 1 need more GPUs than a test box has; the
+    layout for them is covered on CPU by tests/test_distributed_gloo.py.)"""
     import torch
     from decentralized_ekf_mhe_amd.estimator import new_unique_id
     p = _params(go1_params)
-    B, K = 32, 24
+    B, K = 32, 30
     s = make_streams(p, B, K)
+    sd = streams_host(s)
     est = BatchedEstimator(p, B)
     est.comm_init(1, 0, new_unique_id())
-    sd = streams_host(s)
-    vb_all = torch.full((1, B, 3), float("nan"), dtype=torch.float64, device="cuda")
+    vb_all = torch.full((K, 1, B, 3), float("nan"), dtype=torch.float64, device="cuda")
     for k in range(K):
         est.push_stream_step(sd, k)
         est.step(k)
-        est.allgather_vb(vb_all)
+        est.allgather_vb(vb_all[k])
+    est.allgather_wait()
     est.sync()
-    o = est.get()
+    last = est.get()["v_b"]
     est.close()
-    assert np.array_equal(vb_all.cpu().numpy()[0], o["v_b"])
-    assert np.isfinite(o["v_b"]).all() and np.abs(o["v_b"]).max() > 1e-3
+    got = vb_all.cpu().numpy()[:, 0]
+    # the same log again, reading v_b after every step
+    ref = BatchedEstimator(p, B)
+    for k in range(K):
+        ref.push_stream_step(sd, k)
+        ref.step(k)
+        assert np.array_equal(got[k], ref.get()["v_b"]), k
+    ref.close()
+    assert np.array_equal(got[-1], last)
+    assert np.isfinite(last).all() and np.abs(last).max() > 1e-3
