@@ -83,9 +83,25 @@ def test_batch_not_multiple_of_wave_and_masked_vo():
     assert block_err(x[1:], x_ref[ks][1:]) <= 1.0
 
 
-@pytest.mark.parametrize("maker,N,K", [(cassie_params, 20, 50), (pogox_params, 100, 130), (go1_params, 5, 25)])
+def tripod_params():
+    """3 legs x 6 joints: the leg count and joint count no BASELINE config uses"""
+    p = go1_params()
+    p.num_legs, p.joints_per_leg = 3, 6
+    return p
+
+
+def two_joint_quadruped_params():
+    """4 legs x 2 joints at N = 20: the fixed-horizon Go1 solve kernel with another joint count in the assembly"""
+    p = go1_params()
+    p.joints_per_leg = 2
+    return p
+
+
+@pytest.mark.parametrize("maker,N,K", [(cassie_params, 20, 50), (pogox_params, 100, 130), (go1_params, 5, 25),
+                                       (tripod_params, 12, 40), (two_joint_quadruped_params, 20, 45), (cassie_params, 7, 30)])
 def test_other_robot_shapes(maker, N, K):
-    """BASELINE configs 3 (2 legs x 5 joints) and 5 (1 leg, N = 100), plus a short horizon"""
+    """BASELINE configs 3 (2 legs x 5 joints) and 5 (1 leg, N = 100), a short horizon, and shapes outside
+    BASELINE: 3 legs x 6 joints at an even horizon that has no fixed-horizon kernel, 2-joint legs, an odd horizon"""
     p = _params(maker, N=N)
     B = 4
     s = make_streams(p, B, K)
