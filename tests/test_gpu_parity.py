@@ -83,6 +83,30 @@ def test_batch_not_multiple_of_wave_and_masked_vo():
     assert block_err(x[1:], x_ref[ks][1:]) <= 1.0
 
 
+def test_flight_phases_vo_dropouts_and_long_vo_intervals():
+    """inputs the trot logs never produce: every foot in the air for longer than the window (all measurement
+    weights at the swing value 1e-14), every foot in stance, a camera that drops out for 40 ticks, VO frame
+    pairs 8 x longer than usual (their Bezier nodes span more steps than the window holds) and VO samples
+    delivered late (latency of 12 ticks)"""
+    p = _params(go1_params)
+    B, K = 12, 110
+    s = make_streams(p, B, K, vo_rate=30.0)
+    slow = make_streams(p, B, K, vo_rate=3.75, vo_latency=0.06)
+    for key in ("vo_mask", "vo_t_pre", "vo_t_now", "vo_dp", "vo_t_pose", "vo_q"):
+        s[key][:, 6:] = slow[key][:, 6:]          # instances 6.. get the slow, late camera
+    s["contact"][25:55, 0:3] = 0.0               # flight: 30 ticks > N
+    s["contact"][25:55, 6:9] = 0.0
+    s["contact"][60:85, 3:6] = 1.0               # all four feet down
+    s["vo_mask"][40:80, 1::2] = 0                # dropout on every other robot
+    x_ref, vb_ref, q_ref, _, it_ref = O.run_streams(p, s, nthreads=8, want_iters=True)
+    x, q, vb, it, st = run_gpu(p, s, B, K, every=3)
+    ks = [k for k in range(K) if k % 3 == 0 or k == K - 1]
+    assert np.abs(q - q_ref[ks]).max() < 1e-9
+    assert (st[1:] == 1).all()
+    assert block_err(x[1:], x_ref[ks][1:]) <= 1.0
+    assert (it[1:] == it_ref[ks][1:]).mean() > 0.97
+
+
 def tripod_params():
     """3 legs x 6 joints: the leg count and joint count no BASELINE config uses"""
     p = go1_params()
