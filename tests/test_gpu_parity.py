@@ -107,6 +107,23 @@ def test_flight_phases_vo_dropouts_and_long_vo_intervals():
     assert (it[1:] == it_ref[ks][1:]).mean() > 0.97
 
 
+def test_iteration_cap_returns_the_same_unconverged_iterate():
+    """osqp.maxQPIter below what convergence needs: the solve stops at the cap (not at a multiple of the
+    25-iteration check), reports it, and hands back the same iterate as the oracle; adaptive rho off as well"""
+    for cap, adapt in ((40, 1), (60, 0)):
+        p = _params(go1_params, max_qp_iter=cap, adapt_rho=adapt)
+        B, K = 6, 40
+        s = make_streams(p, B, K)
+        x_ref, vb_ref, q_ref, _, it_ref = O.run_streams(p, s, nthreads=6, want_iters=True)
+        x, q, vb, it, st = run_gpu(p, s, B, K, every=4)
+        ks = [k for k in range(K) if k % 4 == 0 or k == K - 1]
+        assert (it[1:] == it_ref[ks][1:]).all() and it[1:].max() == cap
+        capped, st1 = it[1:] == cap, st[1:]
+        # a solve that meets the tolerances in the final check at the cap still reports "solved", as in OSQP
+        assert (st1[~capped] == 1).all() and np.isin(st1[capped], (1, 2)).all() and (st1[capped] == 2).any()
+        assert block_err(x[1:], x_ref[ks][1:]) <= 1.0, (cap, adapt)
+
+
 def tripod_params():
     """3 legs x 6 joints: the leg count and joint count no BASELINE config uses"""
     p = go1_params()
