@@ -254,6 +254,200 @@ DEKF_FN void write_measurement_record(const DevCfg& c, const DevState& s, int b,
     });
 }
 
+#if DEKF_DEVICE_BUILD
+// ---- register-resident forms for the device: one matrix column per lane, no LDS round trips ---------
+// In-place inverse of a definite N x N matrix: lane j < N holds column j in a[0..N).  Same pivot order
+// and update as winverse_definite (natural order, no search).  The loop over pivots is a real loop: after
+// each pivot the register array is rotated by one row, so that the pivot row is always a[0] (static
+// register indices) — after N pivots the rows are back in place.  The pivot column comes from lane p
+// through v_readlane (SGPR operands of the FMAs).
+template <int N>
+DEKF_FN bool gj_columns(double (&a)[N], int lane) {
+    bool ok = true;
+    for (int p = 0; p < N; ++p) {
+        const double piv = readlane_f64(a[0], p);
+        if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) { ok = false; break; }  // wave-uniform
+        const double d = 1.0 / piv;
+        const bool is_p = lane == p;
+        const double rd = (is_p ? 1.0 : a[0]) * d;  // new pivot-row entry of this column (d itself in the pivot column)
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            const double ci = readlane_f64(a[i], p);
+            a[i - 1] = fma(-ci, rd, is_p ? 0.0 : a[i]);  // pivot column: -c d; elsewhere a - c (r d)
+        }
+        a[N - 1] = rd;
+    }
+    return ok;
+}
+
+// column j (0..5) of the 6x6 process covariance G C G' of a step with rotation R (the matrix step_gains inverts)
+DEKF_FN void cov6_column(const DevCfg& c, const double* R, int j, double (&col)[6]) {
+    const double dt = c.dt;
+    const int jj = j < 3 ? j : j - 3;
+    const double* Rj = R + 3 * jj;
+    double cp[3], ca[3], ra[3];  // (R C_p R')[i][jj], (R C_a R')[i][jj], (R C_a R')[jj][i]
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        double sp = 0, sa = 0, sr = 0;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            sp += R[3 * i + t] * c.C_p[t] * Rj[t];
+            sa += R[3 * i + t] * c.C_accel[t] * Rj[t];
+            sr += Rj[t] * c.C_accel[t] * R[3 * i + t];
+        }
+        cp[i] = sp; ca[i] = sa; ra[i] = sr;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        col[i] = j < 3 ? dt * dt * cp[i] + 0.25 * dt * dt * dt * dt * ca[i] : 0.5 * dt * dt * dt * ca[i];
+        col[3 + i] = j < 3 ? 0.5 * dt * dt * dt * ra[i] : dt * dt * ca[i];
+    }
+}
+
+// entry (a, d) of a packed symmetric 3x3 (6 values) for a compile-time a and a lane-dependent d, by selects
+template <int A>
+DEKF_FN double sym3_row(const double (&q)[6], int d) {
+    constexpr int i0 = A == 0 ? 0 : (A == 1 ? 1 : 2), i1 = A == 0 ? 1 : (A == 1 ? 3 : 4), i2 = A == 0 ? 2 : (A == 1 ? 4 : 5);
+    return d == 0 ? q[i0] : (d == 1 ? q[i1] : q[i2]);
+}
+DEKF_FN double sym3_at(const double (&q)[6], int a_static, int d) {
+    return a_static == 0 ? sym3_row<0>(q, d) : (a_static == 1 ? sym3_row<1>(q, d) : sym3_row<2>(q, d));
+}
+
+// marginalize_step with the 9x9 and the (21|24)-dim inverses in registers.  sm: Minv 81 | AmMi 108 | u 24 | Min 9
+template <int L, bool VO>
+DEKF_FN bool marginalize_regs(const DevCfg& c, const DevState& s, int b, const double* r, double* sm) {
+    constexpr int NM = 3 * L, NA = VO ? 12 : 9, DIM = NA + NM;
+    const int lane = DEKF_LANE();
+    double* Mp = s.Mp + 81 * (size_t)b;
+    double* np = s.np_ + 9 * (size_t)b;
+    double* Minv = sm;
+    double* AmMi = Minv + 81;
+    double* u = AmMi + 108;
+    double* Min = u + 24;
+    const double* R = r + Rec::R;
+    const double dt = c.dt;
+    const int j = lane < DIM ? lane : DIM - 1;  // lanes beyond the matrix mirror the last column (no stores)
+    const int j9 = lane < 9 ? lane : 8;
+
+    // M^-1: lane j holds column j
+    double m9[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) m9[i] = Mp[9 * i + j9];
+    bool ok = gj_columns<9>(m9, lane);
+    if (lane < 9) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Minv[9 * i + lane] = m9[i];
+    }
+    DEKF_SYNC();
+    // row `ia` of [A_dyn; A_cam] and of Am M^-1 (lanes < NA), M^-1 n (lanes < 9)
+    const int ia = lane < NA ? lane : NA - 1;
+    double am[9], ami[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) am[t] = ia < 9 ? adyn_entry(R, dt, ia, t) : (ia - 9 == t ? 1.0 : 0.0);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        double acc = 0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc += am[q] * Minv[9 * q + t];
+        ami[t] = acc;
+    }
+    double min_own = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) min_own += Minv[9 * j9 + t] * np[t];
+    if (lane < NA) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) AmMi[9 * lane + t] = ami[t];
+    }
+    if (lane < 9) Min[lane] = min_own;
+    DEKF_SYNC();
+
+    // column j of S = -([A; H] M^-1 [A; H]' + blkdiag(Q_dyn^-1, Q_cam^-1, Q_meas^-1))
+    double a[DIM];
+    const bool dyn_col = j < NA;
+    const int cq = 3 + (dyn_col ? 0 : (j - NA) % 3);
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        double acc = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc += AmMi[9 * i + t] * am[t];
+        a[i] = dyn_col ? -acc : -AmMi[9 * i + cq];
+    }
+#pragma unroll
+    for (int q = 0; q < NM; ++q) a[NA + q] = dyn_col ? -ami[3 + q % 3] : -Minv[9 * (3 + q % 3) + cq];
+    {   // diagonal blocks
+        double col6[6];
+        cov6_column(c, R, j < 6 ? j : 5, col6);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) a[i] -= j < 6 ? col6[i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) a[6 + i] -= j == 6 + i ? 1.0 / c.Q_bias_dt2[i] : 0.0;
+        if (VO) {
+            double qi[6];
+            inv3_sym(r + Rec::QC, qi);
+            const int d = j >= 9 && j < 12 ? j - 9 : 0;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) a[9 + i] -= (j >= 9 && j < 12) ? sym3_at(qi, i, d) : 0.0;
+        }
+        const int leg = dyn_col ? 0 : (j - NA) / 3, d = dyn_col ? 0 : (j - NA) % 3;
+        double qi[6];
+        inv3_sym(r + Rec::qm(NM) + 6 * leg, qi);
+#pragma unroll
+        for (int q = 0; q < NM; ++q) a[NA + q] -= (!dyn_col && q / 3 == leg) ? sym3_at(qi, q % 3, d) : 0.0;
+    }
+    // u = [ b_dyn ; vo bound ] + Am M^-1 n   |   b_meas + H M^-1 n
+    if (lane < DIM) {
+        double v;
+        if (lane < NA) {
+            double acc = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc += am[t] * Min[t];
+            double rhs;
+            if (lane < 3) rhs = -0.5 * dt * dt * r[Rec::AS + lane];
+            else if (lane < 6) rhs = -dt * r[Rec::AS + lane - 3];
+            else if (lane < 9) rhs = 0.0;
+            else rhs = r[Rec::VOB + lane - 9];
+            v = rhs + acc;
+        } else {
+            v = r[Rec::BM + lane - NA] + Min[3 + (lane - NA) % 3];
+        }
+        u[lane] = v;
+    }
+    DEKF_SYNC();
+    ok = gj_columns<DIM>(a, lane) && ok;
+    // (S^-1 u)_j through column j (S^-1 is symmetric)
+    double yu = 0;
+#pragma unroll
+    for (int i = 0; i < DIM; ++i) yu += a[i] * u[i];
+    // M+ = -B' S^-1 B, n+ = B' S^-1 u with B = [-I9; -[I3 0] (VO); 0]: rows/columns 9..11 fold onto 0..2
+    double out[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) out[i] = a[i];
+    if (VO) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i) out[i] += a[9 + i];
+        double fold[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) fold[i] = __shfl_down(a[i], 9);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fold[i] += __shfl_down(a[9 + i], 9);
+        const double yf = __shfl_down(yu, 9);
+        if (lane < 3) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) out[i] += fold[i];
+            yu += yf;
+        }
+    }
+    if (lane < 9) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Mp[9 * i + lane] = -out[i];
+        np[lane] = -yu;
+    }
+    DEKF_SYNC();
+    return ok;
+}
+#endif  // DEKF_DEVICE_BUILD
+
 // marginalizeQP(step): fold window step `step` into (Mp, np)   (MheSrb.cpp:475-713)
 DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int step, double* sm) {
     const double* r = s.rec + ((size_t)b * c.wcap + (step % c.wcap)) * c.rec;
@@ -261,6 +455,15 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
     double* np = s.np_ + 9 * (size_t)b;
     const int nm = c.nm, L = c.L;
     const bool vo = r[Rec::VOF] != 0.0;
+#if DEKF_DEVICE_BUILD
+    switch (L) {  // wave-uniform
+        case 1: return vo ? marginalize_regs<1, true>(c, s, b, r, sm) : marginalize_regs<1, false>(c, s, b, r, sm);
+        case 2: return vo ? marginalize_regs<2, true>(c, s, b, r, sm) : marginalize_regs<2, false>(c, s, b, r, sm);
+        case 3: return vo ? marginalize_regs<3, true>(c, s, b, r, sm) : marginalize_regs<3, false>(c, s, b, r, sm);
+        case 4: return vo ? marginalize_regs<4, true>(c, s, b, r, sm) : marginalize_regs<4, false>(c, s, b, r, sm);
+        default: break;
+    }
+#endif
     const int na = vo ? 12 : 9;
     const int dim = na + nm;
     double* Minv = sm;                 // 81
@@ -379,12 +582,35 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
 DEKF_FN void assemble_update(const DevCfg& c, const DevState& s, int b, int T, int pushes, double* sm) {
     // UpdateMHE part 1: gains of step T-1 from stack.back()
     double* rprev = s.rec + ((size_t)b * c.wcap + ((T - 1) % c.wcap)) * c.rec;
+#if DEKF_DEVICE_BUILD
+    {   // step_gains with the 6x6 inverse spread over six lanes (column j of G C G' in lane j)
+        const int lane = DEKF_LANE();
+        const double* R = rprev + Rec::R;
+        double g[6];
+        cov6_column(c, R, lane < 6 ? lane : 5, g);
+        gj_columns<6>(g, lane);
+        if (lane < 6) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (i <= lane) rprev[Rec::QD + (i * (11 - i)) / 2 + lane] = g[i];  // packed upper triangle, entry (i, lane)
+        } else if (lane < 12) {
+            // Q_cam = R Q_vo R': packed entry e = lane - 6 -> (i, j)
+            const int e = lane - 6;
+            const int i = e < 3 ? 0 : (e < 5 ? 1 : 2), j = e < 3 ? e : (e < 5 ? e - 2 : 2);
+            double acc = 0;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) acc += R[3 * i + t] * c.Q_vo[t] * R[3 * j + t];
+            rprev[Rec::QC + e] = acc;
+        }
+    }
+#else
     if (DEKF_LANE() == 0) {
         double qd[21], qc[6];
         step_gains(c, rprev + Rec::R, qd, qc);
         for (int i = 0; i < 21; ++i) rprev[Rec::QD + i] = qd[i];
         for (int i = 0; i < 6; ++i) rprev[Rec::QC + i] = qc[i];
     }
+#endif
     DEKF_SYNC();
     get_measurement(c, s, b, T, pushes, sm);
     write_measurement_record(c, s, b, T);
