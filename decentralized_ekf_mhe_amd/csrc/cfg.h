@@ -48,6 +48,13 @@ struct DevCfg {
     int ekf_hist;
 };
 
+// argument block of k_latch4: up to four double arrays copied by one launch; end[i] = running element count
+struct LatchCopy4 {
+    double* dst[4];
+    const double* src[4];
+    size_t end[4];
+};
+
 // window record of step k (doubles)
 struct Rec {
     // R_sb (9) | a_s (3) | gyro (3) | Qd 6x6 sym packed (21) | Qc 3x3 sym packed (6) |

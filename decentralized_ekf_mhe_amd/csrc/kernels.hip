@@ -8,6 +8,7 @@
 //                     (mhe_solve_core.h, mhe_admm_core.h)
 //   k_kf_*            KF alternative                      (kf_core.h)
 //   k_latch_vo        masked VO latch (robotSub::vo_callback for a batch)
+//   k_latch4          device-to-device sensor latch of one push (IMU or leg arrays) in one launch
 #include <hip/hip_runtime.h>
 
 #include "cfg.h"
@@ -96,6 +97,16 @@ __global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* 
         s.ekf_vo_flag[b] = 1;
         s.ekf_vo_t[b] = t_pose[b];
         for (int i = 0; i < 4; ++i) s.ekf_vo_q[4 * (size_t)b + i] = q_vo[4 * (size_t)b + i];
+    }
+}
+
+// the device-pointer form of dekf_push_imu / dekf_push_leg: all arrays of one push in one grid-stride copy
+__global__ void __launch_bounds__(256) k_latch4(LatchCopy4 a) {
+    const size_t total = a.end[3], stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += stride) {
+        const int seg = e < a.end[0] ? 0 : (e < a.end[1] ? 1 : (e < a.end[2] ? 2 : 3));
+        const size_t off = e - (seg == 0 ? 0 : a.end[seg - 1]);
+        a.dst[seg][off] = a.src[seg][off];
     }
 }
 
