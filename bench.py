@@ -122,19 +122,37 @@ def main():
     t_gen = time.time() - t_gen
 
     est = BatchedEstimator(p, B, device=local_rank)
-    vb_all = None
+    vb_all, gather_path = None, "none"
     if world > 1 and not args.no_allgather:
-        ids = [new_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        est.comm_init(world, rank, ids[0])
+        # the estimator's own RCCL communicator (dekf_comm_init); should it fail to come up on some rank, every
+        # rank falls back to torch.distributed's communicator for the same exchange, and the line says which ran
+        ok = 1
+        try:
+            ids = [new_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            est.comm_init(world, rank, ids[0])
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] dekf_comm_init failed: {e}", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        gather_path = "dekf_allgather_vb (RCCL, second stream)" if int(flag.item()) == 1 else "torch.distributed.all_gather_into_tensor"
         vb_all = torch.empty((world, B, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
+    own_comm = gather_path.startswith("dekf")
+    vb_mine = torch.empty((B, 3), dtype=torch.float64, device=f"cuda:{local_rank}") if (vb_all is not None and not own_comm) else None
 
     def run(k0, k1):
         for k in range(k0, k1):
             est.push_stream_step(sd, k)
             est.step(k)
-            if vb_all is not None:
+            if vb_all is None:
+                continue
+            if own_comm:
                 est.allgather_vb(vb_all)
+            else:
+                est.get_into(v_b=vb_mine)
+                est.sync()
+                dist.all_gather_into_tensor(vb_all.view(world * B, 3), vb_mine)
 
     run(0, W)
     est.sync()
@@ -175,7 +193,7 @@ def main():
             "config": {"workload": "Go1, batch=4096 per GPU synthetic IMU+encoder+vision streams, 20-step MHE "
                                    "(BASELINE.json configs[1])",
                        "robot": "go1", "legs": 4, "N": int(p.N), "batch_per_gpu": B, "global_batch": world * B,
-                       "eps": 1e-6, "parallelism": f"instances sharded x{world}, RCCL all-gather of v_b per step"},
+                       "eps": 1e-6, "parallelism": f"instances sharded x{world}, RCCL all-gather of v_b per step", "allgather": gather_path},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": measured_traffic() if (B == 4096 and world == 1) else None,
