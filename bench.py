@@ -126,14 +126,20 @@ def main():
     if world > 1 and not args.no_allgather:
         # the estimator's own RCCL communicator (dekf_comm_init); should it fail to come up on some rank, every
         # rank falls back to torch.distributed's communicator for the same exchange, and the line says which ran
-        ok = 1
-        try:
-            ids = [new_unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            est.comm_init(world, rank, ids[0])
-        except Exception as e:  # noqa: BLE001
-            print(f"[rank {rank}] dekf_comm_init failed: {e}", file=sys.stderr)
-            ok = 0
+        uid, ok = None, 0
+        if rank == 0:
+            try:
+                uid = new_unique_id()
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank 0] dekf_comm_unique_id failed: {e}", file=sys.stderr)
+        ids = [uid]
+        dist.broadcast_object_list(ids, src=0)  # every rank reaches this, whatever happened on rank 0
+        if ids[0] is not None:
+            try:
+                est.comm_init(world, rank, ids[0])
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                print(f"[rank {rank}] dekf_comm_init failed: {e}", file=sys.stderr)
         flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         gather_path = "dekf_allgather_vb (RCCL, second stream)" if int(flag.item()) == 1 else "torch.distributed.all_gather_into_tensor"
