@@ -37,6 +37,20 @@ __device__ __forceinline__ double step_movdpp(double v, const double* w, double 
     a0 -= w[6] * b6; a1 -= w[7] * b7; a2 -= w[8] * b8;
     return a0 + (a1 + a2);
 }
+// broadcast the two 32-bit halves with full-rate v_mov_b32_dpp, multiply with a plain (full-rate) v_fma_f64
+#define DPP_MOV32(dst, v, T) asm volatile("v_mov_b32_dpp %0, %1 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "=v"(dst) : "v"(v))
+__device__ __forceinline__ double step_mov32dpp(double v, const double* w, double rhs) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    int l0, l1, l2, l3, l4, l5, l6, l7, l8, h0, h1, h2, h3, h4, h5, h6, h7, h8;
+    asm volatile("s_nop 1");
+    DPP_MOV32(l0, lo, 0); DPP_MOV32(h0, hi, 0); DPP_MOV32(l1, lo, 1); DPP_MOV32(h1, hi, 1); DPP_MOV32(l2, lo, 2); DPP_MOV32(h2, hi, 2);
+    DPP_MOV32(l3, lo, 3); DPP_MOV32(h3, hi, 3); DPP_MOV32(l4, lo, 4); DPP_MOV32(h4, hi, 4); DPP_MOV32(l5, lo, 5); DPP_MOV32(h5, hi, 5);
+    DPP_MOV32(l6, lo, 6); DPP_MOV32(h6, hi, 6); DPP_MOV32(l7, lo, 7); DPP_MOV32(h7, hi, 7); DPP_MOV32(l8, lo, 8); DPP_MOV32(h8, hi, 8);
+    double a0 = rhs - w[0] * __hiloint2double(h0, l0), a1 = -(w[1] * __hiloint2double(h1, l1)), a2 = -(w[2] * __hiloint2double(h2, l2));
+    a0 -= w[3] * __hiloint2double(h3, l3); a1 -= w[4] * __hiloint2double(h4, l4); a2 -= w[5] * __hiloint2double(h5, l5);
+    a0 -= w[6] * __hiloint2double(h6, l6); a1 -= w[7] * __hiloint2double(h7, l7); a2 -= w[8] * __hiloint2double(h8, l8);
+    return a0 + (a1 + a2);
+}
 // nine independent DPP products, then an addition tree (depth 1 + 4 instead of 3 + 2)
 __device__ __forceinline__ double step_dpp9(double v, const double* w, double rhs) {
     double a0 = rhs, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0, a8 = 0.0;
@@ -85,7 +99,7 @@ __global__ void __launch_bounds__(256) chain(double* out, long long* cyc, int re
         for (int s = 1; s <= STEPS; ++s) {
             const Ops& c = o[(s - 1) & 1];
             if (s < STEPS) load(s + 1, o[s & 1]);
-            v = DPP == 1 ? step_dpp(v, c.w, c.rhs) : (DPP == 2 ? step_dpp9(v, c.w, c.rhs) : (DPP == 3 ? step_movdpp(v, c.w, c.rhs) : step_readlane(v, c.w, c.rhs)));
+            v = DPP == 1 ? step_dpp(v, c.w, c.rhs) : (DPP == 2 ? step_dpp9(v, c.w, c.rhs) : (DPP == 3 ? step_movdpp(v, c.w, c.rhs) : (DPP == 4 ? step_mov32dpp(v, c.w, c.rhs) : step_readlane(v, c.w, c.rhs))));
             if (act) x[9 * s + i] = v;
         }
     }
@@ -95,22 +109,23 @@ __global__ void __launch_bounds__(256) chain(double* out, long long* cyc, int re
 }
 
 int main() {
-    double *d, h[4][256]; long long* c;
+    double *d, h[5][256]; long long* c;
     (void)hipMalloc(&d, 256 * 8); (void)hipMalloc(&c, 4 * 8);
     const size_t lds = (20 * 81 + 4 * 180) * 8;
     for (int nw = 1; nw <= 4; nw *= 4)
-        for (int dpp = 0; dpp < 4; ++dpp) {
+        for (int dpp = 0; dpp < 5; ++dpp) {
             for (int rep = 0; rep < 2; ++rep) {
                 if (dpp == 1) chain<1, 10><<<1, 64 * nw, lds>>>(d, c, 200);
                 else if (dpp == 2) chain<2, 10><<<1, 64 * nw, lds>>>(d, c, 200);
                 else if (dpp == 3) chain<3, 10><<<1, 64 * nw, lds>>>(d, c, 200);
+                else if (dpp == 4) chain<4, 10><<<1, 64 * nw, lds>>>(d, c, 200);
                 else chain<0, 10><<<1, 64 * nw, lds>>>(d, c, 200);
                 (void)hipDeviceSynchronize();
             }
             long long hc[4];
             (void)hipMemcpy(hc, c, 32, hipMemcpyDeviceToHost);
             (void)hipMemcpy(h[dpp], d, 256 * 8, hipMemcpyDeviceToHost);
-            printf("waves %d  %-10s %.1f cycles per step   v[0..2] = %.15g %.15g %.15g\n", nw, dpp == 1 ? "dpp fmac" : (dpp == 2 ? "dpp x9" : (dpp == 3 ? "mov_dpp+fma" : "readlane")), (double)hc[0] / 2000.0,
+            printf("waves %d  %-10s %.1f cycles per step   v[0..2] = %.15g %.15g %.15g\n", nw, dpp == 1 ? "dpp fmac" : (dpp == 2 ? "dpp x9" : (dpp == 3 ? "mov_dpp+fma" : (dpp == 4 ? "mov32_dpp+fma" : "readlane"))), (double)hc[0] / 2000.0,
                    h[dpp][0], h[dpp][1], h[dpp][2]);
         }
     for (int dpp = 0; dpp < 2; ++dpp) {
