@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the other BASELINE.json configurations (they are parity cases, not the bench line):
-Cassie (2 legs, 5 joints) B=4096 N=20, PogoX (1 leg) B=1024 N=100, Go1 at the 8-GPU per-rank batch 8192.
+Cassie (2 legs, 5 joints) B=4096 N=20, PogoX (1 leg) B=1024 N=100, Go1 at the 8-GPU per-rank batch 8192,
+and the Kalman-filter alternative (est_type 1).
 Same loop as bench.py (device-resident synthetic logs, steady state), one JSON line per shape."""
 import json
 import os
@@ -51,3 +52,5 @@ if __name__ == "__main__":
     run("go1 N=20, per-rank batch of the 8-GPU config", go1_params, 8192, 60)
     run("cassie N=20", cassie_params, 4096, 100)
     run("pogox N=100", pogox_params, 1024, 60)
+    run("go1 KF mode (est_type 1: recursion instead of the QP)", go1_params, 4096, 200, est_type=1)
+    run("go1 KF mode, batch 65536", go1_params, 65536, 100, est_type=1)
