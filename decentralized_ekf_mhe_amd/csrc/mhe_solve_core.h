@@ -677,23 +677,41 @@ DEKF_FN bool solve_factor(Q& q) {
         // column is -col * d.  Two wait states between the VALU write of a[i] and its DPP read: the s_nop.
 #define DEKF_GJ_DPP(acc, src, mul, PV) \
     asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:" #PV " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul))
-#define DEKF_GJ_PIVOT(PV)                                                        \
+#define DEKF_GJ_UPD(I, PV)                                                       \
+            {                                                                    \
+                double t = a[I] * keep;                                          \
+                DEKF_GJ_DPP(t, a[I], m, PV);                                     \
+                a[I] = t;                                                        \
+            }
+        // The row that holds the NEXT pivot is updated first and its reciprocal started at once, so that the
+        // v_rcp + Newton chain runs underneath the seven remaining (quarter-rate) DPP FMAs of this pivot.
+        // Own lane: base 0 through a multiplication by `keep` (one f64 multiply instead of two 32-bit selects).
+#define DEKF_GJ_PIVOT(PV, NX)                                                    \
         {                                                                        \
-            const double piv = readlane_f64(a[PV], PV);                          \
-            good = good && (fabs(piv) > 0.0) && (fabs(piv) < 1e300);             \
-            const double d = rcp_fast(piv);                                      \
             const bool own = lane == PV;                                         \
+            const double keep = own ? 0.0 : 1.0;                                 \
             const double m = own ? d : a[PV] * d;                                \
+            if (NX < 9) {                                                        \
+                DEKF_GJ_UPD(NX < 9 ? NX : 0, PV)                                 \
+                const double pn = readlane_f64(a[NX < 9 ? NX : 0], NX < 9 ? NX : 0); \
+                good = good && (fabs(pn) > 0.0) && (fabs(pn) < 1e300);           \
+                d = rcp_fast(pn);                                                \
+            }                                                                    \
             _Pragma("unroll") for (int i = 0; i < 9; ++i) {                      \
-                if (i == PV) continue;                                           \
-                double t = own ? 0.0 : a[i];                                     \
-                DEKF_GJ_DPP(t, a[i], m, PV);                                     \
-                a[i] = t;                                                        \
+                if (i == PV || i == NX) continue;                                \
+                DEKF_GJ_UPD(i, PV)                                               \
             }                                                                    \
             a[PV] = m;                                                           \
         }
-        DEKF_GJ_PIVOT(0) DEKF_GJ_PIVOT(1) DEKF_GJ_PIVOT(2) DEKF_GJ_PIVOT(3) DEKF_GJ_PIVOT(4)
-        DEKF_GJ_PIVOT(5) DEKF_GJ_PIVOT(6) DEKF_GJ_PIVOT(7) DEKF_GJ_PIVOT(8)
+        double d;
+        {
+            const double p0 = readlane_f64(a[0], 0);
+            good = good && (fabs(p0) > 0.0) && (fabs(p0) < 1e300);
+            d = rcp_fast(p0);
+        }
+        DEKF_GJ_PIVOT(0, 1) DEKF_GJ_PIVOT(1, 2) DEKF_GJ_PIVOT(2, 3) DEKF_GJ_PIVOT(3, 4) DEKF_GJ_PIVOT(4, 5)
+        DEKF_GJ_PIVOT(5, 6) DEKF_GJ_PIVOT(6, 7) DEKF_GJ_PIVOT(7, 8) DEKF_GJ_PIVOT(8, 9)
+#undef DEKF_GJ_UPD
 #undef DEKF_GJ_PIVOT
 #undef DEKF_GJ_DPP
         wave_sync();  // every lane has read its column of S
