@@ -141,7 +141,6 @@ DEKF_FN void get_measurement(const DevCfg& c, const DevState& s, int b, int T, i
     const double* quat = s.quat + 4 * (size_t)b;
     double R[9];
     quat_to_rot(quat, R);
-    const double* accel = s.accel + 3 * (size_t)b;
     int size = pushes < ring ? pushes : ring;  // entries held before this push
     int base = pushes - size;                  // logical index of the oldest one
     int flag = s.vo_flag[b];

@@ -389,7 +389,7 @@ DEKF_FN void solve_scale(Q& q) {
 template <class Q>
 DEKF_FN bool solve_factor(Q& q) {
     const DevCfg& c = q.c;
-    constexpr int L = Q::LEGS, nm = 3 * Q::LEGS;
+    constexpr int L = Q::LEGS;
     const int K = q.K;
     const auto& ix = q.ix;
     const double sigma = c.sigma, cc = q.cc;
@@ -894,7 +894,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     DEKF_PROF_MARK(q, 0);
     q.rho = dmin(dmax(c.rho0, RHO_MIN), RHO_MAX);
     // scaled bounds, cold start
-    double *x = q.x, *z = q.z, *y = q.y, *xt = q.xt, *zt = q.zt, *at = q.at;
+    double *x = q.x, *z = q.z, *y = q.y, *at = q.at;
     wfor(n + m, [&](int e) {
         if (e < n) { x[e] = 0.0; return; }
         int r = e - n, k, kind, o;
