@@ -120,6 +120,9 @@ DEKF_FN double chain_matvec_dpp(double v, const double* w, double rhs) {
 // Device: the running vector sits in registers of lanes 0..8 of the calling wavefront and is broadcast
 // inside the FMAs (chain_matvec_dpp), so the dependent chain never touches LDS or a barrier; all 64 lanes
 // execute it (lanes >= 9 mirror lane 8 and never store).  Host build: plain loops.
+#ifndef DEKF_GG_RING
+#define DEKF_GG_RING 6
+#endif
 template <bool TR, bool BWD, int STEPS = 0, class Q>
 DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
@@ -176,24 +179,24 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
             }
         }
     } else {
-        // run-time step count: a ring of four operand sets, three steps of prefetch in flight.  The compiler waits
-        // for every outstanding load at the loop back-edge, so one latency is exposed per four steps (it was per
-        // two with two sets) — what matters when W streams from the HBM slab (N = 100: 50-step legs).
-        Ops r0, r1, r2, r3;
-        if (steps >= 1) load(k0 + dk, r0);
-        if (steps >= 2) load(k0 + 2 * dk, r1);
-        if (steps >= 3) load(k0 + 3 * dk, r2);
+        // run-time step count: a ring of RING operand sets, RING - 1 steps of prefetch in flight.  The compiler waits
+        // for every outstanding load at the loop back-edge, so one latency is exposed per RING steps (it was per
+        // two with two sets).  Four sets when W sits in LDS; DEKF_GG_RING when it streams from the HBM slab
+        // (N = 100: 50-step legs, an L2/HBM round trip per back-edge).
+        constexpr int RING = Q::FACTOR_LDS ? 4 : DEKF_GG_RING;
+        Ops r[RING];
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)
+            if (steps >= u + 1) load(k0 + (u + 1) * dk, r[u]);
         int s = 1;
-        for (; s + 3 <= steps; s += 4) {
-            step(r0, r3, s, 3);
-            step(r1, r0, s + 1, 3);
-            step(r2, r1, s + 2, 3);
-            step(r3, r2, s + 3, 3);
+        for (; s + RING - 1 <= steps; s += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) step(r[u], r[(u + RING - 1) % RING], s + u, RING - 1);
         }
-        // here r0, r1, r2 hold the operands of steps s, s+1, s+2 (as far as they exist)
-        if (s <= steps) step(r0, r3, s, 4);
-        if (s + 1 <= steps) step(r1, r3, s + 1, 4);
-        if (s + 2 <= steps) step(r2, r3, s + 2, 4);
+        // here r[0 .. RING-2] hold the operands of steps s .. s+RING-2 (as far as they exist)
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)
+            if (s + u <= steps) step(r[u], r[RING - 1], s + u, RING);
     }
 #else
     double v[9], nv[9];

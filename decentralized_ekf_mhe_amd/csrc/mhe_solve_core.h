@@ -96,10 +96,11 @@ struct IdxT {
     DEKF_FN int rv(int k, int a) const { return rvb + 3 * k + a; }
 };
 
-template <int L, int NF = 0>
+template <int L, int NF = 0, bool FLDS = true>
 struct SolveCtx {
     static constexpr int LEGS = L;
     static constexpr int NFIXED = NF;  // != 0: horizon known at compile time (sweeps fully unrolled when K == NF)
+    static constexpr bool FACTOR_LDS = FLDS;  // false: W_k streams from the HBM slab (deeper operand prefetch in the sweeps)
     const DevCfg& c;
     const DevState& s;
     int b, K, kstart, n, m;
@@ -836,7 +837,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     lay.init(NH, L);
     Gws g;
     g.init(NH, L);
-    SolveCtx<L, NFIX> q{c, s, b, K, kstart, 0, 0, IdxT<L>(K)};
+    SolveCtx<L, NFIX, FACTOR_LDS> q{c, s, b, K, kstart, 0, 0, IdxT<L>(K)};
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
         double* p = lds;
         q.x = p; p += lay.n_pad;

@@ -4,7 +4,7 @@
 debug buffer only) on the bench workload and prints the share of each section.  Never quote the
 absolute time of this build; read the shares.
 
-    DEKF_LIB=decentralized_ekf_mhe_amd/csrc/libdekf_prof.so python tools/profile_sections.py
+    DEKF_LIB=decentralized_ekf_mhe_amd/csrc/libdekf_prof.so python tools/profile_sections.py [batch [ticks [go1|cassie|pogox]]]
 """
 import ctypes as C
 import json
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("DEKF_LIB", os.path.join(ROOT, "decentralized_ekf_mhe_amd", "csrc", "libdekf_prof.so"))
 
-from decentralized_ekf_mhe_amd import capi, go1_params  # noqa: E402
+from decentralized_ekf_mhe_amd import capi, cassie_params, go1_params, pogox_params  # noqa: E402
 from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_device  # noqa: E402
 from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
 
@@ -29,7 +29,8 @@ NAMES = ["0 copy R + Ruiz scaling", "1 bounds + first factorisation + restart", 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
-    p = go1_params()
+    shape = sys.argv[3] if len(sys.argv) > 3 else "go1"
+    p = {"go1": go1_params, "cassie": cassie_params, "pogox": pogox_params}[shape]()
     p.ekf_rate = p.rate
     s = make_streams(p, B, K)
     sd = streams_to_device(s)
