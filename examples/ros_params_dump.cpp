@@ -3,6 +3,8 @@
 // compares it with the Python reader).
 //   g++ -std=c++17 examples/ros_params_dump.cpp -o ros_params_dump -Ldecentralized_ekf_mhe_amd/csrc -ldekf
 #include <cstdio>
+#include <fstream>
+#include <sstream>
 
 #include "../decentralized_ekf_mhe_amd/cpp/est_node_core.hpp"
 #include "../decentralized_ekf_mhe_amd/cpp/orien_node_core.hpp"
@@ -15,9 +17,38 @@ static void row(const char* name, const double* v, int n) {
 }
 static void row(const char* name, double v) { row(name, &v, 1); }
 
+// --raw: every entry of the file as the parser sees it, "name<TAB>type<TAB>value..." (property test of the reader)
+static int dump_raw(const char* path) {
+    std::ifstream f(path);
+    std::stringstream ss;
+    ss << f.rdbuf();
+    for (const auto& kv : dekf_ros::parse_parameter_text(ss.str())) {
+        const dekf_ros::ParamValue& v = kv.second;
+        std::printf("%s\t", kv.first.c_str());
+        switch (v.type()) {
+            case dekf_ros::ParamValue::BOOL: std::printf("bool\t%d", (int)v.as_bool()); break;
+            case dekf_ros::ParamValue::INT: std::printf("int\t%ld", v.as_int()); break;
+            case dekf_ros::ParamValue::DOUBLE: std::printf("double\t%.17g", v.as_double()); break;
+            case dekf_ros::ParamValue::STRING: std::printf("string\t%s", v.as_string().c_str()); break;
+            case dekf_ros::ParamValue::DOUBLE_ARRAY:
+                std::printf("doubles");
+                for (double d : v.as_double_array()) std::printf("\t%.17g", d);
+                break;
+            case dekf_ros::ParamValue::STRING_ARRAY:
+                std::printf("strings");
+                for (const std::string& t : v.as_string_array()) std::printf("\t%s", t.c_str());
+                break;
+            default: std::printf("unset");
+        }
+        std::printf("\n");
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
-    if (argc < 2) { std::fprintf(stderr, "usage: %s params.yaml\n", argv[0]); return 2; }
+    if (argc < 2) { std::fprintf(stderr, "usage: %s [--raw] params.yaml\n", argv[0]); return 2; }
     try {
+        if (argc > 2 && std::string(argv[1]) == "--raw") return dump_raw(argv[2]);
         dekf_ros::ParamNode est = dekf_ros::ParamNode::from_file(argv[1], "est_sub");
         dekf_ros::ParamNode orien = dekf_ros::ParamNode::from_file(argv[1], "orien_sub");
         robot_params rp;

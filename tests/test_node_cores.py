@@ -147,6 +147,75 @@ def test_cpp_reader_rejects_a_wrong_type(tmp_path):
         load_ros_params(bad)
 
 
+def _emit(d, indent=0):
+    """block-style YAML text of a nested dict, with the quirks the reader has to cope with"""
+    out = []
+    pad = " " * indent
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out.append(f"{pad}{k}:")
+            out += _emit(v, indent + 2)
+        elif isinstance(v, bool):
+            out.append(f"{pad}{k}: {'true' if v else 'false'}")
+        elif isinstance(v, list):
+            items = ", ".join(repr(x) for x in v)
+            if len(v) > 3:   # a sequence that starts on the next line and is broken in the middle
+                half = len(v) // 2
+                out.append(f"{pad}{k}:   # comment after the key")
+                out.append(f"{pad}  [{', '.join(repr(x) for x in v[:half])},")
+                out.append(f"{pad}   {', '.join(repr(x) for x in v[half:])}]")
+            else:
+                out.append(f"{pad}{k}: [{items}]  # trailing comment")
+        elif isinstance(v, str):
+            out.append(f'{pad}{k}: "{v}"')
+        else:
+            out.append(f"{pad}{k}: {v!r}")
+    return out
+
+
+def test_cpp_reader_agrees_with_pyyaml_on_generated_files(tmp_path):
+    """property test of the hand-written reader: random nested parameter files, every leaf compared with PyYAML"""
+    import yaml
+    from hypothesis import HealthCheck, given, settings, strategies as st
+    exe = _build(tmp_path, "ros_params_dump")
+    reserved = {"null", "true", "false", "yes", "no", "on", "off", "y", "n"}  # YAML 1.1 gives these a type of their own
+    names = st.text(alphabet="abcdefghijklmnopqrstuvwxyz_", min_size=1, max_size=8).filter(lambda t: t not in reserved)
+    floats = st.floats(allow_nan=False, allow_infinity=False, width=64).filter(lambda x: x == 0 or 1e-300 < abs(x) < 1e300)
+    leaves = st.one_of(st.booleans(), st.integers(-10**9, 10**9), floats,
+                       st.text(alphabet="abcdefghijklmnopqrstuvwxyz /#:-", min_size=1, max_size=12).filter(lambda t: t.strip() == t),
+                       st.lists(floats, min_size=1, max_size=9))
+    trees = st.recursive(st.dictionaries(names, leaves, min_size=1, max_size=4),
+                         lambda inner: st.dictionaries(names, st.one_of(leaves, inner), min_size=1, max_size=4), max_leaves=12)
+    path = tmp_path / "gen.yaml"
+
+    def flat(d, prefix=""):
+        for k, v in d.items():
+            if isinstance(v, dict):
+                yield from flat(v, prefix + k + ".")
+            else:
+                yield prefix + k, v
+
+    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @given(trees)
+    def check(tree):
+        text = "\n".join(_emit({"node": {"ros__parameters": tree}})) + "\n"
+        assert dict(flat(yaml.safe_load(text))) == dict(flat({"node": {"ros__parameters": tree}}))  # the emitter is sound
+        path.write_text(text)
+        r = subprocess.run([exe, "--raw", str(path)], capture_output=True, text=True)
+        assert r.returncode == 0, (r.stderr, text)
+        got = {}
+        for line in r.stdout.splitlines():
+            name, typ, *vals = line.split("\t")
+            got[name] = {"bool": lambda: bool(int(vals[0])), "int": lambda: int(vals[0]), "double": lambda: float(vals[0]),
+                         "string": lambda: vals[0], "doubles": lambda: [float(v) for v in vals]}[typ]()
+        want = dict(flat({"node": {"ros__parameters": tree}}))
+        assert got.keys() == want.keys(), text
+        for k, v in want.items():
+            assert got[k] == v and type(got[k]) is type(v) or (isinstance(v, list) and got[k] == [float(x) for x in v]), (k, v, got[k], text)
+
+    check()
+
+
 @pytest.mark.skipif(not os.path.exists(REF_YAML), reason="reference not mounted")
 def test_reference_go1_file_gives_go1_params(tmp_path):
     p, node = load_ros_params(REF_YAML)
