@@ -210,7 +210,7 @@ def main():
                        "solved_frac": solved, "max_abs_v_err_vs_truth": v_err},
             "stream_gen_s": t_gen,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only (rank 0's host cores, same run)
             line["cpu_baseline"] = cpu_baseline(p, min(W + K, 150), seed_first=0)
         print(json.dumps(line))
     est.close()
