@@ -912,16 +912,21 @@ DEKF_FN void phase_sweeps_rows(Q& q, double alpha, double sigma) {
             const int w = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), lane = DEKF_LANE() & 63;
             RowTile t;
             t.kind = -1;
+            // With at most three tiles (one Meas tile: 2 legs) the three waiting wavefronts take them all and
+            // prefetch while the solve runs; with four (Go1) the solve wavefront does the first Meas tile behind
+            // its solve, unprefetched (folding the fourth tile into another wavefront was slower: DESIGN.md §7).
+            constexpr bool spare = ((NF * L + 63) >> 6) + 2 * ((2 * (NF - 1) + 63) >> 6) <= 3;
+            const int tile = spare ? w - 1 : w;
             if (w == 0) {
                 __builtin_amdgcn_s_setprio(3);
                 sweeps_one_wave<NF>(q, alpha);
                 __builtin_amdgcn_s_setprio(0);
-            } else if (w < ntiles) {
-                row_tile_load(q, w, lane, t);
+            } else if (tile < ntiles) {
+                row_tile_load(q, tile, lane, t);
             }
             DEKF_SYNC();
             DEKF_PROF_MARK(q, 5);
-            if (w == 0) row_tile_load(q, 0, lane, t);
+            if (!spare && w == 0) row_tile_load(q, 0, lane, t);
             row_tile_finish(q, t, alpha, sigma);
             DEKF_SYNC();
             return;
