@@ -1,0 +1,34 @@
+"""bench.py's output contract (one JSON line with the driver's keys, `roofline` and `cpu_baseline`), checked on a
+small batch so that it runs in seconds on the GPU box."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_bench_line_has_the_contract_fields():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "256", "--steps", "8", "--warmup", "24"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 24 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["dtype"] == "f64" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] in ("hbm", "mfma") and rf["unit"] == "GB/s" and rf["peak"] > 0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["value"] > 0 and d["solver"]["solved_frac"] == 1.0
+    # value = instances x steps / elapsed
+    assert abs(d["value"] - 256 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6
