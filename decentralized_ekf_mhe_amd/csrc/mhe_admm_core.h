@@ -69,6 +69,9 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
     const double* qsl = q.tmp + 162;
     const double* at = q.at;
     auto w = [&](int r) { return at[r]; };
+#if defined(DEKF_PROFILE_TL) && defined(DEKF_PROFILE_TLX)  // -DDEKF_PROFILE_TLX: slots 4.. and 8.. describe phase X instead of the row phase
+    const long long tx0 = clock64();
+#endif
     wtiles(3 * nt, [&](int tile, int lane) {
         const int kind = tile < nt ? 0 : (tile < 2 * nt ? 1 : 2);
         const int e = (tile - kind * nt) * 64 + lane;
@@ -86,7 +89,15 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
         }
         q.xs[9 * k + j] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
     });
+#if defined(DEKF_PROFILE_TL) && defined(DEKF_PROFILE_TLX)
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long tx1 = clock64();
+    DEKF_TL_ADD(q, 4 + (DEKF_LANE() >> 6), tx0, tx1);
+#endif
     DEKF_SYNC();
+#if defined(DEKF_PROFILE_TL) && defined(DEKF_PROFILE_TLX)
+    DEKF_TL_ADD(q, 8 + (DEKF_LANE() >> 6), tx1, clock64());
+#endif
 }
 
 // ---------------------------------------------------------------- S: block-tridiagonal solve
@@ -915,6 +926,9 @@ DEKF_FN void phase_sweeps_rows(Q& q, double alpha, double sigma) {
             const int w = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), lane = DEKF_LANE() & 63;
             RowTile t;
             t.kind = -1;
+#if defined(DEKF_PROFILE_TL)
+            const long long tl0 = clock64();
+#endif
             // With at most three tiles (one Meas tile: 2 legs) the three waiting wavefronts take them all and
             // prefetch while the solve runs; with four (Go1) the solve wavefront does the first Meas tile behind
             // its solve, unprefetched (folding the fourth tile into another wavefront was slower: DESIGN.md §7).
@@ -927,11 +941,28 @@ DEKF_FN void phase_sweeps_rows(Q& q, double alpha, double sigma) {
             } else if (tile < ntiles) {
                 row_tile_load(q, tile, lane, t);
             }
+#if defined(DEKF_PROFILE_TL)
+            const long long tl1 = clock64();
+            DEKF_TL_ADD(q, w, tl0, tl1);
+#endif
             DEKF_SYNC();
             DEKF_PROF_MARK(q, 5);
+#if defined(DEKF_PROFILE_TL)
+            const long long tl2 = clock64();
+#endif
             if (!spare && w == 0) row_tile_load(q, 0, lane, t);
             row_tile_finish(q, t, alpha, sigma);
+#if defined(DEKF_PROFILE_TL)
+            __builtin_amdgcn_s_waitcnt(0);  // the tile's stores have left the wavefront
+            const long long tl3 = clock64();
+#if !defined(DEKF_PROFILE_TLX)
+            DEKF_TL_ADD(q, 4 + w, tl2, tl3);
+#endif
+#endif
             DEKF_SYNC();
+#if defined(DEKF_PROFILE_TL) && !defined(DEKF_PROFILE_TLX)
+            DEKF_TL_ADD(q, 8 + w, tl3, clock64());
+#endif
             return;
         }
     }

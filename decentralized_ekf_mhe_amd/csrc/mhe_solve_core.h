@@ -35,7 +35,19 @@ namespace dekf {
 
 // Section stamps for the DIAGNOSTIC build only (-DDEKF_PROFILE -> libdekf_prof.so); the product
 // kernel executes none of this.  Stamp values go to DevState::prof and nowhere else.
-#if defined(DEKF_PROFILE) && DEKF_DEVICE_BUILD
+// -DDEKF_PROFILE_TL (with -DDEKF_PROFILE): instead of the section stamps, every wavefront of an instance adds up
+// three intervals of the fixed-horizon iteration (tools/profile_sections.py --timeline):
+//   prof[w]      solve (w = 0) / row-tile prefetch (w > 0) until the wavefront reaches the barrier behind the solve
+//   prof[4 + w]  its row-tile work behind that barrier
+//   prof[8 + w]  its wait at the barrier that ends the row phase
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_TL) && DEKF_DEVICE_BUILD
+#define DEKF_PROF_MARK(q, sec) ((void)0)
+#define DEKF_TL_ADD(q, slot, t0, t1)                                            \
+    do {                                                                        \
+        if ((DEKF_LANE() & 63) == 0) (q).prof[slot] += (double)((t1) - (t0));   \
+    } while (0)
+#elif defined(DEKF_PROFILE) && DEKF_DEVICE_BUILD
+#define DEKF_TL_ADD(q, slot, t0, t1) ((void)0)
 #define DEKF_PROF_MARK(q, sec)                                                  \
     do {                                                                        \
         if (DEKF_LANE() == 0) {                                                 \
@@ -46,6 +58,7 @@ namespace dekf {
     } while (0)
 #else
 #define DEKF_PROF_MARK(q, sec) ((void)0)
+#define DEKF_TL_ADD(q, slot, t0, t1) ((void)0)
 #endif
 
 // The meeting block of the two-sided block-tridiagonal factorisation / solve.  (K - 1) / 2 makes the

@@ -5,6 +5,7 @@ debug buffer only) on the bench workload and prints the share of each section.  
 absolute time of this build; read the shares.
 
     DEKF_LIB=decentralized_ekf_mhe_amd/csrc/libdekf_prof.so python tools/profile_sections.py [batch [ticks [go1|cassie|pogox]]]
+    DEKF_TIMELINE=1 DEKF_LIB=.../libdekf_tl.so python tools/profile_sections.py 4096 70   # -DDEKF_PROFILE -DDEKF_PROFILE_TL
 """
 import ctypes as C
 import json
@@ -45,6 +46,19 @@ def main():
     capi.check(lib.dekf_debug_sections(est.h, C.c_void_p(out.ctypes.data)))
     info = est.solver_info()
     mean = out.mean(axis=0)
+    if os.environ.get("DEKF_TIMELINE"):
+        # library built with -DDEKF_PROFILE -DDEKF_PROFILE_TL (csrc/libdekf_tl.so): per-wavefront intervals of the
+        # fixed-horizon iteration, summed over the iterations of the last solve
+        it = float(info["iters"].mean())
+        print(f"iterations {it:.1f}; cycles per iteration and wavefront (w0 runs the solve)")
+        for name, base in (("solve | tile prefetch, up to the barrier", 0), ("row-tile work behind the barrier", 4),
+                           ("wait at the barrier that ends the row phase", 8)):
+            print(f"  {name:46s}" + "".join(f"  w{w}: {mean[base + w] / it:7.0f}" for w in range(4)))
+        print(json.dumps({"batch": B, "T": K - 1, "mean_iters": it, "per_iteration_cycles": {
+            "to_barrier": [mean[w] / it for w in range(4)], "row_work": [mean[4 + w] / it for w in range(4)],
+            "row_barrier_wait": [mean[8 + w] / it for w in range(4)]}}))
+        est.close()
+        return
     tot = mean[13]
     res = {"batch": B, "T": K - 1, "mean_iters": float(info["iters"].mean()), "mean_rho_updates": float(info["rho_updates"].mean()),
            "total_cycles_mean": tot, "sections": {}}
