@@ -195,11 +195,21 @@ def test_cpp_reader_agrees_with_pyyaml_on_generated_files(tmp_path):
             else:
                 yield prefix + k, v
 
-    @settings(max_examples=60, deadline=None, suppress_health_check=list(HealthCheck))
+    @settings(max_examples=120, deadline=None, derandomize=True, database=None, suppress_health_check=list(HealthCheck))
     @given(trees)
     def check(tree):
         text = "\n".join(_emit({"node": {"ros__parameters": tree}})) + "\n"
-        assert dict(flat(yaml.safe_load(text))) == dict(flat({"node": {"ros__parameters": tree}}))  # the emitter is sound
+        # the emitter is sound (PyYAML follows YAML 1.1 and reads a float without a dot, `1e-05`, as a string; ROS2's
+        # own reader and ours read a number)
+        def num(y, v):
+            if isinstance(v, float) and isinstance(y, str):
+                return float(y)
+            if isinstance(v, list) and isinstance(y, list):
+                return [num(a, b) for a, b in zip(y, v)]
+            return y
+        truth = dict(flat({"node": {"ros__parameters": tree}}))
+        loaded = dict(flat(yaml.safe_load(text)))
+        assert {k: num(loaded[k], v) for k, v in truth.items()} == truth and loaded.keys() == truth.keys()
         path.write_text(text)
         r = subprocess.run([exe, "--raw", str(path)], capture_output=True, text=True)
         assert r.returncode == 0, (r.stderr, text)
