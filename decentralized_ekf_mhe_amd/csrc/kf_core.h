@@ -6,6 +6,7 @@
 #include "cfg.h"
 #include "mhe_assemble_core.h"
 #include "smallmat.h"
+#include <type_traits>
 
 namespace dekf {
 
@@ -72,7 +73,36 @@ DEKF_FN void kf_correct(const DevCfg& c, const DevState& s, int b, const double*
         if (i / 3 == j / 3) v += symget(r + Rec::qm(nm) + 6 * (i / 3), i % 3, j % 3, 3);
         S[e] = v;
     });
+#if DEKF_DEVICE_BUILD
+    // H C H' + C_meas is symmetric positive definite: the register-resident Gauss-Jordan of the assemble kernel (one
+    // column per lane, no pivot search) instead of the LDS sweep with pivot search
+    {
+        const int lane = DEKF_LANE();
+        auto invert = [&](auto tag) {
+            constexpr int NMC = decltype(tag)::value;
+            const int j = lane < NMC ? lane : NMC - 1;
+            double a[NMC];
+#pragma unroll
+            for (int i = 0; i < NMC; ++i) a[i] = S[i * NMC + j];
+            gj_columns<NMC>(a, lane);
+            DEKF_SYNC();
+            if (lane < NMC) {
+#pragma unroll
+                for (int i = 0; i < NMC; ++i) S[i * NMC + lane] = a[i];
+            }
+            DEKF_SYNC();
+        };
+        switch (c.L) {  // wave-uniform
+            case 1: invert(std::integral_constant<int, 3>()); break;
+            case 2: invert(std::integral_constant<int, 6>()); break;
+            case 3: invert(std::integral_constant<int, 9>()); break;
+            case 4: invert(std::integral_constant<int, 12>()); break;
+            default: winverse(S, nm, wsc, true);
+        }
+    }
+#else
     winverse(S, nm, wsc, true);
+#endif
     wfor(9 * nm, [&](int e) {
         int i = e / nm, j = e - nm * i;
         double acc = 0;
