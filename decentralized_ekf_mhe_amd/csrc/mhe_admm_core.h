@@ -75,10 +75,6 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
     wtiles(3 * nt, [&](int tile, int lane) {
         const int kind = tile < nt ? 0 : (tile < 2 * nt ? 1 : 2);
         const int e = (tile - kind * nt) * 64 + lane;
-#if DEKF_DEVICE_BUILD
-        // the velocity columns gather the most rows (every leg's Meas rows): the longest tile of this phase gets priority
-        if (kind == 1) __builtin_amdgcn_s_setprio(2);
-#endif
         if (e >= n3) return;
         const int k = e / 3, a = e - 3 * k, j = 3 * kind + a, i = k * SV + j;
         const double xv = q.x[i], dv = q.D[i], qv = qsl[j];
@@ -93,9 +89,6 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
         }
         q.xs[9 * k + j] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
     });
-#if DEKF_DEVICE_BUILD
-    __builtin_amdgcn_s_setprio(0);
-#endif
 #if defined(DEKF_PROFILE_TL) && defined(DEKF_PROFILE_TLX)
     __builtin_amdgcn_s_waitcnt(0);
     const long long tx1 = clock64();
