@@ -34,89 +34,93 @@ inline void QuaternionToEuler(const Quaterniond& q, Vector3d& euler) {
 
 namespace robotSub {
 
-// EstSub.cpp:123-208.  `Node` is anything with rclcpp::Node's declare_parameter / get_parameter:
-// dekf_ros::ParamNode (ros_params.hpp) or the rclcpp::Node itself.
+// The est_sub parameter set (names and declared defaults: EstSub.cpp:123-208) as tables of
+// (parameter name, default, robot_params member); `Node` is anything with rclcpp::Node's
+// declare_parameter / get_parameter: dekf_ros::ParamNode (ros_params.hpp) or the rclcpp::Node itself.
+namespace param_tables {
+using V = std::vector<double>;
+struct VecEntry { const char* name; V def; V robot_params::*member; };
+struct NumEntry { const char* name; double def; double robot_params::*member; };
+struct IntEntry { const char* name; int def; int robot_params::*member; };
+struct FlagEntry { const char* name; bool def; bool robot_params::*member; };
+inline const std::vector<VecEntry>& vectors() {
+    static const std::vector<VecEntry> t = {
+        {"prior.p_init_std", V(3, 0.001), &robot_params::p_init_std_},
+        {"prior.v_init_std", V(3, 0.001), &robot_params::v_init_std_},
+        {"prior.foot_init_std", V(3, 0.001), &robot_params::foot_init_std_},
+        {"prior.accel_bias_init_std", V(3, 0.001), &robot_params::accel_bias_init_std_},
+        {"process.p_process_std", V(3, 0.01), &robot_params::p_process_std_},
+        {"process.accel_input_std", V{0.01, 0.04, 0.001}, &robot_params::accel_input_std_},
+        {"process.gyro_input_std", V(3, 0.01), &robot_params::gyro_input_std_},
+        {"process.accel_bias_process_std", V{1.0, 1.0, 0.1}, &robot_params::accel_bias_std_},
+        {"leg_odom.quaternion_ib", V{1.0, 0.0, 0.0, 0.0}, &robot_params::quaternion_ib_},
+        {"leg_odom.p_ib", V(3, 0.0), &robot_params::p_ib_},
+        {"leg_odom.joint_position_std", V(3, 0.01), &robot_params::joint_position_std_},
+        {"leg_odom.joint_velocity_std", V(3, 0.01), &robot_params::joint_velocity_std_},
+        {"leg_odom.foot_slide_std", V(3, 0.001), &robot_params::foot_slide_std_},
+        {"leg_odom.foot_swing_std", V(3, 10000.0), &robot_params::foot_swing_std_},
+        {"visual_odom.vo_p_std", V(3, 0.001), &robot_params::vo_p_std_},
+    };
+    return t;
+}
+inline const std::vector<NumEntry>& numbers() {
+    static const std::vector<NumEntry> t = {
+        {"leg_odom.contact_effort_theshold", 150.0, &robot_params::contact_effort_theshold_},
+        {"osqp.rho", 0.1, &robot_params::rho_},
+        {"osqp.alpha", 1.6, &robot_params::alpha_},
+        {"osqp.delta", 0.00001, &robot_params::delta_},
+        {"osqp.sigma", 0.00001, &robot_params::sigma_},
+        {"osqp.primTol", 0.000001, &robot_params::primTol_},
+        {"osqp.dualTol", 0.000001, &robot_params::dualTol_},
+        {"osqp.realtiveTol", 1e-3, &robot_params::realtiveTol_},
+        {"osqp.absTol", 1e-3, &robot_params::absTol_},
+        {"osqp.timeLimit", 0.005, &robot_params::timeLimit_},
+    };
+    return t;
+}
+inline const std::vector<IntEntry>& integers() {
+    static const std::vector<IntEntry> t = {
+        {"leg_odom.num_leg", 4, &robot_params::num_legs_},
+        {"leg_odom.leg_odom_type", 0, &robot_params::leg_odom_type_},
+        {"estimation.rate", 50, &robot_params::rate_},
+        {"estimation.N", 50, &robot_params::N_},
+        {"estimation.est_type", 0, &robot_params::est_type_},
+        {"osqp.maxQPIter", 1000, &robot_params::maxQPIter_},
+    };
+    return t;
+}
+inline const std::vector<FlagEntry>& flags() {
+    static const std::vector<FlagEntry> t = {
+        {"osqp.verbose", true, &robot_params::verbose_},
+        {"osqp.adaptRho", true, &robot_params::adaptRho_},
+        {"osqp.polish", true, &robot_params::polish_},
+    };
+    return t;
+}
+}  // namespace param_tables
+
 template <class Node>
 void paramsWrapper(Node& node, robot_params& rp, std::string& log_name, int& timer_interval_ms) {
-    using V = std::vector<double>;
     node.declare_parameter("log_name", std::string("exp"));
     log_name = node.get_parameter("log_name").as_string();
-
-    node.declare_parameter("prior.p_init_std", V{0.001, 0.001, 0.001});
-    node.declare_parameter("prior.v_init_std", V{0.001, 0.001, 0.001});
-    node.declare_parameter("prior.foot_init_std", V{0.001, 0.001, 0.001});
-    node.declare_parameter("prior.accel_bias_init_std", V{0.001, 0.001, 0.001});
-    rp.p_init_std_ = node.get_parameter("prior.p_init_std").as_double_array();
-    rp.v_init_std_ = node.get_parameter("prior.v_init_std").as_double_array();
-    rp.foot_init_std_ = node.get_parameter("prior.foot_init_std").as_double_array();
-    rp.accel_bias_init_std_ = node.get_parameter("prior.accel_bias_init_std").as_double_array();
-
-    node.declare_parameter("process.p_process_std", V{0.01, 0.01, 0.01});
-    node.declare_parameter("process.accel_input_std", V{0.01, 0.04, 0.001});
-    node.declare_parameter("process.gyro_input_std", V{0.01, 0.01, 0.01});
-    node.declare_parameter("process.accel_bias_process_std", V{1., 1., 0.1});
-    rp.p_process_std_ = node.get_parameter("process.p_process_std").as_double_array();
-    rp.accel_input_std_ = node.get_parameter("process.accel_input_std").as_double_array();
-    rp.gyro_input_std_ = node.get_parameter("process.gyro_input_std").as_double_array();
-    rp.accel_bias_std_ = node.get_parameter("process.accel_bias_process_std").as_double_array();
-
-    node.declare_parameter("leg_odom.quaternion_ib", V{1.0, 0.0, 0.0, 0.0});
-    node.declare_parameter("leg_odom.p_ib", V{0.0, 0.0, 0.0});
-    node.declare_parameter("leg_odom.num_leg", 4);
-    node.declare_parameter("leg_odom.leg_odom_type", 0);
-    node.declare_parameter("leg_odom.joint_position_std", V{0.01, 0.01, 0.01});
-    node.declare_parameter("leg_odom.joint_velocity_std", V{0.01, 0.01, 0.01});
-    node.declare_parameter("leg_odom.foot_slide_std", V{0.001, 0.001, 0.001});
-    node.declare_parameter("leg_odom.foot_swing_std", V{10000.0, 10000.0, 10000.0});
-    node.declare_parameter("leg_odom.contact_effort_theshold", 150.0);
-    rp.quaternion_ib_ = node.get_parameter("leg_odom.quaternion_ib").as_double_array();
-    rp.p_ib_ = node.get_parameter("leg_odom.p_ib").as_double_array();
-    rp.num_legs_ = (int)node.get_parameter("leg_odom.num_leg").as_int();
-    rp.leg_odom_type_ = (int)node.get_parameter("leg_odom.leg_odom_type").as_int();
-    rp.joint_position_std_ = node.get_parameter("leg_odom.joint_position_std").as_double_array();
-    rp.joint_velocity_std_ = node.get_parameter("leg_odom.joint_velocity_std").as_double_array();
-    rp.foot_slide_std_ = node.get_parameter("leg_odom.foot_slide_std").as_double_array();
-    rp.foot_swing_std_ = node.get_parameter("leg_odom.foot_swing_std").as_double_array();
-    rp.contact_effort_theshold_ = node.get_parameter("leg_odom.contact_effort_theshold").as_double();
-
-    node.declare_parameter("visual_odom.vo_p_std", V{0.001, 0.001, 0.001});
-    rp.vo_p_std_ = node.get_parameter("visual_odom.vo_p_std").as_double_array();
-
-    node.declare_parameter("estimation.rate", 50);
-    node.declare_parameter("estimation.interval", 20);
-    node.declare_parameter("estimation.N", 50);
-    node.declare_parameter("estimation.est_type", 0);
-    rp.rate_ = (int)node.get_parameter("estimation.rate").as_int();
+    node.declare_parameter("estimation.interval", 20);  // period of the node's wall timer, ms
     timer_interval_ms = (int)node.get_parameter("estimation.interval").as_int();
-    rp.N_ = (int)node.get_parameter("estimation.N").as_int();
-    rp.est_type_ = (int)node.get_parameter("estimation.est_type").as_int();
-
-    node.declare_parameter("osqp.rho", 0.1);
-    node.declare_parameter("osqp.alpha", 1.6);
-    node.declare_parameter("osqp.delta", 0.00001);
-    node.declare_parameter("osqp.sigma", 0.00001);
-    node.declare_parameter("osqp.verbose", true);
-    node.declare_parameter("osqp.adaptRho", true);
-    node.declare_parameter("osqp.polish", true);
-    node.declare_parameter("osqp.maxQPIter", 1000);
-    node.declare_parameter("osqp.primTol", 0.000001);
-    node.declare_parameter("osqp.dualTol", 0.000001);
-    node.declare_parameter("osqp.realtiveTol", 1e-3);
-    node.declare_parameter("osqp.absTol", 1e-3);
-    node.declare_parameter("osqp.timeLimit", 0.005);
-    rp.rho_ = node.get_parameter("osqp.rho").as_double();
-    rp.alpha_ = node.get_parameter("osqp.alpha").as_double();
-    rp.delta_ = node.get_parameter("osqp.delta").as_double();
-    rp.sigma_ = node.get_parameter("osqp.sigma").as_double();
-    rp.verbose_ = node.get_parameter("osqp.verbose").as_bool();
-    rp.adaptRho_ = node.get_parameter("osqp.adaptRho").as_bool();
-    rp.polish_ = node.get_parameter("osqp.polish").as_bool();
-    rp.maxQPIter_ = (int)node.get_parameter("osqp.maxQPIter").as_int();
-    rp.primTol_ = node.get_parameter("osqp.primTol").as_double();
-    rp.dualTol_ = node.get_parameter("osqp.dualTol").as_double();
-    rp.realtiveTol_ = node.get_parameter("osqp.realtiveTol").as_double();
-    rp.absTol_ = node.get_parameter("osqp.absTol").as_double();
-    rp.timeLimit_ = node.get_parameter("osqp.timeLimit").as_double();
+    for (const auto& e : param_tables::vectors()) {
+        node.declare_parameter(e.name, e.def);
+        rp.*(e.member) = node.get_parameter(e.name).as_double_array();
+    }
+    for (const auto& e : param_tables::numbers()) {
+        node.declare_parameter(e.name, e.def);
+        rp.*(e.member) = node.get_parameter(e.name).as_double();
+    }
+    for (const auto& e : param_tables::integers()) {
+        node.declare_parameter(e.name, e.def);
+        rp.*(e.member) = (int)node.get_parameter(e.name).as_int();
+    }
+    for (const auto& e : param_tables::flags()) {
+        node.declare_parameter(e.name, e.def);
+        rp.*(e.member) = node.get_parameter(e.name).as_bool();
+    }
 }
 
 class EstNodeCore {
