@@ -44,8 +44,13 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
 // the leg count is a compile-time constant of each instantiation.  The second launch bound (2 waves
 // per SIMD) caps VGPR+AGPR at 256 so that TWO workgroups stay resident per CU — LDS allows exactly
 // two, and at 260 registers the kernel silently dropped to one (2x slower).
+// DEKF_SOLVE_MIN_WAVES: wavefronts per SIMD the generic instantiations are compiled for (2 -> 256 VGPRs; the
+// residency experiment in DESIGN.md §8 builds them with 3 -> 168 VGPRs)
+#ifndef DEKF_SOLVE_MIN_WAVES
+#define DEKF_SOLVE_MIN_WAVES 2
+#endif
 #define DEKF_SOLVE_KERNEL(NAME, LEGS, FL, PL)                                                            \
-    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) NAME(DevCfg c, DevState s, int kstart, int K, \
+    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_SOLVE_MIN_WAVES) NAME(DevCfg c, DevState s, int kstart, int K, \
                                                                   int gws_len) {                         \
         extern __shared__ double lds[];                                                                  \
         double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                              \
