@@ -114,10 +114,16 @@ def main():
     p = go1_params()
     p.ekf_rate = p.rate  # one EKF tick per estimator-step, so its dt is the step
     B, W, K = args.batch, args.warmup, args.steps
-    assert W >= p.N + 1, "warm-up must fill the window (steady state starts at T = N)"
+    # The metric is quoted at steady state: full window AND visual-odometry intervals active (from about tick 40 on the
+    # solves need 75 ADMM iterations instead of 50).  The default warm-up of 50 steps covers that; if the caller asks for
+    # fewer, the missing ticks run as untimed SETUP in front of the W warm-up steps, so that the timed region is always
+    # exactly K steps of the same steady state.
+    STEADY_FROM = 50
+    assert STEADY_FROM >= p.N + 1
+    fill = max(0, STEADY_FROM - W)
 
     t_gen = time.time()
-    s = make_streams(p, B, W + K, first_instance=rank * B)
+    s = make_streams(p, B, fill + W + K, first_instance=rank * B)
     sd = streams_to_device(s, device=f"cuda:{local_rank}")
     t_gen = time.time() - t_gen
 
@@ -160,14 +166,15 @@ def main():
                 est.sync()
                 dist.all_gather_into_tensor(vb_all.view(world * B, 3), vb_mine)
 
-    run(0, W)
+    run(0, fill)      # window fill that the requested warm-up does not cover (0 with the defaults)
+    run(fill, fill + W)
     est.sync()
     est.timing_enable(True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    run(W, W + K)
+    run(fill + W, fill + W + K)
     est.sync()
     torch.cuda.synchronize()
     if world > 1:
@@ -184,7 +191,7 @@ def main():
     out = est.get()
     info = est.solver_info()
     solved = float((out["status"] == 1).mean())
-    v_err = float(np.abs(out["x"][:, 3:6] - s["gt_v_s"][W + K - 1]).max())
+    v_err = float(np.abs(out["x"][:, 3:6] - s["gt_v_s"][fill + W + K - 1]).max())
 
     if rank == 0:
         value = world * B * K / elapsed
@@ -193,7 +200,7 @@ def main():
         achieved = B_ALG_GO1 * B / avg_solve_s / 1e9
         line = {
             "metric": "estimator-steps/sec (EKF+MHE, 20-step window)",
-            "value": value, "unit": "estimator-steps/s", "n_gpus": world, "steps": K, "warmup": W,
+            "value": value, "unit": "estimator-steps/s", "n_gpus": world, "steps": K, "warmup": W, "window_fill_steps_before_warmup": fill,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "Go1, batch=4096 per GPU synthetic IMU+encoder+vision streams, 20-step MHE "
@@ -211,7 +218,7 @@ def main():
             "stream_gen_s": t_gen,
         }
         if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only (rank 0's host cores, same run)
-            line["cpu_baseline"] = cpu_baseline(p, min(W + K, 150), seed_first=0)
+            line["cpu_baseline"] = cpu_baseline(p, min(fill + W + K, 150), seed_first=0)
         print(json.dumps(line))
     est.close()
     if world > 1:
