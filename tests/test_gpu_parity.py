@@ -219,6 +219,59 @@ def test_large_batch_properties():
     assert v_err < 0.45 and o["x"][:64, 3].mean() > 0.15, v_err
 
 
+def test_time_shift_invariance_at_full_batch():
+    """size-independent property at the BASELINE batch: every time stamp (IMU, VO frame pairs, VO pose) enters the
+    estimator only through comparisons and differences, so shifting all of them by a constant must not change the
+    estimates beyond the rounding of the shifted stamps (exactly representable offset: 64 s)"""
+    p = _params(go1_params)
+    B, K = 4096, 60
+    s = make_streams(p, B, K)
+    shifted = dict(s)
+    for key in ("imu_t", "vo_t_pre", "vo_t_now", "vo_t_pose"):
+        shifted[key] = s[key] + 64.0
+    outs = []
+    for streams in (s, shifted):
+        est = BatchedEstimator(p, B)
+        sd = streams_to_device(streams)
+        for k in range(K):
+            est.push_stream_step(sd, k)
+            est.step(k)
+        outs.append(est.get())
+        est.close()
+    a, b = outs
+    assert (a["status"] == 1).all() and (b["status"] == 1).all()
+    assert np.abs(a["quat"] - b["quat"]).max() < 1e-9
+    assert block_err(b["x"], a["x"]) <= 1.0
+
+
+def test_leg_relabelling_and_instance_permutation():
+    """two more properties that need no oracle: renumbering the legs (the estimator does not know which foot is which)
+    changes the estimate only by the rounding of a reordered sum, and permuting the instances of a batch permutes the
+    results bit for bit"""
+    p = _params(go1_params)
+    B, K = 512, 55
+    s = make_streams(p, B, K)
+    legs = [2, 0, 3, 1]
+    relabelled = dict(s)
+    for key in ("p_foot", "J", "qdot", "contact"):
+        relabelled[key] = np.ascontiguousarray(s[key][:, :, legs])
+    perm = np.random.default_rng(3).permutation(B)
+    permuted = {k: (np.ascontiguousarray(v[:, perm]) if isinstance(v, np.ndarray) and v.shape[:2] == (K, B) else v) for k, v in s.items()}
+    outs = []
+    for streams in (s, relabelled, permuted):
+        est = BatchedEstimator(p, B)
+        sd = streams_to_device(streams)
+        for k in range(K):
+            est.push_stream_step(sd, k)
+            est.step(k)
+        outs.append(est.get())
+        est.close()
+    base, rel, per = outs
+    assert (base["status"] == 1).all()
+    assert block_err(rel["x"], base["x"]) <= 1.0
+    assert np.array_equal(per["x"], base["x"][perm]) and np.array_equal(per["v_b"], base["v_b"][perm])
+
+
 def test_rccl_allgather_single_rank():
     """dekf_comm_unique_id / dekf_comm_init / dekf_allgather_vb on a communicator of ONE rank: RCCL is found
     through dlopen, the communicator comes up on the estimator's device, and every step's all-gather — issued
