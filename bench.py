@@ -12,6 +12,10 @@ eps 1e-6, extraction) — SURVEY.md §8(d).  Workload at N=1: BASELINE.json conf
 independent, so N GPUs run N shards of 4096 (weak scaling) and exchange only the fused
 base-velocity estimates (one RCCL all-gather per step).  Sensor logs are synthetic
 (decentralized_ekf_mhe_amd/streams.py) and resident in HBM before the timed region.
+
+The rank choreography (`run_bench`) takes everything that touches a device through a `BenchEnv`, so that
+tests/test_bench_orchestration.py can run the very same code on two gloo ranks with a stand-in estimator; `main()`
+always builds the real environment (HIP estimator through the C ABI, RCCL) and refuses to start without a GPU.
 """
 import argparse
 import json
@@ -28,18 +32,50 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 # SURVEY.md §8(d) contract figure: algorithmic bytes per estimator-step, Go1, N = 20
 B_ALG_GO1 = 5736
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP64_VECTOR_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector peak (the path computes in fp64)
+# dependent-issue floor of one 9x9 chain step: nine v_fmac_f64_dpp, each occupying its SIMD for 16 cycles
+# (quarter-rate DPP f64), back to back on one wavefront (tools/probes/dpp_chain_probe.hip)
+CHAIN_STEP_FLOOR_CYCLES = 9 * 16
+TRAFFIC_FILE = os.path.join("profiles", "traffic_k_mhe_solve.json")
 
 
 def measured_traffic():
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes
-    (profiles/traffic_k_mhe_solve.json, produced by tools/collect_traffic.sh); None if absent"""
-    path = os.path.join(ROOT, "profiles", "traffic_k_mhe_solve.json")
+    """(HBM bytes per launch of the dominant kernel, where the figure comes from).  The PMC passes cannot run inside
+    this process (rocprofv3 wraps the command), so the figure is the committed result of tools/collect_traffic.sh
+    (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes) for exactly this
+    workload; (None, None) if that file is absent."""
     try:
-        with open(path) as fh:
-            return json.load(fh).get("hbm_bytes_per_launch")
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as fh:
+            d = json.load(fh)
+        return d.get("hbm_bytes_per_launch"), f"{TRAFFIC_FILE} ({d.get('collected', 'rocprofv3 --pmc passes')})"
     except Exception:
-        return None
+        return None, None
+
+
+def algorithmic_flops(L, N, iters, factorizations, checks, scaling_passes=10):
+    """fp64 operations (FMA = 2) one estimator-step needs in the STRUCTURED algorithm as it is implemented (slack
+    blocks eliminated, block-tridiagonal 9x9 system in the window states) — what roofline.flop_frac
+    prices against the fp64 vector peak.  Counted per phase:
+      solve    two-sided block substitution: (K-1) forward + K (g = S^-1 f) + (K-1) outward 9x9 mat-vecs
+      rows     per 3-row block: A_x x (3..30), two slack-block applies (18 / 36 each), 17 per row of updates, w (9)
+      x cols   9 K entries, ~8 each
+      factor   slack-block inverses, T_kk / C_k assembly (9 K columns x ~400), per block: Schur update 2.9 k,
+               Gauss-Jordan 1.5 k, W = C S^-1 1.5 k
+      Ruiz     per pass ~ (rows + columns) x 40;   residual check ~ 1.3 x one row phase
+      assemble + marginalise (21/24-dim Gauss-Jordan ~ 2 dim^3) + EKF tick"""
+    K = N
+    mv9 = 2 * 81
+    solve = (3 * K - 2) * mv9
+    rows = K * L * 102 + 2 * (K - 1) * 177 + 2 * (K - 1) * 105
+    xcols = 9 * K * 8
+    per_iter = solve + rows + xcols
+    factor = (K * L * 60 + (K - 1) * 420) + 9 * K * 400 + K * (2900 + 1500 + 1500)
+    ruiz = scaling_passes * (K * (3 * L + 12) + K * (21 + 3 * L)) * 40 // 3
+    check = int(1.3 * rows) + 9 * K * 30
+    dim = 12 + 3 * L
+    assemble = 2 * dim ** 3 + 2 * 9 ** 3 + 4000 + 1200
+    return {"per_iteration": per_iter, "total": iters * per_iter + factorizations * factor + ruiz + checks * check + assemble}
 
 
 def usable_cores():
@@ -60,28 +96,207 @@ def usable_cores():
     return n
 
 
-def cpu_baseline(params, steps, seed_first):
-    """the oracle (CPU restatement of the reference algorithm) timed on this host's cores: one thread
-    (the reference's deployment: one pinned core per robot) and the best of a few thread counts"""
+def cpu_baseline(params, total_steps, seed_first, gpu_x_final=None):
+    """The checker leg.  The oracle (CPU restatement of the reference algorithm, oracle/) is timed on this host's
+    cores — one thread (the reference's deployment: one pinned core per robot) and all usable cores — and, because
+    its multi-thread sample is the first instances of the very logs the GPU just ran, it also yields the error of the
+    timed batch's final states against the oracle (`max_rel_err_vs_oracle`)."""
     import oracle_lib
     from decentralized_ekf_mhe_amd.streams import make_streams
     cores = usable_cores()
-    one = make_streams(params, 2, steps, first_instance=seed_first)
+    short = min(total_steps, 150)
+    one = make_streams(params, 2, short, first_instance=seed_first)
     _, _, _, secs1 = oracle_lib.run_streams(params, one, nthreads=1)
-    best = (2 * steps / secs1, 1, 2)
-    for nt in sorted({min(cores, 8), min(cores, 32), cores}):
-        if nt <= 1:
-            continue
-        inst = 2 * nt
-        s = make_streams(params, inst, steps, first_instance=seed_first)
-        _, _, _, secs = oracle_lib.run_streams(params, s, nthreads=nt)
-        if inst * steps / secs > best[0]:
-            best = (inst * steps / secs, nt, inst)
-    return {"value": best[0], "unit": "estimator-steps/s", "cores": best[1], "kind": "port",
-            "single_thread_value": 2 * steps / secs1, "usable_cores": cores,
-            "sample": f"{best[2]} Go1 instances x {steps} steps (T=0..{steps - 1}, window fill included) of the same "
-                      f"synthetic logs through oracle/liboracle.so (fp64 restatement of the Eigen+OSQP path) on "
-                      f"{best[1]} threads (best of 8/32/all usable cores); single_thread_value = 2 instances on 1 thread"}
+    single = 2 * short / secs1
+    nt = max(1, min(cores, 32))
+    inst = max(16, nt)
+    s = make_streams(params, inst, total_steps, first_instance=seed_first)
+    x_ref, _, _, secs = oracle_lib.run_streams(params, s, nthreads=nt)
+    multi = inst * total_steps / secs
+    best = (multi, nt, inst, total_steps) if multi >= single else (single, 1, 2, short)
+    out = {"value": best[0], "unit": "estimator-steps/s", "cores": best[1], "kind": "port",
+           "single_thread_value": single, "usable_cores": cores,
+           "sample": f"{best[2]} Go1 instances x {best[3]} steps (T = 0.., window fill included) of the same synthetic "
+                     f"logs through oracle/liboracle.so on {best[1]} thread(s); single_thread_value = 2 instances x "
+                     f"{short} steps on 1 thread.  The port is an fp64 restatement of the Eigen+OSQP path that keeps "
+                     f"H and A as DENSE matrices, re-slices them at every marginalisation and factors a generic sparse "
+                     f"KKT matrix per step: slower than Eigen-sparse + QDLDL would be, stated as a baseline only"}
+    if gpu_x_final is not None:
+        n = min(16, inst, len(gpu_x_final))
+        ref, got = x_ref[total_steps - 1, :n], gpu_x_final[:n]
+        rel, norm = 0.0, 0.0
+        for blk in (slice(0, 3), slice(3, 6), slice(6, 9)):
+            num = np.abs(got[:, blk] - ref[:, blk]).max(axis=-1)
+            den = np.abs(ref[:, blk]).max(axis=-1)
+            rel = max(rel, float((num / np.maximum(den, 1e-12))[den > 1e-3].max(initial=0.0)))
+            norm = max(norm, float((num / (1e-4 * den + 1e-6)).max()))
+        out["error_vs_oracle"] = {"instances": n, "at_step": total_steps - 1, "max_rel_err": rel,
+                                  "max_err_over_tolerance": norm,
+                                  "tolerance": "|x - oracle|_inf <= 1e-4 |oracle|_inf + 1e-6 per p / v / bias block"}
+    return out
+
+
+class BenchEnv:
+    """what run_bench needs from the outside: the device, the collective backend and the estimator factory"""
+
+    def __init__(self, device, backend, make_estimator, to_device, new_unique_id, preflight, device_sync, real=True):
+        self.device, self.backend = device, backend
+        self.make_estimator, self.to_device, self.new_unique_id = make_estimator, to_device, new_unique_id
+        self.preflight, self.device_sync, self.real = preflight, device_sync, real
+
+
+def agree_on_gather(env, dist, est, world, rank):
+    """Which all-gather runs, decided TOGETHER.  ncclCommInitRank is a blocking collective: a rank that skipped it
+    (library missing, no unique id) would leave the others hanging inside it.  So the ranks first agree (MIN-reduce
+    of a pre-flight flag: RCCL loadable here, unique id received) whether to try the estimator's own communicator at
+    all; only then does every rank call dekf_comm_init, and a failure THERE is fatal and loud on the failing rank.
+    If the pre-flight fails anywhere, all ranks use torch.distributed's communicator for the same exchange."""
+    import torch
+    uid = None
+    if rank == 0:
+        try:
+            uid = env.new_unique_id()
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank 0] dekf_comm_unique_id failed: {e}", file=sys.stderr)
+    ids = [uid]
+    dist.broadcast_object_list(ids, src=0)  # every rank reaches this, whatever happened on rank 0
+    ok = 1 if (ids[0] is not None and env.preflight()) else 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=env.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) != 1:
+        return "torch.distributed.all_gather_into_tensor"
+    est.comm_init(world, rank, ids[0])  # collective; raises on failure (no silent second path from here on)
+    return "dekf_allgather_vb (RCCL, second stream)"
+
+
+def run_bench(args, env, rank, world):
+    """everything between process-group creation and the JSON line; returns the line (rank 0) or None"""
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+    from decentralized_ekf_mhe_amd import go1_params
+    from decentralized_ekf_mhe_amd.streams import make_streams
+
+    p = go1_params()
+    p.ekf_rate = p.rate  # one EKF tick per estimator-step (SURVEY §8d), so its dt is the step
+    B, W, K = args.batch, args.warmup, args.steps
+    # The metric is quoted at steady state: full window AND visual-odometry intervals active (from about tick 40 on the
+    # solves need 75 ADMM iterations instead of 50).  The default warm-up of 50 steps covers that; if the caller asks for
+    # fewer, the missing ticks run as untimed SETUP in front of the W warm-up steps, so that the timed region is always
+    # exactly K steps of the same steady state.
+    STEADY_FROM = 50
+    assert STEADY_FROM >= p.N + 1
+    fill = max(0, STEADY_FROM - W)
+    total = fill + W + K
+
+    t_gen = time.time()
+    s = make_streams(p, B, total, first_instance=rank * B)
+    sd = env.to_device(s)
+    t_gen = time.time() - t_gen
+
+    est = env.make_estimator(p, B)
+    vb_all, gather_path = None, "none"
+    if world > 1 and not args.no_allgather:
+        gather_path = agree_on_gather(env, dist, est, world, rank)
+        vb_all = torch.empty((world, B, 3), dtype=torch.float64, device=env.device)
+    own_comm = gather_path.startswith("dekf")
+    vb_mine = torch.empty((B, 3), dtype=torch.float64, device=env.device) if (vb_all is not None and not own_comm) else None
+
+    def run(k0, k1):
+        for k in range(k0, k1):
+            est.push_stream_step(sd, k)
+            est.step(k)
+            if vb_all is None:
+                continue
+            if own_comm:
+                est.allgather_vb(vb_all)
+            else:
+                est.get_into(v_b=vb_mine)
+                est.sync()
+                dist.all_gather_into_tensor(vb_all.view(world * B, 3), vb_mine)
+
+    run(0, fill)      # window fill that the requested warm-up does not cover (0 with the defaults)
+    run(fill, fill + W)
+    est.sync()
+    est.timing_enable(True)
+    if world > 1:
+        dist.barrier()
+    env.device_sync()
+    t0 = time.perf_counter()
+    run(fill + W, total)
+    est.sync()
+    env.device_sync()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tim = est.timing_read()
+    est.timing_enable(False)
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=env.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    out = est.get()
+    info = est.solver_info()
+    solved = float((out["status"] == 1).mean())
+    v_err = float(np.abs(out["x"][:, 3:6] - s["gt_v_s"][total - 1]).max())
+
+    line = None
+    if rank == 0:
+        value = world * B * K / elapsed
+        solve_ms, solve_n = tim["solve"]
+        avg_solve_s = solve_ms / max(solve_n, 1) * 1e-3
+        achieved = B_ALG_GO1 * B / avg_solve_s / 1e9
+        mean_iters = float(info["iters"].mean())
+        mean_refactor = float(info["rho_updates"].mean())
+        ct = max(int(p.check_termination), 1)
+        fl = algorithmic_flops(int(p.num_legs), int(p.N), mean_iters, 1.0 + mean_refactor, mean_iters / ct, int(p.scaling_iters))
+        per_gpu_rate = B * K / elapsed
+        # cycles one workgroup spends per solve: a launch runs B / grid solves back to back on each persistent workgroup
+        li = est.launch_info()
+        cycles_per_solve = avg_solve_s * li["clock_hz"] / max(1.0, float(np.ceil(B / max(li["solve_workgroups"], 1))))
+        chain_floor = mean_iters * (int(p.N) + 1) * CHAIN_STEP_FLOOR_CYCLES
+        traffic, traffic_src = measured_traffic() if (B == 4096 and world == 1 and env.real) else (None, None)
+        line = {
+            "metric": "estimator-steps/sec (EKF+MHE, 20-step window)",
+            "value": value, "unit": "estimator-steps/s", "n_gpus": world, "steps": K, "warmup": W, "window_fill_steps_before_warmup": fill,
+            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "Go1, batch=4096 per GPU synthetic IMU+encoder+vision streams, 20-step MHE "
+                                   "(BASELINE.json configs[1])",
+                       "robot": "go1", "legs": 4, "N": int(p.N), "batch_per_gpu": B, "global_batch": world * B,
+                       "eps": 1e-6, "parallelism": f"instances sharded x{world}, RCCL all-gather of v_b per step", "allgather": gather_path},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "k_mhe_solve", "avg_launch_ms": avg_solve_s * 1e3, "launches": solve_n,
+                         "alg_bytes_per_step": B_ALG_GO1, "units_per_launch": B,
+                         # the contract's roofline is the HBM one; what actually limits this kernel is the chain of
+                         # dependent mat-vec steps inside every ADMM iteration, so both honest fractions ride along:
+                         "limiter": "dependent-issue latency (ADMM iterations x dependent 9x9 mat-vec steps), not HBM",
+                         "flops_per_step": fl["total"], "flops_per_admm_iteration": fl["per_iteration"],
+                         "flop_peak_tflops": FP64_VECTOR_TFLOPS,
+                         "flop_frac": fl["total"] * per_gpu_rate / (FP64_VECTOR_TFLOPS * 1e12),
+                         "chain_floor_cycles_per_solve": chain_floor, "measured_cycles_per_solve": cycles_per_solve,
+                         "chain_floor_frac": chain_floor / cycles_per_solve if cycles_per_solve > 0 else None},
+            "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items()},
+            "solver": {"mean_iters": mean_iters, "max_iters": int(info["iters"].max()),
+                       "mean_refactorisations": mean_refactor,
+                       "solved_frac": solved, "max_abs_v_err_vs_truth": v_err},
+            "stream_gen_s": t_gen,
+        }
+        if not args.no_cpu_baseline and world == 1 and env.real:  # the CPU leg runs at N = 1 only (rank 0's host cores, same run)
+            cb = cpu_baseline(p, total, seed_first=0, gpu_x_final=out["x"])
+            err = cb.pop("error_vs_oracle", None)
+            line["cpu_baseline"] = cb
+            if err:
+                line["solver"]["max_rel_err_vs_oracle"] = err["max_rel_err"]
+                line["solver"]["error_vs_oracle"] = err
+    est.close()
+    return line
 
 
 def main():
@@ -107,120 +322,26 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    from decentralized_ekf_mhe_amd import go1_params
+    from decentralized_ekf_mhe_amd import capi
     from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, new_unique_id, streams_to_device
-    from decentralized_ekf_mhe_amd.streams import make_streams
 
-    p = go1_params()
-    p.ekf_rate = p.rate  # one EKF tick per estimator-step, so its dt is the step
-    B, W, K = args.batch, args.warmup, args.steps
-    # The metric is quoted at steady state: full window AND visual-odometry intervals active (from about tick 40 on the
-    # solves need 75 ADMM iterations instead of 50).  The default warm-up of 50 steps covers that; if the caller asks for
-    # fewer, the missing ticks run as untimed SETUP in front of the W warm-up steps, so that the timed region is always
-    # exactly K steps of the same steady state.
-    STEADY_FROM = 50
-    assert STEADY_FROM >= p.N + 1
-    fill = max(0, STEADY_FROM - W)
+    def preflight():
+        try:
+            capi.load()
+            new_unique_id()  # RCCL reachable through dlopen in this process
+            return True
+        except Exception as e:  # noqa: BLE001
+            print(f"[rank {rank}] RCCL pre-flight failed: {e}", file=sys.stderr)
+            return False
 
-    t_gen = time.time()
-    s = make_streams(p, B, fill + W + K, first_instance=rank * B)
-    sd = streams_to_device(s, device=f"cuda:{local_rank}")
-    t_gen = time.time() - t_gen
-
-    est = BatchedEstimator(p, B, device=local_rank)
-    vb_all, gather_path = None, "none"
-    if world > 1 and not args.no_allgather:
-        # the estimator's own RCCL communicator (dekf_comm_init); should it fail to come up on some rank, every
-        # rank falls back to torch.distributed's communicator for the same exchange, and the line says which ran
-        uid, ok = None, 0
-        if rank == 0:
-            try:
-                uid = new_unique_id()
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank 0] dekf_comm_unique_id failed: {e}", file=sys.stderr)
-        ids = [uid]
-        dist.broadcast_object_list(ids, src=0)  # every rank reaches this, whatever happened on rank 0
-        if ids[0] is not None:
-            try:
-                est.comm_init(world, rank, ids[0])
-                ok = 1
-            except Exception as e:  # noqa: BLE001
-                print(f"[rank {rank}] dekf_comm_init failed: {e}", file=sys.stderr)
-        flag = torch.tensor([ok], dtype=torch.int32, device=f"cuda:{local_rank}")
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        gather_path = "dekf_allgather_vb (RCCL, second stream)" if int(flag.item()) == 1 else "torch.distributed.all_gather_into_tensor"
-        vb_all = torch.empty((world, B, 3), dtype=torch.float64, device=f"cuda:{local_rank}")
-    own_comm = gather_path.startswith("dekf")
-    vb_mine = torch.empty((B, 3), dtype=torch.float64, device=f"cuda:{local_rank}") if (vb_all is not None and not own_comm) else None
-
-    def run(k0, k1):
-        for k in range(k0, k1):
-            est.push_stream_step(sd, k)
-            est.step(k)
-            if vb_all is None:
-                continue
-            if own_comm:
-                est.allgather_vb(vb_all)
-            else:
-                est.get_into(v_b=vb_mine)
-                est.sync()
-                dist.all_gather_into_tensor(vb_all.view(world * B, 3), vb_mine)
-
-    run(0, fill)      # window fill that the requested warm-up does not cover (0 with the defaults)
-    run(fill, fill + W)
-    est.sync()
-    est.timing_enable(True)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(fill + W, fill + W + K)
-    est.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    tim = est.timing_read()
-    est.timing_enable(False)
-
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    out = est.get()
-    info = est.solver_info()
-    solved = float((out["status"] == 1).mean())
-    v_err = float(np.abs(out["x"][:, 3:6] - s["gt_v_s"][fill + W + K - 1]).max())
-
+    dev = torch.device("cuda", local_rank)
+    env = BenchEnv(device=dev, backend="nccl",
+                   make_estimator=lambda p, B: BatchedEstimator(p, B, device=local_rank),
+                   to_device=lambda s: streams_to_device(s, device=f"cuda:{local_rank}"),
+                   new_unique_id=new_unique_id, preflight=preflight, device_sync=torch.cuda.synchronize)
+    line = run_bench(args, env, rank, world)
     if rank == 0:
-        value = world * B * K / elapsed
-        solve_ms, solve_n = tim["solve"]
-        avg_solve_s = solve_ms / max(solve_n, 1) * 1e-3
-        achieved = B_ALG_GO1 * B / avg_solve_s / 1e9
-        line = {
-            "metric": "estimator-steps/sec (EKF+MHE, 20-step window)",
-            "value": value, "unit": "estimator-steps/s", "n_gpus": world, "steps": K, "warmup": W, "window_fill_steps_before_warmup": fill,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Go1, batch=4096 per GPU synthetic IMU+encoder+vision streams, 20-step MHE "
-                                   "(BASELINE.json configs[1])",
-                       "robot": "go1", "legs": 4, "N": int(p.N), "batch_per_gpu": B, "global_batch": world * B,
-                       "eps": 1e-6, "parallelism": f"instances sharded x{world}, RCCL all-gather of v_b per step", "allgather": gather_path},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": measured_traffic() if (B == 4096 and world == 1) else None,
-                         "kernel": "k_mhe_solve", "avg_launch_ms": avg_solve_s * 1e3, "launches": solve_n,
-                         "alg_bytes_per_step": B_ALG_GO1, "units_per_launch": B},
-            "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items()},
-            "solver": {"mean_iters": float(info["iters"].mean()), "max_iters": int(info["iters"].max()),
-                       "solved_frac": solved, "max_abs_v_err_vs_truth": v_err},
-            "stream_gen_s": t_gen,
-        }
-        if not args.no_cpu_baseline and world == 1:  # the CPU leg runs at N = 1 only (rank 0's host cores, same run)
-            line["cpu_baseline"] = cpu_baseline(p, min(fill + W + K, 150), seed_first=0)
         print(json.dumps(line))
-    est.close()
     if world > 1:
         dist.destroy_process_group()
 

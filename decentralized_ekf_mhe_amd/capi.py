@@ -44,6 +44,7 @@ PROTOTYPES = {
     "dekf_get_kf_cov": (C.c_int, [_vp, _vp, C.c_int]),
     "dekf_timing_enable": (C.c_int, [_vp, C.c_int]),
     "dekf_timing_read": (C.c_int, [_vp, _dp, _ip]),
+    "dekf_launch_info": (C.c_int, [_vp, _ip, _ip, _dp]),
     "dekf_comm_unique_id": (C.c_int, [_vp]),
     "dekf_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dekf_allgather_vb": (C.c_int, [_vp, _vp]),

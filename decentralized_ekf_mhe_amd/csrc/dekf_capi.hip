@@ -36,6 +36,7 @@ __global__ void k_kf_update(DevCfg c, DevState s, int pushes);
 __global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* t_pre, const double* t_now,
                            const double* dp, const double* t_pose, const double* q_vo);
 __global__ void k_reset_state(DevCfg c, DevState s);
+__global__ void k_ekf_cov_out(DevCfg c, DevState s, double* out);
 __global__ void k_latch4(LatchCopy4 a);
 __global__ void k_go1_leg_odometry(DevCfg c, DevState s, const double* jp, const double* jv, const double* force,
                                    double thr, double pibx, double piby, double pibz);
@@ -145,7 +146,11 @@ struct Timed {  // brackets one launch with events when timing is on
     Timed(dekf_handle h_, int cls_) : h(h_), cls(cls_) {
         if (!h->timing) return;
         if (!h->ev_pool.empty()) { a = h->ev_pool.back().first; b = h->ev_pool.back().second; h->ev_pool.pop_back(); }
-        else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+        else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+            if (a) (void)hipEventDestroy(a);
+            a = b = nullptr;
+            return;
+        }
         (void)hipEventRecord(a, h->stream);
     }
     ~Timed() {
@@ -186,7 +191,8 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     if (stream) h->stream = (hipStream_t)stream;
     else {
         if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
-            delete h;
+            h->stream = nullptr;
+            dekf_destroy(h);
             return fail(DEKF_ERR_HIP, "hipStreamCreate failed");
         }
         h->own_stream = true;
@@ -218,7 +224,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     h->lds_asm = (size_t)AsmScratch::len(c.L) * sizeof(double);
     h->lds_kf = (size_t)KfScratch::len(c.L) * sizeof(double);
     if (h->lds_solve > 160 * 1024) {
-        delete h;
+        dekf_destroy(h);
         return fail(DEKF_ERR_INVALID, "window too large: ADMM iterates exceed the 160 KiB LDS of one CU");
     }
     if (h->lds_solve > 64 * 1024)
@@ -244,14 +250,22 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
         dekf_destroy(h);
         return fail(DEKF_ERR_HIP, "hipMalloc failed while allocating the estimator state");
     }
+    // the handle is published only once it is usable: a caller that checks the status alone leaks nothing
+    const dekf_status st = dekf_reset(h);
+    if (st != DEKF_OK) {
+        const std::string keep = g_err;
+        dekf_destroy(h);
+        g_err = keep;
+        return st;
+    }
     *out = h;
-    return dekf_reset(h);
+    return DEKF_OK;
 }
 
 dekf_status dekf_destroy(dekf_handle h) {
     if (!h) return DEKF_OK;
     (void)hipSetDevice(h->device);
-    (void)hipStreamSynchronize(h->stream);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) rccl_destroy(h->comm);
     if (h->ev_vb_ready) (void)hipEventDestroy(h->ev_vb_ready);
@@ -262,7 +276,7 @@ dekf_status dekf_destroy(dekf_handle h) {
     for (auto& pr : h->ev_pool) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
     for (void* q : h->blocks) (void)hipFree(q);
     if (h->stage) (void)hipFree(h->stage);
-    if (h->own_stream) (void)hipStreamDestroy(h->stream);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return DEKF_OK;
 }
@@ -370,6 +384,9 @@ dekf_status dekf_ekf_step(dekf_handle h) {
     }
     HIPCHK(hipGetLastError());
     h->ekf_count++;
+    // the kernel uses the count only modulo the ring depth and to know whether the ring is full: folded long before
+    // the int overflows (a 500 Hz node reaches 2^31 ticks after 49 days)
+    if (h->ekf_count >= (1 << 30)) h->ekf_count = h->c.ekf_hist + h->ekf_count % h->c.ekf_hist;
     return DEKF_OK;
 }
 
@@ -435,17 +452,19 @@ dekf_status dekf_get(dekf_handle h, double* x_mhe, double* v_b, double* quat, do
 
 dekf_status dekf_get_ekf_cov(dekf_handle h, double* cov, dekf_mem where) {
     if (!h || !cov) return fail(DEKF_ERR_INVALID, "null argument");
-    // device layout is [16][B]; hand out [B][4][4]
-    size_t B = h->c.B;
-    std::vector<double> tmp(16 * B);
-    HIPCHK(hipMemcpyAsync(tmp.data(), h->s.ekf_P, 16 * B * 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    std::vector<double> outv(16 * B);
-    for (size_t b = 0; b < B; ++b)
-        for (int i = 0; i < 16; ++i) outv[16 * b + i] = tmp[(size_t)i * B + b];
-    if (where == DEKF_HOST) std::memcpy(cov, outv.data(), 16 * B * 8);
-    else {
-        HIPCHK(hipMemcpyAsync(cov, outv.data(), 16 * B * 8, hipMemcpyHostToDevice, h->stream));
+    // device layout is [16][B] (field-major, one lane per instance in k_ekf_tick); hand out [B][4][4].  The transpose
+    // is a kernel in stream order: with DEKF_DEVICE this call is as asynchronous as every other getter.
+    const size_t B = h->c.B;
+    double* dst = cov;
+    if (where == DEKF_HOST) {
+        dekf_status st = ensure_stage(h, 16 * B * sizeof(double));
+        if (st) return st;
+        dst = (double*)h->stage;
+    }
+    k_ekf_cov_out<<<(int)((16 * B + 255) / 256), 256, 0, h->stream>>>(h->c, h->s, dst);
+    HIPCHK(hipGetLastError());
+    if (where == DEKF_HOST) {
+        HIPCHK(hipMemcpyAsync(cov, dst, 16 * B * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIPCHK(hipStreamSynchronize(h->stream));
     }
     return DEKF_OK;
@@ -474,6 +493,19 @@ dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where) {
 dekf_status dekf_timing_enable(dekf_handle h, int on) {
     if (!h) return fail(DEKF_ERR_INVALID, "null handle");
     h->timing = on != 0;
+    // events are created here, not inside the timed region: enough pairs for a few hundred steps of three launches
+    if (h->timing) {
+        size_t have = h->ev_pool.size();
+        for (int c = 0; c < DEKF_TIMING_CLASSES; ++c) have += h->ev[c].size();
+        for (size_t i = have; i < 3 * 1024; ++i) {
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+                if (a) (void)hipEventDestroy(a);
+                break;
+            }
+            h->ev_pool.push_back({a, b});
+        }
+    }
     return DEKF_OK;
 }
 dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches) {
@@ -491,6 +523,16 @@ dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches) {
         launches[c] = (int)h->ev[c].size();
         h->ev[c].clear();
     }
+    return DEKF_OK;
+}
+
+dekf_status dekf_launch_info(dekf_handle h, int* solve_workgroups, int* compute_units, double* clock_hz) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, h->device));
+    if (solve_workgroups) *solve_workgroups = h->solve_grid;
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_hz) *clock_hz = (double)prop.clockRate * 1e3;
     return DEKF_OK;
 }
 
@@ -514,14 +556,41 @@ dekf_status dekf_comm_init(dekf_handle h, int world, int rank, const void* id) {
     if (!h || !id || world < 1 || rank < 0 || rank >= world) return fail(DEKF_ERR_INVALID, "bad communicator arguments");
     if (h->comm) return fail(DEKF_ERR_ORDER, "dekf_comm_init was already called on this handle");
     HIPCHK(hipSetDevice(h->device));
-    const char* e = rccl_init_rank(&h->comm, world, rank, id);
-    if (e) return fail(DEKF_ERR_COMM, e);
+    // Everything the all-gather needs besides the communicator comes first and the communicator is assigned LAST, so
+    // a failure on the way leaves the handle exactly as it was (h->comm == nullptr: dekf_allgather_vb refuses, a retry
+    // is accepted) instead of half-initialised.
+    hipStream_t cs = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    double* snap = nullptr;
+    auto rollback = [&] {
+        if (snap) (void)hipFree(snap);
+        if (e1) (void)hipEventDestroy(e1);
+        if (e0) (void)hipEventDestroy(e0);
+        if (cs) (void)hipStreamDestroy(cs);
+    };
+    hipError_t he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipMalloc((void**)&snap, 3 * (size_t)h->c.B * sizeof(double));
+    if (he != hipSuccess) {
+        rollback();
+        g_err = std::string("dekf_comm_init: ") + hipGetErrorString(he);
+        return DEKF_ERR_HIP;
+    }
+    void* comm = nullptr;
+    const char* e = rccl_init_rank(&comm, world, rank, id);  // collective: every rank of `world` must be here
+    if (e) {
+        rollback();
+        return fail(DEKF_ERR_COMM, e);
+    }
+    h->comm_stream = cs;
+    h->ev_vb_ready = e0;
+    h->ev_ag_done = e1;
+    h->vb_snapshot = snap;
     h->world = world;
     h->rank = rank;
-    HIPCHK(hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_vb_ready, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&h->ev_ag_done, hipEventDisableTiming));
-    HIPCHK(hipMalloc((void**)&h->vb_snapshot, 3 * (size_t)h->c.B * sizeof(double)));
+    h->ag_pending = false;
+    h->comm = comm;
     return DEKF_OK;
 }
 dekf_status dekf_allgather_vb(dekf_handle h, double* v_b_all_dev) {

@@ -5,7 +5,7 @@
 // (src/go1_example/src/Expressions/*.cc); here the same serial chain is written out by hand
 // (hip abduction about x, thigh and calf about y; link constants identified from, and
 // checked against, golden vectors of the reference's own compiled code:
-// tests/golden/go1_kin.npz, tests/test_go1_kinematics.py).
+// tests/golden/go1_kin.npz, tests/test_golden.py::test_go1_kinematics_against_reference_vectors).
 // Leg order FR, FL, RR, RL; joint order hip, thigh, calf (go1Sub.cpp:84-85).
 #pragma once
 #include "cfg.h"

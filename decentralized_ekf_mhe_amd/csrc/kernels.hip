@@ -124,6 +124,15 @@ __global__ void __launch_bounds__(64) k_go1_leg_odometry(DevCfg c, DevState s, c
     go1_leg_odometry(s, b, jp, jv, force, thr, p_ib);
 }
 
+// Cov_q_ of every instance as [B][4][4] from the field-major EKF state [16][B]: consecutive lanes write consecutive
+// doubles, the strided side is the read (16 streams of B doubles: each is contiguous across the lanes that share i)
+__global__ void __launch_bounds__(256) k_ekf_cov_out(DevCfg c, DevState s, double* out) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x, B = (size_t)c.B;
+    if (e >= 16 * B) return;
+    const size_t b = e / 16, i = e - 16 * b;
+    out[e] = s.ekf_P[i * B + b];
+}
+
 __global__ void k_reset_state(DevCfg c, DevState s) {
     int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= c.B) return;

@@ -155,6 +155,12 @@ class BatchedEstimator:
         capi.check(self.lib.dekf_timing_read(self.h, ms, cnt))
         return {k: (ms[i], cnt[i]) for i, k in enumerate(("ekf", "assemble", "solve"))}
 
+    def launch_info(self):
+        """{'solve_workgroups', 'compute_units', 'clock_hz'} of the solve kernel's launch on this device"""
+        wg, cu, hz = C.c_int(), C.c_int(), C.c_double()
+        capi.check(self.lib.dekf_launch_info(self.h, C.byref(wg), C.byref(cu), C.byref(hz)))
+        return dict(solve_workgroups=wg.value, compute_units=cu.value, clock_hz=hz.value)
+
     # ---- multi-GPU --------------------------------------------------------------------
     def comm_init(self, world, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, capi.DEKF_UNIQUE_ID_BYTES)

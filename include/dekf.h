@@ -197,6 +197,11 @@ dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where);
 dekf_status dekf_timing_enable(dekf_handle h, int on);
 dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches);
 
+/* How the solve kernel is launched on this device: the number of persistent workgroups (each solves
+ * ceil(B / solve_workgroups) instances back to back per launch), the compute units and the engine clock in Hz —
+ * what a caller needs to turn a launch time into cycles per solve. Any pointer may be NULL. */
+dekf_status dekf_launch_info(dekf_handle h, int* solve_workgroups, int* compute_units, double* clock_hz);
+
 /* ---- multi-GPU (new: the reference is single-robot) ------------------------------ */
 /* All-gather of the fused base velocity over RCCL: every rank contributes its
  * v_b[B][3] and receives v_b_all[world][B][3] (device pointer). The communicator is

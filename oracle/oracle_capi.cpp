@@ -51,6 +51,19 @@ void set_leg(EstOracle* e, const double* p_foot, const double* J, const double* 
 
 extern "C" {
 
+// ---------------------------------------------------------------- Bezier (Bezier_simple.cpp:12-82)
+// way points P[n][3] with their stamps t[n] are added one by one (only the last four survive), then
+// set_interval(t_start, num, dt) + interpolate_waypoint(); returns the node count (0 with fewer than four points)
+int orc_bezier(int n, const double* P, const double* t, double t_start, int num, double dt, double* nodes, double* distances) {
+    BezierOracle c;
+    for (int i = 0; i < n; ++i) c.add_way_point(Vec{P[3 * i], P[3 * i + 1], P[3 * i + 2]}, t[i]);
+    c.set_interval(t_start, num, dt);
+    c.interpolate_waypoint();
+    for (int i = 0; i < c.node_count(); ++i)
+        for (int a = 0; a < 3; ++a) { nodes[3 * i + a] = c.nodes[i][a]; distances[3 * i + a] = c.distances[i][a]; }
+    return c.node_count();
+}
+
 // ---------------------------------------------------------------- EKF
 void* orc_ekf_create(const dekf_params* p) { return new EkfOracle(ekf_params_from(*p)); }
 void orc_ekf_destroy(void* h) { delete (EkfOracle*)h; }

@@ -57,6 +57,8 @@ def lib():
                      "orc_est_initialize"):
             getattr(L, name).restype = None
             getattr(L, name).argtypes = [vp]
+        L.orc_bezier.restype = C.c_int
+        L.orc_bezier.argtypes = [C.c_int, _dp, _dp, C.c_double, C.c_int, C.c_double, _dp, _dp]
         L.orc_ekf_set_imu.argtypes = [vp, C.c_double, _dp, _dp]
         L.orc_ekf_set_vo.argtypes = [vp, C.c_double, _dp]
         L.orc_ekf_last_replay.argtypes = [vp]
@@ -87,6 +89,14 @@ def lib():
         L.orc_pipe_run.argtypes = [pp, C.c_int, C.c_int, C.c_int] + [_dp] * 7 + [_ip] + [_dp] * 5 + [_dp, _dp, _dp, _ip]
         _lib = L
     return _lib
+
+
+def bezier(points, times, t_start, num, dt):
+    """BezierOracle: add the way points in order, interpolate `num` nodes from t_start on; (nodes, distances)"""
+    P, t = np.ascontiguousarray(points, float), np.ascontiguousarray(times, float)
+    nodes, dist = np.zeros((num, 3)), np.zeros((num, 3))
+    n = lib().orc_bezier(len(t), _ptr(P), _ptr(t), float(t_start), int(num), float(dt), _ptr(nodes), _ptr(dist))
+    return nodes[:n], dist[:n]
 
 
 class Ekf:

@@ -134,9 +134,61 @@ def kalman_filter(p, s, b, quats, ref_double_init=False):
     return xs, Cs
 
 
-def window_qp(p, s, b, quats, T):
-    """The un-marginalised QP after update(T), T < N, no VO rows active, in the layout of
-    SURVEY.md Appendix A: variables [x0 v0 | w0 c0 x1 v1 | ...], rows [M0 | D0 V0 M1 | ...]."""
+class VoTrack:
+    """Independent numpy statement of the visual-odometry branch of GetMeasurement + UpdateVOConstraints
+    (DecentralEst.cpp:883-945, 987-1009) and of the cubic Bezier over the last four accumulated VO positions
+    (Bezier_simple.cpp:12-82).  Deliberately written differently from oracle/est_oracle.hpp: absolute sample
+    indices (sample k of the log = discrete time k) with a sliding lower limit instead of trimmed stacks,
+    np.searchsorted for upper_bound, the Bernstein form of the cubic, and the bounds of ALL steps kept in one dict
+    keyed by discrete time ({k: -(node_{i+1} - node_i)}, the value UpdateVOConstraints writes into l and u)."""
+
+    def __init__(self, N, dt):
+        self.N, self.dt = N, dt
+        self.times, self.R = [], []
+        self.p_acc = np.zeros(3)
+        self.way, self.way_t = [], []
+        self.bounds = {}
+
+    @staticmethod
+    def bernstein(u, P):
+        v = 1.0 - u
+        return v ** 3 * P[0] + 3 * v * v * u * P[1] + 3 * v * u * u * P[2] + u ** 3 * P[3]
+
+    def vo_event(self, T, t_pre, t_now, dp_body):
+        """a frame pair latched before the sample of update(T) is taken (stack = samples 0..T-1)"""
+        n = len(self.times)
+        if n == 0:
+            return False                                  # stays pending in the reference; the logs never do this
+        lo = max(0, n - (4 * self.N + 1))                   # the stacks are trimmed to 4N+1 entries (:963)
+        tt = np.array(self.times[lo:n])
+        j = int(np.searchsorted(tt, t_pre, side="right"))
+        if j == 0:
+            return True                                   # too early: discarded (:898-904)
+        i_pre = lo + j - 1
+        i_now = lo + int(np.searchsorted(tt, t_now, side="right")) - 1
+        self.p_acc = self.p_acc + self.R[i_pre] @ np.asarray(dp_body)
+        self.way.append(self.p_acc.copy())
+        self.way_t.append(t_now)
+        self.way, self.way_t = self.way[-4:], self.way_t[-4:]
+        w0 = n - min(self.N, T)                           # first sample of the window
+        i0 = max(w0, i_pre)
+        if i_now > w0 and len(self.way) == 4:
+            span = self.way_t[-1] - self.way_t[0]
+            u0 = (self.times[i0] - self.way_t[0]) / span
+            nodes = [self.bernstein(u0 + (self.dt / span) * i, self.way) for i in range(i_now - i0 + 1)]
+            for i in range(len(nodes) - 1):
+                self.bounds[i0 + i] = -(nodes[i + 1] - nodes[i])
+        return True
+
+    def push(self, t, R):
+        self.times.append(float(t))
+        self.R.append(np.array(R))
+
+
+def window_qp(p, s, b, quats, T, vo=False, return_track=False):
+    """The UN-MARGINALISED QP after update(T) over ALL steps 0..T (for T < N this is the window itself), in the
+    layout of SURVEY.md Appendix A: variables [x0 v0 | w0 c0 x1 v1 | ...], rows [M0 | D0 V0 M1 | ...].
+    vo=True: VO rows carry the equality bounds VoTrack writes, the others stay +-1e30."""
     m = Model(p)
     L = m.L
     nm, ns, nc = 3 * L, 9, 3
@@ -146,11 +198,16 @@ def window_qp(p, s, b, quats, T):
     H, g = np.zeros((n, n)), np.zeros(n)
     A, l, u = np.zeros((mm, n)), np.zeros(mm), np.zeros(mm)
     samples = [m.sample(s, k, b, quats[k]) for k in range(T + 1)]
+    track = VoTrack(m.N, m.dt)
+    for k in range(T + 1):
+        if vo and k >= 1 and s["vo_mask"][k, b]:
+            track.vo_event(k, s["vo_t_pre"][k, b], s["vo_t_now"][k, b], s["vo_dp"][k, b])
+        track.push(s["imu_t"][k, b], samples[k][0])
 
     def xo(k):
         return 0 if k == 0 else (ns + nm) + (k - 1) * sv + ns + nc
 
-    def vo(k):
+    def vo_(k):
         return xo(k) + ns
 
     def wo(k):  # w_k, c_k live in the block created at update(k+1)
@@ -161,9 +218,9 @@ def window_qp(p, s, b, quats, T):
         R, a_s, om, b_meas, C_meas = samples[k]
         r0 = 0 if k == 0 else nm + (k - 1) * sc + ns + nc
         A[r0:r0 + nm, xo(k):xo(k) + ns] = m.A_meas
-        A[r0:r0 + nm, vo(k):vo(k) + nm] = -np.eye(nm)
+        A[r0:r0 + nm, vo_(k):vo_(k) + nm] = -np.eye(nm)
         l[r0:r0 + nm] = u[r0:r0 + nm] = b_meas
-        H[vo(k):vo(k) + nm, vo(k):vo(k) + nm] = np.linalg.inv(C_meas)
+        H[vo_(k):vo_(k) + nm, vo_(k):vo_(k) + nm] = np.linalg.inv(C_meas)
         if k < T:
             Ad, bd, Cd = m.dynamics(R, a_s)
             rd = nm + k * sc
@@ -180,8 +237,13 @@ def window_qp(p, s, b, quats, T):
             A[rc:rc + 3, xo(k):xo(k) + 3] = np.eye(3)
             A[rc:rc + 3, xo(k + 1):xo(k + 1) + 3] = -np.eye(3)
             A[rc:rc + 3, co:co + 3] = -np.eye(3)
-            l[rc:rc + 3], u[rc:rc + 3] = -INF, INF
+            if k in track.bounds:
+                l[rc:rc + 3] = u[rc:rc + 3] = track.bounds[k]
+            else:
+                l[rc:rc + 3], u[rc:rc + 3] = -INF, INF
             H[co:co + 3, co:co + 3] = R @ m.Q_vo @ R.T
+    if return_track:
+        return (H, g, A, l, u), track
     return H, g, A, l, u
 
 

@@ -1,0 +1,305 @@
+"""GPU tests for the BASELINE.json configurations and rates that tests/test_gpu_parity.py does not reach:
+config 4's per-rank batch (Go1, 8192 instances per GPU), the full batches of configs 3 (Cassie, 4096) and 5 (PogoX,
+1024), the reference's real timer rates (orientation EKF at 500 Hz, MHE at 200 Hz: parameters_go1.yaml:33,75), the
+error paths of the ABI, and — where the box has at least two GPUs — the RCCL all-gather with world size > 1.
+Tolerances as in test_gpu_parity.py (1e-4 relative per 3-block + OSQP's eps_abs 1e-6; quaternion 1e-9)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from decentralized_ekf_mhe_amd import capi, cassie_params, go1_params, pogox_params
+from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, new_unique_id, streams_host, streams_to_device
+from decentralized_ekf_mhe_amd.streams import make_streams
+from test_gpu_parity import ATOL, RTOL, _params, block_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _tile(s, reps):
+    return {k: (np.ascontiguousarray(np.tile(v, (1, reps) + (1,) * (v.ndim - 2))) if isinstance(v, np.ndarray) else v)
+            for k, v in s.items()}
+
+
+def _first(s, n):
+    return {k: (np.ascontiguousarray(v[:, :n]) if isinstance(v, np.ndarray) else v) for k, v in s.items()}
+
+
+def _full_batch_run(p, B, K, distinct, n_oracle, gather=False):
+    """B instances = `distinct` different logs tiled over the batch.  Returns the outputs, the per-step all-gather
+    results (when asked) and the oracle's states of the first n_oracle instances."""
+    import torch
+    s = make_streams(p, distinct, K)
+    big = _tile(s, B // distinct)
+    est = BatchedEstimator(p, B)
+    vb_all = None
+    if gather:
+        est.comm_init(1, 0, new_unique_id())
+        vb_all = torch.full((2, 1, B, 3), float("nan"), dtype=torch.float64, device="cuda")
+    sd = streams_to_device(big)
+    for k in range(K):
+        est.push_stream_step(sd, k)
+        est.step(k)
+        if gather:
+            est.allgather_vb(vb_all[k & 1])
+    if gather:
+        est.allgather_wait()
+    est.sync()
+    o = est.get()
+    info = est.solver_info()
+    est.close()
+    x_ref, vb_ref, q_ref, _ = O.run_streams(p, _first(s, n_oracle), nthreads=min(8, n_oracle))
+    return s, o, info, (vb_all.cpu().numpy() if gather else None), (x_ref, vb_ref, q_ref)
+
+
+def _check_full_batch(p, B, K, distinct, o, refs, n_oracle):
+    x_ref, vb_ref, q_ref = refs
+    assert (o["status"] == 1).all()
+    x = o["x"].reshape(B // distinct, distinct, 9)
+    assert np.array_equal(x, np.broadcast_to(x[0], x.shape))      # same log -> same bits, wherever it sits in the batch
+    q = o["quat"].reshape(B // distinct, distinct, 4)
+    assert np.array_equal(q, np.broadcast_to(q[0], q.shape))
+    assert block_err(x[0, :n_oracle], x_ref[K - 1]) <= 1.0
+    assert np.abs(q[0, :n_oracle] - q_ref[K - 1]).max() < 1e-9
+    assert np.abs(o["v_b"][:n_oracle] - vb_ref[K - 1]).max() <= RTOL * np.abs(vb_ref[K - 1]).max() + ATOL
+
+
+def test_go1_config4_per_rank_batch_8192():
+    """BASELINE config 4 shards 65 536 Go1 instances over 8 GPUs: 8192 per rank.  One rank's share here: every instance
+    solved, tiled logs give identical bits, 8 instances against the oracle, and the per-step all-gather of that size
+    (communicator of one rank, second stream) hands back exactly the step's v_b."""
+    p = _params(go1_params)
+    B, K, distinct = 8192, 45, 64
+    s, o, info, vb_all, refs = _full_batch_run(p, B, K, distinct, 8, gather=True)
+    _check_full_batch(p, B, K, distinct, o, refs, 8)
+    assert np.array_equal(vb_all[(K - 1) & 1, 0], o["v_b"])
+    assert np.isfinite(vb_all).all()
+    assert info["iters"].max() <= 200 and info["iters"].min() >= 25
+
+
+def test_cassie_full_batch_4096():
+    """BASELINE config 3 at its full batch (2 legs x 5 joints, fixed-horizon kernel k_mhe_solve_lg_2_n20)"""
+    p = _params(cassie_params)
+    B, K, distinct = 4096, 45, 64
+    s, o, info, _, refs = _full_batch_run(p, B, K, distinct, 8)
+    _check_full_batch(p, B, K, distinct, o, refs, 8)
+
+
+def test_pogox_full_batch_1024():
+    """BASELINE config 5 at its full batch (1 leg, N = 100: factor streamed from the HBM slab), past the window fill"""
+    p = _params(pogox_params)
+    B, K, distinct = 1024, 125, 32
+    s, o, info, _, refs = _full_batch_run(p, B, K, distinct, 4)
+    _check_full_batch(p, B, K, distinct, o, refs, 4)
+
+
+# ---------------------------------------------------------------- the reference's two timers together
+def _multirate_schedule(p, B, n_mhe, seed_first=0):
+    """Sensor events on a 1 ms grid: IMU + joint states every 2 ms (500 Hz, each followed by one EKF timer tick,
+    orien_ekf.cpp:43), the MHE timer every 5 ms (EstSub.cpp:25, parameters_go1.yaml:33), VO as it arrives."""
+    grid = p.copy()
+    grid.rate = 1000
+    n_grid = 5 * (n_mhe - 1) + 1
+    return make_streams(grid, B, n_grid, first_instance=seed_first), n_grid
+
+
+def test_multirate_ekf_500hz_mhe_200hz_matches_oracle():
+    p = go1_params()
+    assert (p.ekf_rate, p.rate) == (500, 200)
+    B, n_mhe = 6, 48
+    s, n_grid = _multirate_schedule(p, B, n_mhe)
+    sh = streams_host(s)
+    # ---- GPU: dekf_ekf_step on every IMU sample, dekf_initialize / dekf_update on the 5 ms timer
+    est = BatchedEstimator(p, B)
+    xs, qs, sts = [], [], []
+    for i in range(n_grid):
+        if s["vo_mask"][i].any():
+            est.push_vo(sh["vo_mask"][i], sh["vo_t_pre"][i], sh["vo_t_now"][i], sh["vo_dp"][i], sh["vo_t_pose"][i], sh["vo_q"][i])
+        if i % 2 == 0:
+            est.push_imu(sh["imu_t"][i], sh["accel"][i], sh["gyro"][i])
+            est.push_leg(sh["p_foot"][i], sh["J"][i], sh["qdot"][i], sh["contact"][i])
+            est.ekf_step()
+        if i % 5 == 0:
+            T = i // 5
+            if T == 0:
+                est.initialize()
+            else:
+                est.update(T)
+            o = est.get()
+            xs.append(o["x"]); qs.append(o["quat"]); sts.append(o["status"])
+    est.close()
+    xs, qs, sts = np.array(xs), np.array(qs), np.array(sts)
+    # ---- oracle: orien_ekf and DecentralizedEstimation restatements driven by the same events
+    x_ref, q_ref = np.zeros_like(xs), np.zeros_like(qs)
+    replays = 0
+    for b in range(B):
+        ekf, mhe = O.Ekf(p), O.Est(p)
+        for i in range(n_grid):
+            if s["vo_mask"][i, b]:
+                ekf.set_vo(s["vo_t_pose"][i, b], s["vo_q"][i, b])
+                mhe.set_vo(s["vo_t_pre"][i, b], s["vo_t_now"][i, b], s["vo_dp"][i, b])
+            if i % 2 == 0:
+                ekf.set_imu(s["imu_t"][i, b], s["accel"][i, b], s["gyro"][i, b])
+                mhe.set_imu(s["imu_t"][i, b], s["accel"][i, b], s["gyro"][i, b])
+                mhe.set_leg(s["p_foot"][i, b], s["J"][i, b], s["qdot"][i, b], s["contact"][i, b])
+                ekf.step()
+                replays += ekf.last_replay() > 0
+                mhe.set_quat(ekf.get()[0])
+            if i % 5 == 0:
+                T = i // 5
+                if T == 0:
+                    mhe.initialize()
+                else:
+                    mhe.update(T)
+                x_ref[T, b] = mhe.get()[0]
+                q_ref[T, b] = ekf.get()[0]
+    assert replays > 0                      # VO poses did rewind the 500 Hz filter
+    assert np.abs(qs - q_ref).max() < 1e-9
+    assert (sts[1:] == 1).all()
+    assert block_err(xs[1:], x_ref[1:]) <= 1.0
+
+
+# ---------------------------------------------------------------- error paths
+def _run_collect(p, s, B, K, every=1):
+    est = BatchedEstimator(p, B)
+    sh = streams_host(s)
+    outs = []
+    for k in range(K):
+        est.push_stream_step(sh, k)
+        est.step(k)
+        if k % every == 0 or k == K - 1:
+            outs.append(est.get())
+    est.close()
+    return outs
+
+
+def test_nan_sample_poisons_only_its_own_instance():
+    """The reference ignores OSQP's exit flag (MheSrb.cpp:345); this ABI promises a per-instance status.  A NaN
+    accelerometer sample on one robot must mark that robot DEKF_SOLVE_NUMERIC — at once and for as long as the
+    sample sits in its window — while every other robot of the batch is bit-for-bit unaffected and the kernels
+    terminate."""
+    p = _params(go1_params)
+    B, K, bad, at = 9, 40, 4, 27
+    s = make_streams(p, B, K)
+    clean = _run_collect(p, s, B, K)
+    s2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in s.items()}
+    s2["accel"][at, bad, 1] = np.nan
+    dirty = _run_collect(p, s2, B, K)
+    others = [b for b in range(B) if b != bad]
+    for k in range(K):
+        assert np.array_equal(dirty[k]["x"][others], clean[k]["x"][others]), k
+        assert np.array_equal(dirty[k]["quat"][others], clean[k]["quat"][others]), k
+        assert (dirty[k]["status"][others] == clean[k]["status"][others]).all()
+        if k < at:
+            assert np.array_equal(dirty[k]["x"][bad], clean[k]["x"][bad])
+        else:
+            assert dirty[k]["status"][bad] == capi.DEKF_SOLVE_NUMERIC, (k, dirty[k]["status"][bad])
+
+
+def test_vo_pose_older_than_the_ekf_ring_is_dropped():
+    """orien_ekf drops a VO pose older than its whole history (orien_ekf.cpp:178-183).  Here the history is a ring
+    of ekf_history samples, so "older than the ring" is dropped the same way: the filter and the estimator behave
+    as if the pose (and the too-early frame pair, DecentralEst.cpp:898-904) had never arrived."""
+    p = _params(go1_params, ekf_history=16)
+    B, K, at = 5, 60, 50
+    s = make_streams(p, B, K, vo=False)
+    clean = _run_collect(p, s, B, K, every=K)[-1]
+    for t_old in (-1.0, float(s["imu_t"][at - 30, 0])):    # before everything / inside the run but 30 ticks back
+        s2 = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in s.items()}
+        s2["vo_mask"][at] = 1
+        s2["vo_t_pose"][at] = t_old
+        s2["vo_q"][at] = np.array([0.6, 0.0, 0.8, 0.0])     # far from the truth: applying it would show
+        s2["vo_t_pre"][at] = -2.0                            # the frame pair itself is older than the estimator's stack
+        s2["vo_t_now"][at] = -1.5
+        s2["vo_dp"][at] = 5.0
+        got = _run_collect(p, s2, B, K, every=K)[-1]
+        assert np.array_equal(got["quat"], clean["quat"]), t_old
+        assert np.array_equal(got["x"], clean["x"]), t_old
+        assert np.array_equal(got["p_vo"], np.zeros((B, 3)))
+
+
+def test_ekf_cov_device_pointer_equals_host_pointer():
+    """dekf_get_ekf_cov with a device pointer is a kernel in stream order (no host bounce)"""
+    import ctypes as C
+    import torch
+    p = _params(go1_params)
+    B, K = 37, 12
+    s = streams_host(make_streams(p, B, K))
+    est = BatchedEstimator(p, B)
+    for k in range(K):
+        est.push_stream_step(s, k)
+        est.step(k)
+    host = est.ekf_cov()
+    dev = torch.zeros((B, 4, 4), dtype=torch.float64, device="cuda")
+    capi.check(est.lib.dekf_get_ekf_cov(est.h, C.c_void_p(dev.data_ptr()), capi.DEKF_DEVICE))
+    est.sync()
+    est.close()
+    assert np.array_equal(dev.cpu().numpy(), host)
+    assert np.abs(host - host.transpose(0, 2, 1)).max() < 1e-12 and (np.einsum("bii->bi", host) > 0).all()
+
+
+def test_create_failure_publishes_no_handle():
+    import ctypes as C
+    bad = _params(go1_params, N=1)
+    h = C.c_void_p(1234)
+    st = capi.load().dekf_create(C.byref(bad), 4, 0, C.c_void_p(0), C.byref(h))
+    assert st == capi.DEKF_ERR_INVALID and not h.value
+
+
+# ---------------------------------------------------------------- RCCL with world size > 1 (needs >= 2 GPUs)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _rccl_worker(rank, world, port, B, K, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # only to hand the unique id around
+    p = _params(go1_params)
+    s = make_streams(p, B, K, first_instance=rank * B)
+    est = BatchedEstimator(p, B, device=rank)
+    ids = [new_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(ids, src=0)
+    est.comm_init(world, rank, ids[0])
+    sd = streams_to_device(s, device=f"cuda:{rank}")
+    vb_all = torch.full((K, world, B, 3), float("nan"), dtype=torch.float64, device=f"cuda:{rank}")
+    for k in range(K):
+        est.push_stream_step(sd, k)
+        est.step(k)
+        est.allgather_vb(vb_all[k])
+    est.allgather_wait()
+    est.sync()
+    np.save(os.path.join(out_dir, f"gathered_{rank}.npy"), vb_all.cpu().numpy())
+    est.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rccl_allgather_two_ranks_equals_single_rank_results(tmp_path):
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs at least two GPUs (the test box has one); the layout is covered by tests/test_distributed_gloo.py")
+    import torch.multiprocessing as mp
+    world, B, K = 2, 48, 30
+    mp.spawn(_rccl_worker, args=(world, _free_port(), B, K, str(tmp_path)), nprocs=world, join=True)
+    p = _params(go1_params)
+    s = make_streams(p, world * B, K)
+    sh = streams_host(s)
+    ref = BatchedEstimator(p, world * B)
+    g = [np.load(tmp_path / f"gathered_{r}.npy") for r in range(world)]
+    assert np.array_equal(g[0], g[1])
+    for k in range(K):
+        ref.push_stream_step(sh, k)
+        ref.step(k)
+        assert np.array_equal(g[0][k].reshape(world * B, 3), ref.get()["v_b"]), k
+    ref.close()

@@ -171,3 +171,83 @@ def test_cassie_shape_runs():
     xs_np, _ = RN.kalman_filter(p, s, 0, quats)
     for k in range(1, 20):
         assert relerr(out[k][2][3:6], xs_np[k][3:6]) < 1e-7
+
+
+# ---------------------------------------------------------------- VO branch: a second, independent restatement
+def test_vo_bounds_match_independent_numpy_writer():
+    """VO synchronisation (upper_bound on the IMU stamps), accumulation in the world frame, the cubic Bezier over the
+    last four way points and the equality bounds on the VO rows (DecentralEst.cpp:883-945, 987-1009;
+    Bezier_simple.cpp:29-82): the oracle's (l, u) against ref_numpy.VoTrack, written independently.  N = 50 so that
+    VO rows switch on (fourth accepted way point at tick 40: the first frame pair is older than the first IMU stamp and is discarded) while nothing has been marginalised yet."""
+    p = _params(N=50)
+    nsteps = 50
+    s = make_streams(p, 2, nsteps, vo=True)
+    for b in range(2):
+        qps = {}
+        pipe, quats = _run(p, s, b, nsteps, lambda k, pp: qps.__setitem__(k, pp.est.qp()) if k in (40, 43, 46, 49) else None)
+        for T, (H, g, A, l, u) in qps.items():
+            (H2, g2, A2, l2, u2), track = RN.window_qp(p, s, b, quats, T, vo=True, return_track=True)
+            assert A.shape == A2.shape and np.max(np.abs(A - A2)) < 1e-13
+            fin, fin2 = np.abs(l) < 1e20, np.abs(l2) < 1e20
+            assert np.array_equal(fin, fin2), T                       # the same rows became equalities
+            vo_rows = np.zeros(len(l), bool)
+            for k in range(T):
+                vo_rows[12 + 24 * k + 9:12 + 24 * k + 12] = True
+            assert (fin & vo_rows).sum() == 3 * len([k for k in track.bounds if k < T]) > 0
+            assert np.array_equal(l[fin & vo_rows], u[fin & vo_rows])
+            scale = np.abs(l2[fin2 & vo_rows]).max()
+            assert np.max(np.abs(l[fin] - l2[fin2])) < 1e-9 * max(scale, 1.0)
+            assert np.max(np.abs(l[fin & vo_rows] - l2[fin2 & vo_rows])) < 1e-9 * scale, T
+            assert np.all(l[~fin] == -1e30) and np.all(u[~fin] == 1e30)
+        # accumulated VO position: the oracle's public member against the independent accumulation
+        assert np.max(np.abs(pipe.est.get()[2] - track.p_acc)) < 1e-12
+
+
+def test_marginalised_window_equals_the_never_marginalised_problem_with_vo():
+    """marginalizeQP with the 24-dim saddle system (VO rows flagged as equalities, MheSrb.cpp:527-599) and the 21-dim
+    one (MheSrb.cpp:600-651): the exact optimum of the oracle's marginalised 648-variable window must equal the exact
+    optimum of the FULL problem over every step since T = 0, which ref_numpy builds without ever marginalising
+    (its own VO bounds, its own block layout).  Checked while steps with and without active VO rows leave the window."""
+    p = _params(N=20)
+    nsteps = 63
+    s = make_streams(p, 1, nsteps, vo=True)
+    want = (24, 31, 40, 47, 55, 62)
+    qps = {}
+    pipe, quats = _run(p, s, 0, nsteps, lambda k, pp: qps.__setitem__(k, pp.est.qp()) if k in want else None)
+    dropped_with_vo = 0
+    for T in want:
+        H, g, A, l, u = qps[T]
+        assert H.shape[0] == 648
+        x_win, _ = RN.kkt_exact(H, g, A, l, u)
+        (H2, g2, A2, l2, u2), track = RN.window_qp(p, s, 0, quats, T, vo=True, return_track=True)
+        x_full, _ = RN.kkt_exact(H2, g2, A2, l2, u2)
+        dropped_with_vo += len([k for k in track.bounds if k <= T - 20])
+        a, r = x_win[-21:-12], x_full[-21:-12]
+        for blk in (slice(0, 3), slice(3, 6), slice(6, 9)):
+            assert relerr(a[blk], r[blk]) < 2e-6, (T, blk, relerr(a[blk], r[blk]))
+        # not only the newest state: the whole window of states agrees
+        for k in range(20):
+            aw, rw = x_win[33 * k:33 * k + 9], x_full[-21 - 33 * (19 - k):][:9]
+            assert relerr(aw[3:6], rw[3:6]) < 2e-6, (T, k)
+    assert dropped_with_vo > 10     # steps WITH active VO rows were folded into the arrival cost (24-dim branch)
+
+
+def test_bezier_ka5():
+    """KA5: the curve starts at the first and ends at the last of its four control points, only the last four way
+    points count, and the node differences UpdateVOConstraints consumes add up to last node - first node."""
+    rng = np.random.default_rng(11)
+    P = rng.normal(0, 1, (6, 3))
+    t = np.array([0.0, 0.031, 0.066, 0.1, 0.134, 0.17])
+    for n in (4, 5, 6):
+        Pn, tn = P[:n], t[:n]
+        span = tn[-1] - tn[-4]
+        nodes, dist = O.bezier(Pn, tn, tn[-4], 2, span)          # u = 0 and u = 1
+        assert np.max(np.abs(nodes[0] - Pn[-4])) < 1e-14 and np.max(np.abs(nodes[1] - Pn[-1])) < 1e-13
+        nodes, dist = O.bezier(Pn, tn, tn[-4] + 0.011, 9, 0.005)
+        assert len(nodes) == 9
+        assert np.max(np.abs(dist[1:].sum(axis=0) - (nodes[-1] - nodes[0]))) < 1e-14
+        assert np.array_equal(dist[0], nodes[0])                  # first "distance" is measured from zero (node_pre = 0)
+        u = (0.011 + 0.005 * np.arange(9)) / span
+        want = np.array([RN.VoTrack.bernstein(ui, Pn[-4:]) for ui in u])
+        assert np.max(np.abs(nodes - want)) < 1e-13               # power form (reference) == Bernstein form
+    assert len(O.bezier(P[:3], t[:3], 0.0, 5, 0.005)[0]) == 0     # fewer than four way points: nothing
