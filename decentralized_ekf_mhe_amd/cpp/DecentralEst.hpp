@@ -170,8 +170,10 @@ class DecentralizedEstimation {
         prm_ = dekf_shim::to_dekf_params(*params);
         if (h_) { dekf_destroy(h_); h_ = nullptr; }
         dekf_shim::check(dekf_create(&prm_, 1, device, nullptr, &h_));
-        x_MHE_.resize(9);
-        x_KF_.resize(9);
+        dim_state_ = 9 + 3 * prm_.leg_odom_type * prm_.num_legs;  // DecentralEst.cpp:20
+        x_MHE_.resize(dim_state_);
+        x_KF_.resize(dim_state_);
+        C_KF_ = MatrixXd(dim_state_, dim_state_);
         latch();
         dekf_shim::check(dekf_initialize(h_));
         fetch();
@@ -195,6 +197,7 @@ class DecentralizedEstimation {
     MatrixXd C_KF_ = MatrixXd(9, 9);
     Vector3d v_KF_b_;
     int solver_status_ = DEKF_SOLVE_NONE, solver_iters_ = 0;  // new: the reference ignores OSQP's flag
+    int dim_state_ = 9;                                       // 9 + 3 * leg_odom_type * num_legs
     // new: take raw Go1 joint states from robot_store (joint_states_position_/velocity_) instead of
     // p_imu_2_foot_/J_imu_2_foot_/contact_; set before initialize()  
     bool go1_raw_joints_ = false;
@@ -241,7 +244,7 @@ class DecentralizedEstimation {
         dekf_shim::check(dekf_sync(h_));  // the staging arrays above die with this scope
     }
     void fetch() {
-        double x[9], vb[3], q[4], pv[3];
+        double x[9 + 3 * DEKF_MAX_LEGS], vb[3], q[4], pv[3];
         int st = 0, it = 0;
         dekf_shim::check(dekf_get(h_, x, vb, q, pv, &st, DEKF_HOST));
         dekf_shim::check(dekf_get_solver_info(h_, &it, nullptr, nullptr, nullptr, DEKF_HOST));
@@ -249,7 +252,7 @@ class DecentralizedEstimation {
         solver_iters_ = it;
         VectorXd& xs = prm_.est_type == 0 ? x_MHE_ : x_KF_;
         Vector3d& v = prm_.est_type == 0 ? v_MHE_b_ : v_KF_b_;
-        for (int i = 0; i < 9; ++i) xs(i) = x[i];
+        for (int i = 0; i < dim_state_; ++i) xs(i) = x[i];
         for (int i = 0; i < 3; ++i) { v(i) = vb[i]; p_vo_accmulate_(i) = pv[i]; }
         // R_sb_ = quaternion_.normalized().toRotationMatrix()  (DecentralEst.cpp:867)
         double n = std::sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
@@ -258,9 +261,9 @@ class DecentralizedEstimation {
         R_sb_(1, 0) = 2 * (xq * y + w * z); R_sb_(1, 1) = 1 - 2 * (xq * xq + z * z); R_sb_(1, 2) = 2 * (y * z - w * xq);
         R_sb_(2, 0) = 2 * (xq * z - w * y); R_sb_(2, 1) = 2 * (y * z + w * xq); R_sb_(2, 2) = 1 - 2 * (xq * xq + y * y);
         if (prm_.est_type == 1) {
-            double C[81];
+            double C[(9 + 3 * DEKF_MAX_LEGS) * (9 + 3 * DEKF_MAX_LEGS)];
             dekf_shim::check(dekf_get_kf_cov(h_, C, DEKF_HOST));
-            for (int i = 0; i < 9; ++i) for (int j = 0; j < 9; ++j) C_KF_(i, j) = C[9 * i + j];
+            for (int i = 0; i < dim_state_; ++i) for (int j = 0; j < dim_state_; ++j) C_KF_(i, j) = C[dim_state_ * i + j];
         }
     }
 };

@@ -8,7 +8,7 @@
 //   MHE stack      [B][ring]        imu time, R (9) per pushed sample; ring = 4N+1
 //                                   (the reference trims its stacks to 4N+1, DecentralEst.cpp:963)
 //   MHE window     [B][N+1][REC]    one record per window step (see Rec below)
-//   arrival cost   [B][81 + 9]      M_p, n_p (MheSrb.cpp:594-598)
+//   arrival cost   [B][ns^2 + ns]   M_p, n_p (MheSrb.cpp:594-598), ns = 9 (21 for Go1 with foot-position states)
 //   solver scratch [B][GWS]         factor + scaled data of the ADMM solve (streamed from L2)
 // One wavefront owns one instance in the MHE kernels, so instance-major keeps every
 // access of a wave inside one contiguous slab.
@@ -28,7 +28,9 @@ constexpr double MIN_SCALING = 1e-4, MAX_SCALING = 1e4;
 
 struct DevCfg {
     int B, L, nj, N, nm;  // nm = 3L
-    int SV, SC;           // per-step variable / row block: 9+nm+12, nm+12
+    int ft;               // leg_odom_type: 0 foot-velocity measurements (9 states), 1 foot positions as states
+    int ns;               // dim_state = 9 + 3 L ft (DecentralEst.cpp:20)
+    int SV, SC;           // per-step variable / row block: 2 ns + nm + 3, nm + ns + 3
     int ring;             // 4N+1 stack entries
     int wcap;             // N+1 window records
     int rec;              // doubles per window record
@@ -38,7 +40,9 @@ struct DevCfg {
     double C_p[3], C_accel[3], C_accel_bias[3], C_gyro[3];
     double C_enc_pos[DEKF_MAX_JOINTS], C_enc_vel[DEKF_MAX_JOINTS];
     double C_swing[3], Q_swing[3], Q_vo[3], Q_bias_dt2[3];
+    double C_slide[3], Q_slide[3];                 // foot_slide_std (leg_odom_type 1: process noise of a stance foot)
     double Q_prior[9], C_prior[9];
+    double Q_foot_init[3], C_foot_init[3];         // prior of the foot-position states (DecentralEst.cpp:310-325)
     // OSQP settings (DecentralEst.cpp:204-217 + defaults)
     double rho0, sigma, alpha, eps_abs, eps_rel;
     int max_iter, scaling, check_termination, adaptive_rho, adaptive_rho_interval;
@@ -58,10 +62,13 @@ struct LatchCopy4 {
 // window record of step k (doubles)
 struct Rec {
     // R_sb (9) | a_s (3) | gyro (3) | Qd 6x6 sym packed (21) | Qc 3x3 sym packed (6) |
-    // vo flag (1) | vo bound (3) | bm (nm) | Qm L x sym packed (6L)
+    // vo flag (1) | vo bound (3) | bm (nm) | Qm L x sym packed (6L) |
+    // leg_odom_type 1 only: Qf L x sym packed (6L), the process gain 1/dt^2 R Q_{slide|swing} R' of every foot
+    // position (DecentralEst.cpp:432-451; in KF mode the covariance dt^2 R C R', :753)
     static constexpr int R = 0, AS = 9, GY = 12, QD = 15, QC = 36, VOF = 42, VOB = 43, BM = 46;
     DEKF_HD static int qm(int nm) { return BM + nm; }
-    DEKF_HD static int len(int L) { return BM + 3 * L + 6 * L; }
+    DEKF_HD static int qf(int nm) { return BM + nm + 2 * nm; }
+    DEKF_HD static int len(int L, int ft = 0) { return BM + 3 * L + 6 * L + (ft ? 6 * L : 0); }
 };
 
 // packed symmetric index, i <= j, n x n
@@ -85,17 +92,17 @@ struct Idx {
     DEKF_FN int rv(int k, int a) const { return k * SC + nm + 9 + a; }
 };
 
-// global-memory scratch of one solve (doubles), K_max = N steps
+// global-memory scratch of one solve (doubles), K_max = N steps, NS = 9 + 3 L ft states per step
 struct Gws {
-    // D (n) | E (m) | lo (m) | hi (m) | rho (m) | Sv (K*6L) | Sw (K*24) | Sc (K*6) |
-    // Wm (K*6L) | Wd (K*24) | Wc (K*6) | PA (K*81) | Sinv (K*81) | Wk (K*81)
+    // D (n) | E (m) | lo (m) | hi (m) | rho (m) | Sv (K*6L) | Sw (K*25) | Sc (K*6) | Sf (K*6L ft) |
+    // Wm (K*6L) | Wd (K*24) | Wc (K*6) | Wf (K*6L ft) | PA (K*NS^2) | Sinv (K*NS^2) | Wk (K*NS^2)
     int n_pad, m_pad, K;
-    int D, E, lo, hi, rho, Sv, Sw, Sc, Wm, Wd, Wc, PA, Sinv, Wk, total;
-    DEKF_HD void init(int N, int L) {
+    int D, E, lo, hi, rho, Sv, Sw, Sc, Sf, Wm, Wd, Wc, Wf, PA, Sinv, Wk, total;
+    DEKF_HD void init(int N, int L, int ft = 0) {
         K = N;
-        int nm = 3 * L;
-        n_pad = N * (9 + nm + 12);
-        m_pad = N * (nm + 12);
+        const int nm = 3 * L, ns = 9 + (ft ? nm : 0), b2 = ns * ns;
+        n_pad = N * (2 * ns + nm + 3);
+        m_pad = N * (nm + ns + 3);
         int o = 0;
         D = o; o += n_pad;
         E = o; o += m_pad;
@@ -105,12 +112,14 @@ struct Gws {
         Sv = o; o += K * 6 * L;
         Sw = o; o += K * 25;  // SWS (mhe_solve_core.h)
         Sc = o; o += K * 6;
+        Sf = o; o += ft ? K * 6 * L : 0;
         Wm = o; o += K * 6 * L;
         Wd = o; o += K * 24;
         Wc = o; o += K * 6;
-        PA = o; o += K * 81;
-        Sinv = o; o += K * 81;
-        Wk = o; o += K * 81;
+        Wf = o; o += ft ? K * 6 * L : 0;
+        PA = o; o += K * b2;
+        Sinv = o; o += K * b2;
+        Wk = o; o += K * b2;
         total = o;
     }
 };

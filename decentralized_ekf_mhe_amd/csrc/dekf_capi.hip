@@ -31,6 +31,13 @@ DEKF_DECL_SOLVE(1)
 DEKF_DECL_SOLVE(2)
 DEKF_DECL_SOLVE(3)
 DEKF_DECL_SOLVE(4)
+#define DEKF_DECL_SOLVE_FOOT(LEGS)                                                                        \
+    __global__ void k_mhe_solve_foot_lg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);     \
+    __global__ void k_mhe_solve_foot_gg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);
+DEKF_DECL_SOLVE_FOOT(1)
+DEKF_DECL_SOLVE_FOOT(2)
+DEKF_DECL_SOLVE_FOOT(3)
+DEKF_DECL_SOLVE_FOOT(4)
 __global__ void k_kf_initialize(DevCfg c, DevState s);
 __global__ void k_kf_update(DevCfg c, DevState s, int pushes);
 __global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* t_pre, const double* t_now,
@@ -198,7 +205,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
         h->own_stream = true;
     }
     SolveLayout lay;
-    lay.init(c.N, c.L);
+    lay.init(c.N, c.L, c.ft);
     h->lds_solve = lay.lds_bytes();
 #ifdef DEKF_PROFILE
     // diagnostic build only: DEKF_DEBUG_LDS_PAD=<bytes> inflates the request (e.g. to force one workgroup per CU)
@@ -212,17 +219,22 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
         h->solve_kernel = table[c.L - 1][lay.pa_in_lds() ? 0 : (lay.factor_in_lds() ? 1 : 2)];
         if (c.L == 4 && c.N == 20 && lay.pa_in_lds()) h->solve_kernel = k_mhe_solve_ll_4_n20;
         if (c.L == 2 && c.N == 20 && lay.factor_in_lds() && !lay.pa_in_lds()) h->solve_kernel = k_mhe_solve_lg_2_n20;
+        if (c.ft) {  // foot-position states: their own kernel family (two rows per block in the solve)
+            static const SolveFn foot[4][2] = {{k_mhe_solve_foot_lg_1, k_mhe_solve_foot_gg_1}, {k_mhe_solve_foot_lg_2, k_mhe_solve_foot_gg_2},
+                                               {k_mhe_solve_foot_lg_3, k_mhe_solve_foot_gg_3}, {k_mhe_solve_foot_lg_4, k_mhe_solve_foot_gg_4}};
+            h->solve_kernel = foot[c.L - 1][lay.factor_in_lds() ? 0 : 1];
+        }
 #ifdef DEKF_PROFILE
         // diagnostic build only: DEKF_DEBUG_PLACEMENT=1|2 forces the _lg / _gg placement (2 also shrinks the LDS request)
         if (const char* pl = getenv("DEKF_DEBUG_PLACEMENT")) {
             int p = atoi(pl);
-            if (p == 1 || p == 2) h->solve_kernel = table[c.L - 1][p];
+            if ((p == 1 || p == 2) && !c.ft) h->solve_kernel = table[c.L - 1][p];
             if (p == 2) h->lds_solve = (size_t)lay.vec * sizeof(double);
         }
 #endif
     }
-    h->lds_asm = (size_t)AsmScratch::len(c.L) * sizeof(double);
-    h->lds_kf = (size_t)KfScratch::len(c.L) * sizeof(double);
+    h->lds_asm = (size_t)AsmScratch::len(c.L, c.ft) * sizeof(double);
+    h->lds_kf = (size_t)KfScratch::len(c.L, c.ft) * sizeof(double);
     if (h->lds_solve > 160 * 1024) {
         dekf_destroy(h);
         return fail(DEKF_ERR_INVALID, "window too large: ADMM iterates exceed the 160 KiB LDS of one CU");
@@ -235,7 +247,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     long slots = (long)per_cu * prop.multiProcessorCount;
     h->solve_grid = (int)(slots < batch ? slots : batch);
     Gws g;
-    g.init(c.N, c.L);
+    g.init(c.N, c.L, c.ft);
     h->gws_len = g.total;
     bool ok = true;
     alloc_state(h->c, h->s, h->solve_grid, [&](size_t bytes) -> void* {
@@ -441,7 +453,7 @@ dekf_status dekf_get(dekf_handle h, double* x_mhe, double* v_b, double* quat, do
     if (!h) return fail(DEKF_ERR_INVALID, "null handle");
     size_t B = h->c.B;
     dekf_status st;
-    if ((st = fetch(h, x_mhe, h->s.x_mhe, 9 * B * 8, where))) return st;
+    if ((st = fetch(h, x_mhe, h->s.x_mhe, (size_t)h->c.ns * B * 8, where))) return st;
     if ((st = fetch(h, v_b, h->s.v_b, 3 * B * 8, where))) return st;
     if ((st = fetch(h, quat, h->s.quat, 4 * B * 8, where))) return st;
     if ((st = fetch(h, p_vo, h->s.p_vo, 3 * B * 8, where))) return st;
@@ -484,7 +496,7 @@ dekf_status dekf_get_solver_info(dekf_handle h, int* iters, int* rho_updates, do
 
 dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where) {
     if (!h || !cov) return fail(DEKF_ERR_INVALID, "null argument");
-    dekf_status st = fetch(h, cov, h->s.kf_C, 81 * (size_t)h->c.B * 8, where);
+    dekf_status st = fetch(h, cov, h->s.kf_C, (size_t)h->c.ns * h->c.ns * h->c.B * 8, where);
     if (st) return st;
     if (where == DEKF_HOST) HIPCHK(hipStreamSynchronize(h->stream));
     return DEKF_OK;

@@ -49,7 +49,7 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     if (B < 1) return "batch must be >= 1";
     if (p.num_legs < 1 || p.num_legs > DEKF_MAX_LEGS) return "num_legs out of range";
     if (p.joints_per_leg < 1 || p.joints_per_leg > DEKF_MAX_JOINTS) return "joints_per_leg out of range";
-    if (p.leg_odom_type != 0) return "leg_odom_type 1 (foot-position states) is not implemented";
+    if (p.leg_odom_type != 0 && p.leg_odom_type != 1) return "leg_odom_type must be 0 (foot velocity) or 1 (foot position)";
     if (p.est_type != 0 && p.est_type != 1) return "est_type must be 0 (MHE) or 1 (KF)";
     if (p.N < 2 || p.N > 128) return "N out of range [2,128]";
     if (p.rate < 1 || p.ekf_rate < 1) return "rate must be positive";
@@ -58,8 +58,9 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     if (!(p.sigma > 0) || !(p.rho > 0) || !(p.alpha > 0 && p.alpha < 2)) return "rho/sigma/alpha out of range";
     std::memset(&c, 0, sizeof(c));
     c.B = B; c.L = p.num_legs; c.nj = p.joints_per_leg; c.N = p.N; c.nm = 3 * p.num_legs;
-    c.SV = 9 + c.nm + 12; c.SC = c.nm + 12;
-    c.ring = 4 * p.N + 1; c.wcap = p.N + 1; c.rec = Rec::len(c.L);
+    c.ft = p.leg_odom_type; c.ns = 9 + 3 * c.ft * c.L;
+    c.SV = 2 * c.ns + c.nm + 3; c.SC = c.nm + c.ns + 3;
+    c.ring = 4 * p.N + 1; c.wcap = p.N + 1; c.rec = Rec::len(c.L, c.ft);
     c.est_type = p.est_type;
     c.dt = 1.0 / (double)p.rate;
     auto sq = [](double v) { return v * v; };
@@ -70,6 +71,10 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
         c.C_gyro[i] = sq(p.gyro_input_std[i]);
         c.C_swing[i] = sq(p.foot_swing_std[i]);
         c.Q_swing[i] = 1.0 / sq(p.foot_swing_std[i]);
+        c.C_slide[i] = sq(p.foot_slide_std[i]);
+        c.Q_slide[i] = 1.0 / sq(p.foot_slide_std[i]);
+        c.C_foot_init[i] = sq(p.foot_init_std[i]);
+        c.Q_foot_init[i] = 1.0 / sq(p.foot_init_std[i]);
         c.Q_vo[i] = 1.0 / sq(p.vo_p_std[i]);
         c.Q_bias_dt2[i] = 1 / (c.dt * c.dt) * (1.0 / sq(p.accel_bias_std[i]));
         c.Q_prior[i] = 1.0 / sq(p.p_init_std[i]);
@@ -109,14 +114,15 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
     s.ekf_vo_flag = I(B); s.ekf_vo_t = D(B); s.ekf_vo_q = D(4 * B);
     s.ekf_q = D(4 * B); s.ekf_P = D(16 * B); s.ekf_hist = D((size_t)c.ekf_hist * EKF_HIST_REC * B);
     s.st_time = D((size_t)c.ring * B); s.st_R = D((size_t)c.ring * 9 * B); s.st_dtime = I((size_t)c.ring * B);
-    s.rec = D((size_t)c.wcap * c.rec * B); s.Mp = D(81 * B); s.np_ = D(9 * B);
+    const size_t ns = (size_t)c.ns;
+    s.rec = D((size_t)c.wcap * c.rec * B); s.Mp = D(ns * ns * B); s.np_ = D(ns * B);
     s.wp = D(12 * B); s.wpt = D(4 * B); s.wp_count = I(B);
     s.p_vo = D(3 * B); s.vo_ins_idx = I(B); s.vo_ins_dtime = I(B);
     Gws g;
-    g.init(c.N, c.L);
+    g.init(c.N, c.L, c.ft);
     s.gws = D((size_t)solve_slots * g.total);
-    s.kf_x = D(9 * B); s.kf_C = D(81 * B);
-    s.x_mhe = D(9 * B); s.v_b = D(3 * B);
+    s.kf_x = D(ns * B); s.kf_C = D(ns * ns * B);
+    s.x_mhe = D(ns * B); s.v_b = D(3 * B);
     s.status = I(B); s.iters = I(B); s.rho_updates = I(B);
     s.pri_res = D(B); s.dua_res = D(B);
     s.prof = D(16 * B);

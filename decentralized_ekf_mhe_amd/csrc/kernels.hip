@@ -79,6 +79,24 @@ DEKF_SOLVE_KERNELS(1)
 DEKF_SOLVE_KERNELS(2)
 DEKF_SOLVE_KERNELS(3)
 DEKF_SOLVE_KERNELS(4)
+// leg_odom_type 1: the foot positions are states (9 + 3 LEGS per window step, 21 for Go1).  Two placements: factor in
+// LDS with the factor-time temporary in HBM (short windows), factor streamed from the workgroup's HBM slab (Go1, N = 20:
+// S^-1 and W alone are 141 KB).
+#define DEKF_SOLVE_KERNEL_FOOT(NAME, LEGS, FL)                                                                \
+    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_SOLVE_MIN_WAVES) NAME(DevCfg c, DevState s, int kstart, int K, \
+                                                                  int gws_len) {                             \
+        extern __shared__ double lds[];                                                                      \
+        double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                                  \
+        for (int b = blockIdx.x; b < c.B; b += gridDim.x)                                                    \
+            solve_window<LEGS, FL, false, 0, 1>(c, s, b, kstart, K, lds, gws);                               \
+    }
+#define DEKF_SOLVE_KERNELS_FOOT(LEGS)                               \
+    DEKF_SOLVE_KERNEL_FOOT(k_mhe_solve_foot_lg_##LEGS, LEGS, true)  \
+    DEKF_SOLVE_KERNEL_FOOT(k_mhe_solve_foot_gg_##LEGS, LEGS, false)
+DEKF_SOLVE_KERNELS_FOOT(1)
+DEKF_SOLVE_KERNELS_FOOT(2)
+DEKF_SOLVE_KERNELS_FOOT(3)
+DEKF_SOLVE_KERNELS_FOOT(4)
 
 __global__ void __launch_bounds__(64) k_kf_initialize(DevCfg c, DevState s) {
     extern __shared__ double lds[];
@@ -143,7 +161,7 @@ __global__ void k_reset_state(DevCfg c, DevState s) {
     s.ekf_vo_flag[b] = 0;
     s.wp_count[b] = 0;
     for (int i = 0; i < 3; ++i) s.p_vo[3 * (size_t)b + i] = 0.0;
-    for (int i = 0; i < 9; ++i) s.x_mhe[9 * (size_t)b + i] = 0.0;
+    for (int i = 0; i < c.ns; ++i) s.x_mhe[(size_t)c.ns * b + i] = 0.0;
     for (int i = 0; i < 3; ++i) s.v_b[3 * (size_t)b + i] = 0.0;
     s.status[b] = DEKF_SOLVE_NONE;
     s.iters[b] = 0;

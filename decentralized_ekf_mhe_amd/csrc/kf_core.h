@@ -11,37 +11,39 @@
 namespace dekf {
 
 struct KfScratch {
-    DEKF_HD static int len(int L) {
-        int nm = 3 * L;
-        return 81 * 3 + nm * nm * 2 + nm + 9 * nm * 2 + 32;
+    DEKF_HD static int len(int L, int ft = 0) {
+        const int nm = 3 * L, ns = 9 + (ft ? nm : 0);
+        return ns * ns * 3 + nm * nm * 2 + nm + ns * nm * 2 + ns + 32;
     }
 };
 
 // x <- A x - b ; C <- A C A' + G C_in G'   with the sample stored in record `r`
+// (foot-position states: identity dynamics, process noise dt^2 R C_{slide|swing} R' per foot, DecentralEst.cpp:753)
 DEKF_FN void kf_predict(const DevCfg& c, const DevState& s, int b, const double* r, double* sm) {
-    double* x = s.kf_x + 9 * (size_t)b;
-    double* C = s.kf_C + 81 * (size_t)b;
-    double* A = sm;         // 81
-    double* AC = A + 81;    // 81
-    double* xn = AC + 81;   // 9
+    const int ns = c.ns, n2 = ns * ns;
+    double* x = s.kf_x + (size_t)ns * b;
+    double* C = s.kf_C + (size_t)n2 * b;
+    double* A = sm;         // ns x ns
+    double* AC = A + n2;    // ns x ns
+    double* xn = AC + n2;   // ns
     const double* R = r + Rec::R;
     const double dt = c.dt;
-    wfor(81 + 9, [&](int e) {
-        if (e < 81) A[e] = adyn_entry(R, dt, e / 9, e % 9);
+    wfor(n2 + ns, [&](int e) {
+        if (e < n2) A[e] = adyn_entry(R, dt, e / ns, e % ns);
         else {
-            int i = e - 81;
+            int i = e - n2;
             double acc = 0;
-            for (int t = 0; t < 9; ++t) acc += adyn_entry(R, dt, i, t) * x[t];
+            for (int t = 0; t < ns; ++t) acc += adyn_entry(R, dt, i, t) * x[t];
             double bd = i < 3 ? -0.5 * dt * dt * r[Rec::AS + i] : (i < 6 ? -dt * r[Rec::AS + i - 3] : 0.0);
             xn[i] = acc - bd;
         }
     });
-    wmatmul<false, false>(AC, 9, A, 9, C, 9, 9, 9, 9);
-    wfor(81 + 9, [&](int e) {
-        if (e >= 81) { x[e - 81] = xn[e - 81]; return; }
-        int i = e / 9, j = e - 9 * i;
+    wmatmul<false, false>(AC, ns, A, ns, C, ns, ns, ns, ns);
+    wfor(n2 + ns, [&](int e) {
+        if (e >= n2) { x[e - n2] = xn[e - n2]; return; }
+        int i = e / ns, j = e - ns * i;
         double acc = 0;
-        for (int t = 0; t < 9; ++t) acc += AC[9 * i + t] * A[9 * j + t];
+        for (int t = 0; t < ns; ++t) acc += AC[ns * i + t] * A[ns * j + t];
         // G C_in G' (DecentralEst.cpp:742-751, 784)
         int bi = i / 3, bj = j / 3, a = i % 3, d = j % 3;
         auto rcr = [&](const double* cv) {
@@ -53,23 +55,29 @@ DEKF_FN void kf_predict(const DevCfg& c, const DevState& s, int b, const double*
         else if ((bi == 0 && bj == 1) || (bi == 1 && bj == 0)) acc += 0.5 * dt * dt * dt * rcr(c.C_accel);
         else if (bi == 1 && bj == 1) acc += dt * dt * rcr(c.C_accel);
         else if (bi == 2 && bj == 2 && a == d) acc += dt * dt * c.C_accel_bias[a];
+        else if (bi >= 3 && bi == bj) acc += symget(r + Rec::qf(c.nm) + 6 * (bi - 3), a, d, 3);  // stored as dt^2 R C R'
         C[e] = acc;
     });
 }
 
-// K = C H'(H C H' + C_meas)^-1 ; x += K (b_meas - H x) ; C = (I - K H) C, H = A_meas (type 0)
+// K = C H'(H C H' + C_meas)^-1 ; x += K (b_meas - H x) ; C = (I - K H) C, H = A_meas
 DEKF_FN void kf_correct(const DevCfg& c, const DevState& s, int b, const double* r, double* sm) {
-    const int nm = c.nm;
-    double* x = s.kf_x + 9 * (size_t)b;
-    double* C = s.kf_C + 81 * (size_t)b;
+    const int nm = c.nm, ns = c.ns, n2 = ns * ns, ft = c.ft;
+    double* x = s.kf_x + (size_t)ns * b;
+    double* C = s.kf_C + (size_t)n2 * b;
     double* S = sm;                   // nm x nm
     double* wsc = S + nm * nm;        // nm*nm + nm
-    double* Kg = wsc + nm * nm + nm;  // 9 x nm
-    double* Cn = Kg + 9 * nm;         // 81
-    double* xn = Cn + 81;             // 9
+    double* Kg = wsc + nm * nm + nm;  // ns x nm
+    double* HC = Kg + ns * nm;        // nm x ns: A_meas C
+    double* Cn = HC + ns * nm;        // ns x ns
+    double* xn = Cn + n2;             // ns
+    wfor(nm * ns, [&](int e) {
+        int q = e / ns, t = e - q * ns;
+        HC[e] = ameas_dot_strided(ft, C + t, ns, q);
+    });
     wfor(nm * nm, [&](int e) {
         int i = e / nm, j = e - nm * i;
-        double v = C[9 * (3 + i % 3) + 3 + j % 3];
+        double v = ameas_dot(ft, HC + i * ns, j);
         if (i / 3 == j / 3) v += symget(r + Rec::qm(nm) + 6 * (i / 3), i % 3, j % 3, 3);
         S[e] = v;
     });
@@ -103,38 +111,39 @@ DEKF_FN void kf_correct(const DevCfg& c, const DevState& s, int b, const double*
 #else
     winverse(S, nm, wsc, true);
 #endif
-    wfor(9 * nm, [&](int e) {
+    wfor(ns * nm, [&](int e) {  // K = (H C)' S^-1  (C symmetric)
         int i = e / nm, j = e - nm * i;
         double acc = 0;
-        for (int t = 0; t < nm; ++t) acc += C[9 * i + 3 + t % 3] * S[t * nm + j];
+        for (int t = 0; t < nm; ++t) acc += ameas_dot_strided(ft, C + ns * i, 1, t) * S[t * nm + j];
         Kg[e] = acc;
     });
-    wfor(81 + 9, [&](int e) {
-        if (e < 81) {
-            int i = e / 9, j = e - 9 * i;
+    wfor(n2 + ns, [&](int e) {
+        if (e < n2) {
+            int i = e / ns, j = e - ns * i;
             double acc = C[e];
-            for (int t = 0; t < nm; ++t) acc -= Kg[i * nm + t] * C[9 * (3 + t % 3) + j];
+            for (int t = 0; t < nm; ++t) acc -= Kg[i * nm + t] * HC[t * ns + j];
             Cn[e] = acc;
         } else {
-            int i = e - 81;
+            int i = e - n2;
             double acc = x[i];
-            for (int t = 0; t < nm; ++t) acc += Kg[i * nm + t] * (r[Rec::BM + t] - x[3 + t % 3]);
+            for (int t = 0; t < nm; ++t) acc += Kg[i * nm + t] * (r[Rec::BM + t] - ameas_dot(ft, x, t));
             xn[i] = acc;
         }
     });
-    wfor(90, [&](int e) { if (e < 81) C[e] = Cn[e]; else x[e - 81] = xn[e - 81]; });
+    wfor(n2 + ns, [&](int e) { if (e < n2) C[e] = Cn[e]; else x[e - n2] = xn[e - n2]; });
 }
 
 // v_KF_b_ is only written by update(), not by initialize() (DecentralEst.cpp:189-196)
 DEKF_FN void kf_output(const DevCfg& c, const DevState& s, int b, const double* r, bool write_vb) {
     if (DEKF_LANE() == 0) {
-        const double* x = s.kf_x + 9 * (size_t)b;
+        const int ns = c.ns;
+        const double* x = s.kf_x + (size_t)ns * b;
         const double p_opti[3] = {0.016041, 0.089061, 0.0579875};
         double wxp[3], t[3], vb[3];
         cross3(r + Rec::GY, p_opti, wxp);
         for (int a = 0; a < 3; ++a) t[a] = x[3 + a] + wxp[a];
         mv3(r + Rec::R, t, vb);
-        for (int j = 0; j < 9; ++j) s.x_mhe[9 * (size_t)b + j] = x[j];
+        for (int j = 0; j < ns; ++j) s.x_mhe[(size_t)ns * b + j] = x[j];
         if (write_vb)
             for (int a = 0; a < 3; ++a) s.v_b[3 * (size_t)b + a] = vb[a];
         s.status[b] = DEKF_SOLVE_NONE;
@@ -157,13 +166,15 @@ DEKF_FN void kf_update(const DevCfg& c, const DevState& s, int b, int pushes, do
 DEKF_FN void kf_initialize(const DevCfg& c, const DevState& s, int b, double* sm) {
     get_measurement(c, s, b, 0, 0, sm);
     write_measurement_record(c, s, b, 0, false);
-    double* x = s.kf_x + 9 * (size_t)b;
-    double* C = s.kf_C + 81 * (size_t)b;
-    wfor(90, [&](int e) {
-        if (e < 81) C[e] = (e / 9 == e % 9) ? c.C_prior[e / 9] : 0.0;
-        else x[e - 81] = 0.0;
-    });
+    DEKF_SYNC();
+    const int ns = c.ns, n2 = ns * ns;
+    double* x = s.kf_x + (size_t)ns * b;
+    double* C = s.kf_C + (size_t)n2 * b;
     const double* r0 = s.rec + ((size_t)b * c.wcap + 0) * c.rec;
+    wfor(n2 + ns, [&](int e) {
+        if (e < n2) { const int i = e / ns; C[e] = (i == e % ns) ? (i < 9 ? c.C_prior[i] : c.C_foot_init[(i - 9) % 3]) : 0.0; }
+        else { const int i = e - n2; x[i] = i < 9 ? 0.0 : r0[Rec::BM + i - 9]; }  // prior mean of a foot: its first measurement (:640)
+    });
     kf_correct(c, s, b, r0, sm);
     kf_update(c, s, b, 1, sm, false);
 }

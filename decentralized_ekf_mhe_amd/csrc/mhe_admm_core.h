@@ -32,7 +32,20 @@ DEKF_FN double gather_pcol(const Q& q, int k, int a, WF w) {
     const bool hn = k < q.K - 1, hp = k > 0;
     const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
     const double n0 = w(q.ix.rd(kn, a)), n1 = w(q.ix.rv(kn, a)), p0 = w(q.ix.rd(kp, a)), p1 = w(q.ix.rv(kp, a));
-    return (hn ? n0 + n1 : 0.0) - (hp ? p0 + p1 : 0.0);
+    double g = (hn ? n0 + n1 : 0.0) - (hp ? p0 + p1 : 0.0);
+    if constexpr (Q::FOOT) {  // A_meas = [-I 0 0 .. I ..] (DecentralEst.cpp:106-110)
+#pragma unroll
+        for (int leg = 0; leg < Q::LEGS; ++leg) g -= w(q.ix.rm(k, 3 * leg + a));
+    }
+    return g;
+}
+// foot-position column (leg, a) of step k: its Meas row, the Dyn row of this step (+I) and of the previous one (-I)
+template <class Q, class WF>
+DEKF_FN double gather_fcol(const Q& q, int k, int la, WF w) {
+    const bool hn = k < q.K - 1, hp = k > 0;
+    const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
+    const double m0 = w(q.ix.rm(k, la)), n0 = w(q.ix.rd(kn, 9 + la)), p0 = w(q.ix.rd(kp, 9 + la));
+    return m0 + (hn ? n0 : 0.0) - (hp ? p0 : 0.0);
 }
 template <class Q, class WF>
 DEKF_FN double gather_vcol(const Q& q, int k, int a, WF w) {
@@ -41,8 +54,10 @@ DEKF_FN double gather_vcol(const Q& q, int k, int a, WF w) {
     const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
     const double n0 = w(q.ix.rd(kn, 3 + a)), n1 = w(q.ix.rd(kn, a)), p0 = w(q.ix.rd(kp, 3 + a));
     double g = 0.0;
+    if constexpr (!Q::FOOT) {
 #pragma unroll
-    for (int leg = 0; leg < L; ++leg) g += w(q.ix.rm(k, 3 * leg + a));
+        for (int leg = 0; leg < L; ++leg) g += w(q.ix.rm(k, 3 * leg + a));
+    }
     return g + (hn ? n0 + q.c.dt * n1 : 0.0) - (hp ? p0 : 0.0);
 }
 template <class Q, class WF>
@@ -64,15 +79,25 @@ DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
 // kind (position / velocity / bias) because their gathers differ.
 template <class Q>
 DEKF_FN void phase_xcols(Q& q, double sigma) {
-    constexpr int SV = 21 + 3 * Q::LEGS;
+    constexpr int NS = Q::NS, NM = 3 * Q::LEGS, SV = 2 * NS + 3 + NM;
     const int K = q.K, n3 = 3 * K, nt = (n3 + 63) >> 6;
-    const double* qsl = q.tmp + 162;
+    const int ntf = Q::FOOT ? (NM * K + 63) >> 6 : 0;
+    const double* qsl = q.tmp + TmpMap<NS>::QSL;
     const double* at = q.at;
     auto w = [&](int r) { return at[r]; };
 #if defined(DEKF_PROFILE_TL) && defined(DEKF_PROFILE_TLX)  // -DDEKF_PROFILE_TLX: slots 4.. and 8.. describe phase X instead of the row phase
     const long long tx0 = clock64();
 #endif
-    wtiles(3 * nt, [&](int tile, int lane) {
+    wtiles(3 * nt + ntf, [&](int tile, int lane) {
+        if (Q::FOOT && tile >= 3 * nt) {  // foot-position columns
+            const int e = (tile - 3 * nt) * 64 + lane;
+            if (e >= NM * K) return;
+            const int k = e / NM, la = e - NM * k, j = 9 + la, i = k * SV + j;
+            const double xv = q.x[i], dv = q.D[i], qv = qsl[j];
+            const double g = gather_fcol(q, k, la, w);
+            q.xs[NS * k + j] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
+            return;
+        }
         const int kind = tile < nt ? 0 : (tile < 2 * nt ? 1 : 2);
         const int e = (tile - kind * nt) * 64 + lane;
         if (e >= n3) return;
@@ -87,7 +112,7 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
             const double n0 = w(q.ix.rd(kn, 6 + a)), n1 = q.gb[3 * kn + a], p0 = w(q.ix.rd(kp, 6 + a));
             g = (hn ? n0 - n1 : 0.0) - (hp ? p0 : 0.0);
         }
-        q.xs[9 * k + j] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
+        q.xs[NS * k + j] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
     });
 #if defined(DEKF_PROFILE_TL) && defined(DEKF_PROFILE_TLX)
     __builtin_amdgcn_s_waitcnt(0);
@@ -433,11 +458,246 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
 }
 #endif
 
+// ---------------------------------------------------------------- S for state blocks wider than a DPP row
+// With foot-position states a block has NS = 9 + 3 L entries (21 for Go1): its running vector no longer fits the 16
+// lanes a DPP row broadcast reaches.  TWO ROWS PER BLOCK: row 2s holds components 0..15 of side s, row 2s + 1 components
+// 16..NS-1; every lane keeps BOTH halves of the running vector of its side (va: lane li holds v[li], vb: lane li holds
+// v[16 + li]), so a lane's NS products are NS DPP-broadcast FMAs on its own row (16 on va, NS - 16 on vb), and ONE
+// v_permlane16_swap per 32-bit half redistributes the new components (even rows -> va of the pair, odd rows -> vb).
+// Rows 0/1 run the top leg and rows 2/3 the bottom leg of the two-sided solve in lock step: both legs of a phase on one
+// wavefront, no workgroup barrier inside a phase.  Host build: plain loops.
+#if DEKF_DEVICE_BUILD
+struct RowPairVec { double va, vb; };
+DEKF_FN RowPairVec pair_redistribute(double own) {  // rows [r0 r1 r2 r3] -> va = [r0 r0 r2 r2], vb = [r1 r1 r3 r3]
+    unsigned lo = (unsigned)__double2loint(own), hi = (unsigned)__double2hiint(own);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    RowPairVec r;
+    r.va = __hiloint2double((int)b[0], (int)a[0]);
+    r.vb = __hiloint2double((int)b[1], (int)a[1]);
+    return r;
+}
+template <int NS>
+DEKF_FN double pair_matvec_dpp(double va, double vb, const double* w, double rhs) {
+    static_assert(NS > 9 && NS <= 32, "two rows per block");
+    double a0 = rhs, a1 = 0.0;
+#define DEKF_PFMAC(pre, acc, src, T, IDX)                                                                          \
+    if constexpr (NS > IDX)                                                                                        \
+        asm volatile(pre "v_fmac_f64_dpp %0, %1, -%2 row_newbcast:" #T " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(w[IDX]))
+    DEKF_PFMAC("s_nop 1\n\t", a0, va, 0, 0); DEKF_PFMAC("", a1, va, 1, 1); DEKF_PFMAC("", a0, va, 2, 2); DEKF_PFMAC("", a1, va, 3, 3);
+    DEKF_PFMAC("", a0, va, 4, 4); DEKF_PFMAC("", a1, va, 5, 5); DEKF_PFMAC("", a0, va, 6, 6); DEKF_PFMAC("", a1, va, 7, 7);
+    DEKF_PFMAC("", a0, va, 8, 8); DEKF_PFMAC("", a1, va, 9, 9); DEKF_PFMAC("", a0, va, 10, 10); DEKF_PFMAC("", a1, va, 11, 11);
+    DEKF_PFMAC("", a0, va, 12, 12); DEKF_PFMAC("", a1, va, 13, 13); DEKF_PFMAC("", a0, va, 14, 14); DEKF_PFMAC("", a1, va, 15, 15);
+    DEKF_PFMAC("s_nop 1\n\t", a0, vb, 0, 16); DEKF_PFMAC("", a1, vb, 1, 17); DEKF_PFMAC("", a0, vb, 2, 18); DEKF_PFMAC("", a1, vb, 3, 19);
+    DEKF_PFMAC("", a0, vb, 4, 20); DEKF_PFMAC("", a1, vb, 5, 21); DEKF_PFMAC("", a0, vb, 6, 22); DEKF_PFMAC("", a1, vb, 7, 23);
+    DEKF_PFMAC("", a0, vb, 8, 24); DEKF_PFMAC("", a1, vb, 9, 25); DEKF_PFMAC("", a0, vb, 10, 26); DEKF_PFMAC("", a1, vb, 11, 27);
+    DEKF_PFMAC("", a0, vb, 12, 28); DEKF_PFMAC("", a1, vb, 13, 29); DEKF_PFMAC("", a0, vb, 14, 30); DEKF_PFMAC("", a1, vb, 15, 31);
+#undef DEKF_PFMAC
+    return a0 + a1;
+}
+#endif
+
+// both legs of one phase of the two-sided solve.  Forward (BWD = false): f_k = b_k - W_{k-1} f_{k-1} downwards from block 0
+// and f^_k = b_k - W^_k f^_{k+1} upwards from block K-1, in xs.  Outward (BWD = true): u_k = g_k - W_k' u_{k+1} from the
+// meeting block to block 0 and u_k = g_k - W^_{k-1}' u_{k-1} to block K-1; leaves xd = D .* u and the relaxed x.
+template <bool BWD, class Q>
+DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
+    constexpr int NS = Q::NS, NS2 = Q::NS2, SV = 2 * NS + 3 + 3 * Q::LEGS;
+    const int K = q.K, mid = mid_block(K);
+    double *xs = q.xs, *xd = q.xd, *x = q.x;
+    // side 0 (top): blocks k0 + s dk; the matrix of step s is Wk[kn + wofs], transposed on the way out
+    const int k0s[2] = {BWD ? mid : 0, BWD ? mid : K - 1};
+    const int dks[2] = {BWD ? -1 : 1, BWD ? 1 : -1};
+    const int nst[2] = {mid, BWD ? K - 1 - mid : K - 2 - mid};
+    const int wof[2] = {BWD ? 0 : -1, BWD ? -1 : 0};
+#if DEKF_DEVICE_BUILD
+    const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15, side = row >> 1, half = row & 1;
+    const int ic = half * 16 + li;
+    const bool act = ic < NS;
+    const int i = act ? ic : NS - 1;
+    const int k0 = k0s[side], dk = dks[side], steps = nst[side], wofs = wof[side];
+    const int smax = nst[0] > nst[1] ? nst[0] : nst[1];
+    struct Ops { double w[NS], rhs, dsc, xo; };
+    auto load = [&](int s, Ops& o) {
+        const int sc = s <= steps ? s : (steps > 0 ? steps : 1);  // a finished (or empty) side re-reads a valid block
+        const int kn = steps > 0 ? k0 + sc * dk : k0;
+        const int kw = steps > 0 ? kn + wofs : (k0 + wofs >= 0 && k0 + wofs < K - 1 ? k0 + wofs : 0);
+        const double* W = q.Wk + kw * NS2;
+#pragma unroll
+        for (int t = 0; t < NS; ++t) o.w[t] = BWD ? W[NS * t + i] : W[NS * i + t];
+        o.rhs = BWD ? xd[NS * kn + i] : xs[NS * kn + i];
+        o.dsc = BWD ? q.D[kn * SV + i] : 0.0;
+        o.xo = BWD ? x[kn * SV + i] : 0.0;
+    };
+    double va = xs[NS * k0 + li], vb = xs[NS * k0 + (16 + li < NS ? 16 + li : NS - 1)];
+    auto step = [&](int s, const Ops& c) {
+        const double own = pair_matvec_dpp<NS>(va, vb, c.w, c.rhs);
+        const RowPairVec nv = pair_redistribute(own);
+        va = nv.va;
+        vb = nv.vb;
+        if (act && s <= steps) {
+            const int kn = k0 + s * dk;
+            if (BWD) {
+                xd[NS * kn + i] = c.dsc * own;
+                x[kn * SV + i] = alpha * own + (1.0 - alpha) * c.xo;
+            } else {
+                xs[NS * kn + i] = own;
+            }
+        }
+    };
+    if (smax > 0) {
+        Ops o0, o1;
+        load(1, o0);
+        for (int s = 1; s <= smax; s += 2) {
+            if (s + 1 <= smax) load(s + 1, o1);
+            step(s, o0);
+            if (s + 1 <= smax) {
+                if (s + 2 <= smax) load(s + 2, o0);
+                step(s + 1, o1);
+            }
+        }
+    }
+#else
+    for (int side = 0; side < 2; ++side) {
+        const int k0 = k0s[side], dk = dks[side], steps = nst[side], wofs = wof[side];
+        double v[NS], nv[NS];
+        for (int i = 0; i < NS; ++i) v[i] = xs[NS * k0 + i];
+        for (int s = 1; s <= steps; ++s) {
+            const int kn = k0 + s * dk;
+            const double* W = q.Wk + (kn + wofs) * NS2;
+            for (int i = 0; i < NS; ++i) {
+                double a0 = BWD ? xd[NS * kn + i] : xs[NS * kn + i], a1 = 0.0;
+                for (int t = 0; t < NS; ++t) {
+                    const double wt = BWD ? W[NS * t + i] : W[NS * i + t];
+                    if (t & 1) a1 -= wt * v[t]; else a0 -= wt * v[t];
+                }
+                nv[i] = a0 + a1;
+            }
+            for (int i = 0; i < NS; ++i) {
+                v[i] = nv[i];
+                if (BWD) {
+                    xd[NS * kn + i] = q.D[kn * SV + i] * v[i];
+                    x[kn * SV + i] = alpha * v[i] + (1.0 - alpha) * x[kn * SV + i];
+                } else {
+                    xs[NS * kn + i] = v[i];
+                }
+            }
+        }
+    }
+#endif
+}
+
+// the meeting block for any NS: f_m -= W^_m f^_{m+1}, u_m = S_m^-1 f_m (f_m passes through LDS between the two products)
+template <class Q>
+DEKF_FN void sweep_mid_block_generic(Q& q, int lane, double alpha) {
+    constexpr int NS = Q::NS, NS2 = Q::NS2, SV = 2 * NS + 3 + 3 * Q::LEGS;
+    const int K = q.K, mid = mid_block(K);
+    double *xs = q.xs, *xd = q.xd, *x = q.x;
+    const double* Si = q.Sinv + mid * NS2;
+    double* ft = q.tmp + TmpMap<NS>::SIDE0;  // factor-time scratch, free during the iterations
+#if DEKF_DEVICE_BUILD
+    const int i = lane < NS ? lane : NS - 1;
+    double f = xs[NS * mid + i];
+    if (mid < K - 1) {
+        const double* W = q.Wk + mid * NS2 + NS * i;
+        const double* fh = xs + NS * (mid + 1);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int t = 0; t + 2 < NS; t += 3) { a0 += W[t] * fh[t]; a1 += W[t + 1] * fh[t + 1]; a2 += W[t + 2] * fh[t + 2]; }
+        f -= a0 + (a1 + a2);
+    }
+    if (lane < NS) ft[lane] = f;
+    wave_sync();
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int t = 0; t + 2 < NS; t += 3) { a0 += Si[NS * i + t] * ft[t]; a1 += Si[NS * i + t + 1] * ft[t + 1]; a2 += Si[NS * i + t + 2] * ft[t + 2]; }
+    const double u = a0 + (a1 + a2);
+    if (lane < NS) {
+        const int xi = mid * SV + i;
+        xs[NS * mid + i] = u;
+        xd[NS * mid + i] = q.D[xi] * u;
+        x[xi] = alpha * u + (1.0 - alpha) * x[xi];
+    }
+#else
+    if (lane != 0) return;
+    for (int i = 0; i < NS; ++i) {
+        double f = xs[NS * mid + i];
+        if (mid < K - 1) {
+            const double* W = q.Wk + mid * NS2 + NS * i;
+            const double* fh = xs + NS * (mid + 1);
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+            for (int t = 0; t + 2 < NS; t += 3) { a0 += W[t] * fh[t]; a1 += W[t + 1] * fh[t + 1]; a2 += W[t + 2] * fh[t + 2]; }
+            f -= a0 + (a1 + a2);
+        }
+        ft[i] = f;
+    }
+    for (int i = 0; i < NS; ++i) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+        for (int t = 0; t + 2 < NS; t += 3) { a0 += Si[NS * i + t] * ft[t]; a1 += Si[NS * i + t + 1] * ft[t + 1]; a2 += Si[NS * i + t + 2] * ft[t + 2]; }
+        const double u = a0 + (a1 + a2);
+        const int xi = mid * SV + i;
+        xs[NS * mid + i] = u;
+        xd[NS * mid + i] = q.D[xi] * u;
+        x[xi] = alpha * u + (1.0 - alpha) * x[xi];
+    }
+#endif
+}
+
+template <class Q>
+DEKF_FN void phase_sweeps_generic(Q& q, double alpha) {
+    constexpr int NS = Q::NS, NS2 = Q::NS2;
+    const int K = q.K, mid = mid_block(K);
+#if DEKF_DEVICE_BUILD
+    const bool w0 = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6) == 0;
+    if (w0) {
+        __builtin_amdgcn_s_setprio(3);
+        sweep_legs_generic<false>(q, alpha);
+        __builtin_amdgcn_s_setprio(0);
+    }
+#else
+    sweep_legs_generic<false>(q, alpha);
+#endif
+    DEKF_SYNC();
+    DEKF_PROF_MARK(q, 3);
+    // g_k = S_k^-1 f_k is outside both recursions: one entry per lane, next to the meeting block
+    const int ngt = (K * NS + 63) >> 6;
+    wtiles(1 + ngt, [&](int tile, int lane) {
+        if (tile == 0) { sweep_mid_block_generic(q, lane, alpha); return; }
+        const int e = (tile - 1) * 64 + lane;
+        if (e >= K * NS) return;
+        const int k = e / NS, i = e - NS * k;
+        if (k == mid) return;
+        const double* Si = q.Sinv + k * NS2 + NS * i;
+        const double* f = q.xs + NS * k;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+        for (int t = 0; t + 2 < NS; t += 3) { a0 += Si[t] * f[t]; a1 += Si[t + 1] * f[t + 1]; a2 += Si[t + 2] * f[t + 2]; }
+        q.xd[e] = a0 + (a1 + a2);
+    });
+    DEKF_SYNC();
+    DEKF_PROF_MARK(q, 4);
+#if DEKF_DEVICE_BUILD
+    if (w0) {
+        __builtin_amdgcn_s_setprio(3);
+        sweep_legs_generic<true>(q, alpha);
+        __builtin_amdgcn_s_setprio(0);
+    }
+#else
+    sweep_legs_generic<true>(q, alpha);
+#endif
+    DEKF_SYNC();
+    DEKF_PROF_MARK(q, 5);
+}
+
 // In: xs = reduced right-hand side.  Out: x blocks relaxed, xd = D .* (solution).  The
 // factorisation is two-sided (solve_factor 3d): W_k = C_k S_k^-1 in Wk[k] for k < mid,
 // W^_k = C_k' S^_{k+1}^-1 in Wk[k] for k >= mid.
 template <class Q>
 DEKF_FN void phase_sweeps(Q& q, double alpha) {
+    if constexpr (Q::NS != 9) {
+        phase_sweeps_generic(q, alpha);
+        return;
+    } else {
     const int K = q.K, mid = mid_block(K);
     constexpr int NF = Q::NFIXED, FM = mid_block(NF);  // full window (steady state) of a compile-time horizon
     const bool fixed = NF >= 4 && K == NF;
@@ -499,6 +759,7 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
 #endif
     DEKF_SYNC();
     DEKF_PROF_MARK(q, 5);
+    }  // NS == 9
 }
 
 // ---------------------------------------------------------------- R: rows
@@ -689,7 +950,7 @@ struct DynPairMat {
 // cf, t, w from (x, z, y).  Tiles: [Meas leg blocks][Dyn p+v 6-blocks][VO and Dyn bias blocks].
 template <bool RESTART, class Q>
 DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
-    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
+    constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     const int ntm = (nmeas + 63) >> 6;
 #if DEKF_DEVICE_BUILD
@@ -699,21 +960,23 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
 #endif
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
     const double *xd = q.xd, *E = q.E;
-    // Tile order [Meas | Dyn | VO + bias].  VO blocks and Dyn bias blocks share tiles and ONE code path (3 rows,
-    // a 3x3 symmetric slack-block inverse that is diagonal for the bias rows, the generic projection):
+    // Tile order [Meas | Dyn | VO + bias | foot-position Dyn].  VO blocks and Dyn bias blocks share tiles and ONE code
+    // path (3 rows, a 3x3 symmetric slack-block inverse that is diagonal for the bias rows, the generic projection):
     // as separate kinds they were two tile bodies run one after the other by some wavefront.
     const int nvb = (2 * K1 + 63) >> 6;
-    wtiles(ntm + ntp + nvb, [&](int tile, int lane) {
-        if (tile < ntm) {  // Meas: leg block (k, leg), A_meas = [0 I 0]
+    const int ntf = FT ? (K1 * L + 63) >> 6 : 0;
+    wtiles(ntm + ntp + nvb + ntf, [&](int tile, int lane) {
+        if (tile < ntm) {  // Meas: leg block (k, leg), A_meas = [0 I 0]  (foot-position states: [-I 0 0 .. I ..])
             const int e = tile * 64 + lane;
             if (e >= nmeas) return;
             const int k = e / L, leg = e - k * L;
-            const int r0 = q.ix.rm(k, 3 * leg), sv0 = k * SV + 9 + 3 * leg;
+            const int r0 = q.ix.rm(k, 3 * leg), sv0 = q.ix.v(k, 3 * leg);
             const SymMat<3> S(q.Sv + e * 6);
             if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
             double ar[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * xd[9 * k + 3 + a];
+            for (int a = 0; a < 3; ++a)
+                ar[a] = FT ? E[r0 + a] * (xd[NS * k + 9 + 3 * leg + a] - xd[NS * k + a]) : E[r0 + a] * xd[NS * k + 3 + a];
             row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma);
             return;
         }
@@ -723,7 +986,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             const int pl = td * 64 + lane, k = pl >> 1;
             const bool vel = pl & 1;
             if (k >= K1) return;
-            const int r0 = q.ix.rd(k, vel ? 3 : 0), sv0 = k * SV + 9 + NM + (vel ? 3 : 0);
+            const int r0 = q.ix.rd(k, vel ? 3 : 0), sv0 = q.ix.w(k, vel ? 3 : 0);
             const DynPairMat S(q.Sw + k * SWS, vel);
             const double* R = q.R + 9 * k;
             double Rk[9], wo[3];
@@ -731,14 +994,14 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             for (int t = 0; t < 9; ++t) Rk[t] = R[t];
             if (RESTART) row_block_restart<3, true>(q, r0, sv0, S, sigma, wo);
             else {
-                const double* xk = xd + 9 * k;
+                const double* xk = xd + NS * k;
                 const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
                 const int o = vel ? 3 : 0;
                 double ar[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     const double rb = Rk[3 * a] * xk[6] + Rk[3 * a + 1] * xk[7] + Rk[3 * a + 2] * xk[8];
-                    ar[a] = E[r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+                    ar[a] = E[r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[NS + o + a]);
                 }
                 row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma, true, wo);
             }
@@ -760,8 +1023,8 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
         if (td < ntp) {  // Dyn position + velocity rows: 6x6 slack block on one lane (host build)
             const int k = td * 64 + lane;
             if (k >= K1) return;
-            const double* xk = xd + 9 * k;
-            const int r0 = q.ix.rd(k, 0), sv0 = k * SV + 9 + NM;
+            const double* xk = xd + NS * k;
+            const int r0 = q.ix.rd(k, 0), sv0 = q.ix.w(k, 0);
             const SymMat<6> S(q.Sw + k * SWS);
             const double* R = q.R + 9 * k;
             double wo[6];
@@ -771,8 +1034,8 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     const double rb = R[3 * a] * xk[6] + R[3 * a + 1] * xk[7] + R[3 * a + 2] * xk[8];
-                    ar[a] = E[r0 + a] * (xk[a] + dt * xk[3 + a] - hdt2 * rb - xk[9 + a]);
-                    ar[3 + a] = E[r0 + 3 + a] * (xk[3 + a] - dt * rb - xk[12 + a]);
+                    ar[a] = E[r0 + a] * (xk[a] + dt * xk[3 + a] - hdt2 * rb - xk[NS + a]);
+                    ar[3 + a] = E[r0 + 3 + a] * (xk[3 + a] - dt * rb - xk[NS + 3 + a]);
                 }
                 row_block_update<6, true>(q, r0, sv0, ar, S, alpha, sigma, true, wo);
             }
@@ -783,19 +1046,33 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             }
             return;
         }
-        {   // VO rows (+-inf box or equality, per-row rho) and Dyn bias rows (equalities, diagonal slack block)
+        if (td < ntp + nvb) {   // VO rows (+-inf box or equality, per-row rho) and Dyn bias rows (equalities, diagonal slack block)
             const int idx = (td - ntp) * 64 + lane;
             if (idx >= 2 * K1) return;
             const bool vo = idx < K1;
             const int k = vo ? idx : idx - K1, o = vo ? 0 : 6;
-            const int r0 = vo ? q.ix.rv(k, 0) : q.ix.rd(k, 6), sv0 = k * SV + (vo ? 18 + NM : 9 + NM + 6);
+            const int r0 = vo ? q.ix.rv(k, 0) : q.ix.rd(k, 6), sv0 = vo ? q.ix.c(k, 0) : q.ix.w(k, 6);
             const VoOrBiasMat S(q.Sc + k * 6, q.Sw + k * SWS + 21, vo);
             if (RESTART) { row_block_restart<3, false>(q, r0, sv0, S, sigma); return; }
-            const double* xk = xd + 9 * k;
+            const double* xk = xd + NS * k;
             double ar[3];
 #pragma unroll
-            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[o + a] - xk[9 + o + a]);
+            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[o + a] - xk[NS + o + a]);
             row_block_update<3, false>(q, r0, sv0, ar, S, alpha, sigma, vo);
+            return;
+        }
+        if constexpr (FT) {  // Dyn rows of a foot-position state: f_k - f_{k+1} - w = 0 (identity dynamics, DecentralEst.cpp:395-398)
+            const int e = (td - ntp - nvb) * 64 + lane;
+            if (e >= K1 * L) return;
+            const int k = e / L, leg = e - k * L;
+            const int r0 = q.ix.rd(k, 9 + 3 * leg), sv0 = q.ix.w(k, 9 + 3 * leg);
+            const SymMat<3> S(q.Sf + e * 6);
+            if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
+            const double* xk = xd + NS * k + 9 + 3 * leg;
+            double ar[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[a] - xk[NS + a]);
+            row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma);
         }
     });
     DEKF_SYNC();
@@ -919,7 +1196,7 @@ template <class Q>
 DEKF_FN void phase_sweeps_rows(Q& q, double alpha, double sigma) {
 #if DEKF_DEVICE_BUILD
     constexpr int NF = Q::NFIXED, L = Q::LEGS;
-    if constexpr (NF >= 4 && NF % 2 == 0) {
+    if constexpr (NF >= 4 && NF % 2 == 0 && Q::NS == 9) {
         const int K = q.K;
         const int ntiles = ((K * L + 63) >> 6) + 2 * ((2 * (K - 1) + 63) >> 6);
         if (K == NF && ntiles <= wave_count()) {
@@ -987,13 +1264,13 @@ DEKF_FN void phase_sweeps_rows(Q& q, double alpha, double sigma) {
 // per-item kind decoding (50 k cycles per check on Go1, 3 checks per solve).
 template <class Q>
 DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
-    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
+    constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, SV = 2 * NS + 3 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt, cc = q.cc;
     double *x = q.x, *z = q.z, *y = q.y, *xd = q.xd;
     const double *D = q.D, *E = q.E;
-    wfor(K * 9, [&](int e) {
-        int k = e / 9, j = e - 9 * k;
+    wfor(K * NS, [&](int e) {
+        int k = e / NS, j = e - NS * k;
         xd[e] = D[k * SV + j] * x[k * SV + j];
     });
     double acc[14];
@@ -1023,25 +1300,33 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             acc[13] = dmax(acc[13], fabs(Px));
         }
     };
+    // a 3-block whose P block is a packed symmetric 3x3 in the window record
+    auto block_sym3 = [&](int r0, int sv0, const double* ar, const double* q6) {
+        double p6[6], dx[3], ps[3];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) p6[t] = q6[t];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) dx[a] = D[sv0 + a] * x[sv0 + a];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+            ps[a] = p6[symidx(0, a, 3)] * dx[0] + p6[1 < a ? symidx(1, a, 3) : symidx(a, 1, 3)] * dx[1] + p6[symidx(a, 2, 3)] * dx[2];
+        block(r0, sv0, ar, ps);
+    };
     const int ntm = (nmeas + 63) >> 6, ntp = (2 * K1 + 63) >> 6, ntd = (K1 + 63) >> 6, ntx = (3 * K + 63) >> 6;
-    const double* qsl = q.tmp + 162;
+    const int ntf = FT ? (K1 * L + 63) >> 6 : 0, ntxf = FT ? (NM * K + 63) >> 6 : 0;
+    const double* qsl = q.tmp + TmpMap<NS>::QSL;
     auto wy = [&](int r) { return E[r] * y[r]; };
-    wtiles(ntm + ntp + 2 * ntd + 3 * ntx, [&](int tile, int lane) {
+    wtiles(ntm + ntp + 2 * ntd + 3 * ntx + ntf + ntxf, [&](int tile, int lane) {
         if (tile < ntm) {  // Meas leg blocks
             const int e = tile * 64 + lane;
             if (e >= nmeas) return;
             const int k = e / L, leg = e - k * L;
-            const int r0 = q.ix.rm(k, 3 * leg), sv0 = k * SV + 9 + 3 * leg;
-            const double* q6 = q.rec(k) + Rec::qm(NM) + 6 * leg;
-            double p6[6], dx[3], ps[3], ar[3];
-#pragma unroll
-            for (int t = 0; t < 6; ++t) p6[t] = q6[t];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) { dx[a] = D[sv0 + a] * x[sv0 + a]; ar[a] = E[r0 + a] * xd[9 * k + 3 + a]; }
+            const int r0 = q.ix.rm(k, 3 * leg), sv0 = q.ix.v(k, 3 * leg);
+            double ar[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a)
-                ps[a] = p6[symidx(0, a, 3)] * dx[0] + p6[1 < a ? symidx(1, a, 3) : symidx(a, 1, 3)] * dx[1] + p6[symidx(a, 2, 3)] * dx[2];
-            block(r0, sv0, ar, ps);
+                ar[a] = FT ? E[r0 + a] * (xd[NS * k + 9 + 3 * leg + a] - xd[NS * k + a]) : E[r0 + a] * xd[NS * k + 3 + a];
+            block_sym3(r0, sv0, ar, q.rec(k) + Rec::qm(NM) + 6 * leg);
             return;
         }
         int td = tile - ntm;
@@ -1050,20 +1335,20 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             if (k >= K1) return;
             const bool vel = pl & 1;
             const int o = vel ? 3 : 0;
-            const int r0 = q.ix.rd(k, o), sv0 = k * SV + 9 + NM + o, w0 = k * SV + 9 + NM;
+            const int r0 = q.ix.rd(k, o), sv0 = q.ix.w(k, o), w0 = q.ix.w(k, 0);
             const double* q21 = q.rec(k) + Rec::QD;
             double p21[21], dx[6], ps[3], ar[3];
 #pragma unroll
             for (int t = 0; t < 21; ++t) p21[t] = q21[t];
 #pragma unroll
             for (int t = 0; t < 6; ++t) dx[t] = D[w0 + t] * x[w0 + t];
-            const double* xk = xd + 9 * k;
+            const double* xk = xd + NS * k;
             const double* R = q.R + 9 * k;
             const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
                 const double rb = R[3 * a] * xk[6] + R[3 * a + 1] * xk[7] + R[3 * a + 2] * xk[8];
-                ar[a] = E[r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+                ar[a] = E[r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[NS + o + a]);
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
@@ -1080,55 +1365,86 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             const bool vo = td < ntd;
             const int k = (td - (vo ? 0 : ntd)) * 64 + lane;
             if (k >= K1) return;
-            const double* xk = xd + 9 * k;
+            const double* xk = xd + NS * k;
             double ar[3], ps[3];
             if (!vo) {
-                const int r0 = q.ix.rd(k, 6), sv0 = k * SV + 9 + NM + 6;
+                const int r0 = q.ix.rd(k, 6), sv0 = q.ix.w(k, 6);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    ar[a] = E[r0 + a] * (xk[6 + a] - xk[15 + a]);
+                    ar[a] = E[r0 + a] * (xk[6 + a] - xk[NS + 6 + a]);
                     ps[a] = q.c.Q_bias_dt2[a] * D[sv0 + a] * x[sv0 + a];
                 }
                 block(r0, sv0, ar, ps);
             } else {
-                const int r0 = q.ix.rv(k, 0), sv0 = k * SV + 18 + NM;
-                const double* q6 = q.rec(k) + Rec::QC;
-                double p6[6], dx[3];
+                const int r0 = q.ix.rv(k, 0), sv0 = q.ix.c(k, 0);
 #pragma unroll
-                for (int t = 0; t < 6; ++t) p6[t] = q6[t];
-#pragma unroll
-                for (int a = 0; a < 3; ++a) { dx[a] = D[sv0 + a] * x[sv0 + a]; ar[a] = E[r0 + a] * (xk[a] - xk[9 + a]); }
-#pragma unroll
-                for (int a = 0; a < 3; ++a)
-                    ps[a] = p6[symidx(0, a, 3)] * dx[0] + p6[1 < a ? symidx(1, a, 3) : symidx(a, 1, 3)] * dx[1] + p6[symidx(a, 2, 3)] * dx[2];
-                block(r0, sv0, ar, ps);
+                for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[a] - xk[NS + a]);
+                block_sym3(r0, sv0, ar, q.rec(k) + Rec::QC);
             }
             return;
         }
-        td -= 2 * ntd;  // x columns: position / velocity / bias tiles
-        const int kind = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2);
-        const int e = (td - kind * ntx) * 64 + lane;
-        if (e >= 3 * K) return;
-        const int k = e / 3, a = e - 3 * k, j = 3 * kind + a, i = k * SV + j;
-        const double d = D[i], qv = k == 0 ? qsl[j] : 0.0;
-        double g;
-        if (kind == 0) g = gather_pcol(q, k, a, wy);
-        else if (kind == 1) g = gather_vcol(q, k, a, wy);
-        else g = gather_bcol(q, k, a, wy);
-        double Px = 0.0;
-        if (k == 0) {  // the arrival cost is the only Hessian on an x block
-            for (int t = 0; t < 9; ++t) Px += (j <= t ? q.Mp[9 * j + t] : q.Mp[9 * t + j]) * xd[t];
-            Px *= cc * d;
+        td -= 2 * ntd;
+        if (td < 3 * ntx) {  // x columns: position / velocity / bias tiles
+            const int kind = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2);
+            const int e = (td - kind * ntx) * 64 + lane;
+            if (e >= 3 * K) return;
+            const int k = e / 3, a = e - 3 * k, j = 3 * kind + a, i = k * SV + j;
+            const double d = D[i], qv = k == 0 ? qsl[j] : 0.0;
+            double g;
+            if (kind == 0) g = gather_pcol(q, k, a, wy);
+            else if (kind == 1) g = gather_vcol(q, k, a, wy);
+            else g = gather_bcol(q, k, a, wy);
+            double Px = 0.0;
+            if (k == 0) {  // the arrival cost is the only Hessian on an x block
+                for (int t = 0; t < NS; ++t) Px += (j <= t ? q.Mp[NS * j + t] : q.Mp[NS * t + j]) * xd[t];
+                Px *= cc * d;
+            }
+            const double Aty = d * g, dr = qv + Px + Aty, di = rcp_fast(d);
+            acc[6] = dmax(acc[6], fabs(dr) * di);
+            acc[7] = dmax(acc[7], fabs(qv) * di);
+            acc[8] = dmax(acc[8], fabs(Aty) * di);
+            acc[9] = dmax(acc[9], fabs(Px) * di);
+            acc[10] = dmax(acc[10], fabs(dr));
+            acc[11] = dmax(acc[11], fabs(qv));
+            acc[12] = dmax(acc[12], fabs(Aty));
+            acc[13] = dmax(acc[13], fabs(Px));
+            return;
         }
-        const double Aty = d * g, dr = qv + Px + Aty, di = rcp_fast(d);
-        acc[6] = dmax(acc[6], fabs(dr) * di);
-        acc[7] = dmax(acc[7], fabs(qv) * di);
-        acc[8] = dmax(acc[8], fabs(Aty) * di);
-        acc[9] = dmax(acc[9], fabs(Px) * di);
-        acc[10] = dmax(acc[10], fabs(dr));
-        acc[11] = dmax(acc[11], fabs(qv));
-        acc[12] = dmax(acc[12], fabs(Aty));
-        acc[13] = dmax(acc[13], fabs(Px));
+        td -= 3 * ntx;
+        if constexpr (FT) {
+            if (td < ntf) {  // Dyn rows of the foot-position states
+                const int e = td * 64 + lane;
+                if (e >= K1 * L) return;
+                const int k = e / L, leg = e - k * L;
+                const int r0 = q.ix.rd(k, 9 + 3 * leg), sv0 = q.ix.w(k, 9 + 3 * leg);
+                const double* xk = xd + NS * k + 9 + 3 * leg;
+                double ar[3];
+#pragma unroll
+                for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[a] - xk[NS + a]);
+                block_sym3(r0, sv0, ar, q.rec(k) + Rec::qf(NM) + 6 * leg);
+                return;
+            }
+            td -= ntf;
+            const int e = td * 64 + lane;  // foot-position columns
+            if (e >= NM * K) return;
+            const int k = e / NM, la = e - NM * k, j = 9 + la, i = k * SV + j;
+            const double d = D[i], qv = k == 0 ? qsl[j] : 0.0;
+            const double g = gather_fcol(q, k, la, wy);
+            double Px = 0.0;
+            if (k == 0) {
+                for (int t = 0; t < NS; ++t) Px += (j <= t ? q.Mp[NS * j + t] : q.Mp[NS * t + j]) * xd[t];
+                Px *= cc * d;
+            }
+            const double Aty = d * g, dr = qv + Px + Aty, di = rcp_fast(d);
+            acc[6] = dmax(acc[6], fabs(dr) * di);
+            acc[7] = dmax(acc[7], fabs(qv) * di);
+            acc[8] = dmax(acc[8], fabs(Aty) * di);
+            acc[9] = dmax(acc[9], fabs(Px) * di);
+            acc[10] = dmax(acc[10], fabs(dr));
+            acc[11] = dmax(acc[11], fabs(qv));
+            acc[12] = dmax(acc[12], fabs(Aty));
+            acc[13] = dmax(acc[13], fabs(Px));
+        }
     });
 #pragma unroll
     for (int r = 0; r < 14; ++r) acc[r] = wave_max(acc[r]);

@@ -15,24 +15,36 @@
 namespace dekf {
 
 struct AsmScratch {
-    // LDS doubles needed by assemble_instance for (L): see assemble_scratch_len()
-    DEKF_HD static int len(int L) {
-        int dim = 12 + 3 * L;
-        return 81 /*Minv*/ + 12 * 9 /*Am*/ + 12 * 9 /*AmMinv*/ + dim * dim /*S*/ + dim * dim + dim /*winverse*/ +
-               dim /*u*/ + dim /*Yu*/ + 81 /*tmp9*/ + 16;
+    // LDS doubles needed by assemble_update for (L, leg_odom_type): the generic marginalisation's buffers
+    DEKF_HD static int len(int L, int ft = 0) {
+        const int ns = 9 + (ft ? 3 * L : 0), na = ns + 3, dim = na + 3 * L;
+        return ns * ns /*Minv*/ + 2 * na * ns /*Am, AmMi*/ + dim * dim /*S*/ + 2 * dim /*pivot row, column*/ +
+               dim /*u*/ + dim /*Yu*/ + ns /*M^-1 n*/ + 3 * L * ns /*H M^-1*/ + 16;
     }
 };
 
 // A_dyn,k[r][j] for R (row-major) and dt (DecentralEst.cpp:395-398)
+// (rows / columns >= 9 are the foot-position states of leg_odom_type 1: identity, :395-398)
 DEKF_FN double adyn_entry(const double* R, double dt, int r, int j) {
     if (r == j) return 1.0;
     if (r < 3) {
         if (j == r + 3) return dt;
-        if (j >= 6) return -0.5 * dt * dt * R[3 * r + (j - 6)];
+        if (j >= 6 && j < 9) return -0.5 * dt * dt * R[3 * r + (j - 6)];
         return 0.0;
     }
-    if (r < 6 && j >= 6) return -dt * R[3 * (r - 3) + (j - 6)];
+    if (r < 6 && j >= 6 && j < 9) return -dt * R[3 * (r - 3) + (j - 6)];
     return 0.0;
+}
+
+// A_meas row q = (leg, a) applied to a state-sized vector: leg_odom_type 0 picks the velocity ([0 I 0],
+// DecentralEst.cpp:95-98), type 1 the foot position relative to the base ([-I 0 0 .. I ..], :106-110)
+DEKF_FN double ameas_dot(int ft, const double* v, int q) {
+    const int a = q % 3;
+    return ft ? v[9 + q] - v[a] : v[3 + a];
+}
+DEKF_FN double ameas_dot_strided(int ft, const double* v, int stride, int q) {  // v[t * stride]
+    const int a = q % 3;
+    return ft ? v[(9 + q) * stride] - v[a * stride] : v[(3 + a) * stride];
 }
 
 // gains that depend only on R_sb of a step: Q_dyn's 6x6 block and Q_cam (one lane)
@@ -123,6 +135,42 @@ DEKF_FN void leg_terms_nj(const DevCfg& c, const double* R, const double* gyro, 
     const double cs[6] = {Cw[0], 0.5 * (Cw[1] + Cw[3]), 0.5 * (Cw[2] + Cw[6]), Cw[4], 0.5 * (Cw[5] + Cw[7]), Cw[8]};
     if (as_gain) { inv3_sym(cs, w6); return; }
     w6[0] = Cw[0]; w6[1] = Cw[1]; w6[2] = Cw[2]; w6[3] = Cw[4]; w6[4] = Cw[5]; w6[5] = Cw[8];
+}
+// leg_odom_type 1 (DecentralEst.cpp:310-325, 550-563, 753, 803): b_meas = R p_foot; measurement weight
+// R (J C_enc_pos J')^-1 R' (as_gain) or the covariance R J C_enc_pos J' R'; process weight of the foot-position state
+// 1/dt^2 R Q R' with Q = Q_foot_slide in contact, Q_foot_swing otherwise (:432-451), or its covariance dt^2 R C R'
+DEKF_FN void leg_terms_position(const DevCfg& c, const double* R, const double* p_foot, const double* J, double contact,
+                                bool as_gain, double* bm3, double* w6, double* f6) {
+    const int nj = c.nj;
+    mv3(R, p_foot, bm3);
+    double JCJ[9];
+    for (int i = 0; i < 3; ++i)
+        for (int k = 0; k < 3; ++k) {
+            double s = 0;
+            for (int j = 0; j < nj; ++j) s += J[i * nj + j] * c.C_enc_pos[j] * J[k * nj + j];
+            JCJ[3 * i + k] = s;
+        }
+    double Mi[6];
+    const double cs[6] = {JCJ[0], 0.5 * (JCJ[1] + JCJ[3]), 0.5 * (JCJ[2] + JCJ[6]), JCJ[4], 0.5 * (JCJ[5] + JCJ[7]), JCJ[8]};
+    if (as_gain) inv3_sym(cs, Mi);
+    else for (int t = 0; t < 6; ++t) Mi[t] = cs[t];
+    // R Mi R' and R diag(d) R', packed upper triangles
+    const double* d = contact != 0.0 ? (as_gain ? c.Q_slide : c.C_slide) : (as_gain ? c.Q_swing : c.C_swing);
+    const double sc = as_gain ? 1.0 / (c.dt * c.dt) : c.dt * c.dt;
+    int pk = 0;
+    for (int i = 0; i < 3; ++i)
+        for (int k = i; k < 3; ++k) {
+            double sm = 0, sf = 0;
+            for (int t = 0; t < 3; ++t) {
+                double rm = 0;
+                for (int u = 0; u < 3; ++u) rm += R[3 * i + u] * symget(Mi, u, t, 3);
+                sm += rm * R[3 * k + t];
+                sf += R[3 * i + t] * d[t] * R[3 * k + t];
+            }
+            w6[pk] = sm;
+            f6[pk] = sc * sf;
+            ++pk;
+        }
 }
 DEKF_FN void leg_terms(const DevCfg& c, const double* R, const double* gyro, const double* p_foot, const double* J,
                        const double* qdot, double contact, bool as_gain, double* bm3, double* w6) {
@@ -237,8 +285,15 @@ DEKF_FN void write_measurement_record(const DevCfg& c, const DevState& s, int b,
     wfor(L + 1, [&](int i) {
         if (i < L) {
             double bm[3], w6[6];
-            leg_terms(c, R, gyro, s.p_foot + ((size_t)b * L + i) * 3, s.J + ((size_t)b * L + i) * 3 * nj,
-                      s.qdot + ((size_t)b * L + i) * nj, s.contact[(size_t)b * L + i], as_gain, bm, w6);
+            if (c.ft) {
+                double f6[6];
+                leg_terms_position(c, R, s.p_foot + ((size_t)b * L + i) * 3, s.J + ((size_t)b * L + i) * 3 * nj,
+                                   s.contact[(size_t)b * L + i], as_gain, bm, w6, f6);
+                for (int a = 0; a < 6; ++a) r[Rec::qf(c.nm) + 6 * i + a] = f6[a];
+            } else {
+                leg_terms(c, R, gyro, s.p_foot + ((size_t)b * L + i) * 3, s.J + ((size_t)b * L + i) * 3 * nj,
+                          s.qdot + ((size_t)b * L + i) * nj, s.contact[(size_t)b * L + i], as_gain, bm, w6);
+            }
             for (int a = 0; a < 3; ++a) r[Rec::BM + 3 * i + a] = bm[a];
             for (int a = 0; a < 6; ++a) r[Rec::qm(c.nm) + 6 * i + a] = w6[a];
         } else {
@@ -447,67 +502,202 @@ DEKF_FN bool marginalize_regs(const DevCfg& c, const DevState& s, int b, const d
 }
 #endif  // DEKF_DEVICE_BUILD
 
+// marginalizeQP in INFORMATION form, used when the foot positions are states (leg_odom_type 1).
+// The reference (MheSrb.cpp:527-651) builds the saddle matrix S = -([A;H] M^-1 [A;H]' + blkdiag(Q^-1, R^-1)) out of
+// COVARIANCES and inverts it.  With foot-position states that is numerically fragile: a swinging foot has process
+// covariance dt^2 * 1e14 and, after a few swing steps, an arrival information of 1e-10, so M^-1 and Q^-1 carry entries of
+// 1e9..1e10 next to measurement covariances of 1e-4 — the information of the measurement survives the additions with
+// three or four digits.  (Measured on the oracle, which follows the reference's formulas: its states drift 1e-5 away from
+// the never-marginalised problem once a foot has been through a swing phase, tests/test_oracle_mhe.py.)  Eliminating
+// x_k from   1/2 x'Mx + n'x + 1/2 |A x - x+ - b|_Q^2 + 1/2 |H x - y|_R^2 [+ 1/2 |E x - E x+ - b_c|_Qc^2]
+// directly gives the same arrival cost (matrix inversion lemma) from gains only:
+//     Lambda = M + A'QA + H'RH [+ E'Qc E],   G = QA [+ E'Qc E],   r0 = -n + A'Qb + H'Ry [+ E'Qc b_c]
+//     M+ = Q [+ E'Qc E] - G Lambda^-1 G',      n+ = Qb [+ E'Qc b_c] - G Lambda^-1 r0
+// sm: QA/G ns^2 | Lambda ns^2 | T1 ns^2 | Qb ns | r0 ns | scratch 2 ns
+DEKF_FN bool marginalize_info(const DevCfg& c, const DevState& s, int b, const double* r, double* sm) {
+    const int nm = c.nm, L = c.L, ns = c.ns, ft = c.ft, n2 = ns * ns;
+    double* Mp = s.Mp + (size_t)n2 * b;
+    double* np = s.np_ + (size_t)ns * b;
+    const bool vo = r[Rec::VOF] != 0.0;
+    double* QA = sm;
+    double* Lam = QA + n2;
+    double* T1 = Lam + n2;
+    double* Qb = T1 + n2;
+    double* r0 = Qb + ns;
+    double* wsc = r0 + ns;
+    const double* R = r + Rec::R;
+    const double dt = c.dt;
+    // Q(i, t): process gain, block diagonal [6x6 | diag 3 | 3x3 per foot]
+    auto qdyn = [&](int i, int t) -> double {
+        if (i < 6) return t < 6 ? symget(r + Rec::QD, i, t, 6) : 0.0;
+        if (i < 9) return t == i ? c.Q_bias_dt2[i - 6] : 0.0;
+        const int leg = (i - 9) / 3;
+        return (t >= 9 + 3 * leg && t < 12 + 3 * leg) ? symget(r + Rec::qf(nm) + 6 * leg, i - 9 - 3 * leg, t - 9 - 3 * leg, 3) : 0.0;
+    };
+    auto bdyn = [&](int i) -> double { return i < 3 ? -0.5 * dt * dt * r[Rec::AS + i] : (i < 6 ? -dt * r[Rec::AS + i - 3] : 0.0); };
+    // A_meas' W A_meas, entry (i, j), W = blkdiag of the packed 3x3 measurement gains
+    auto hrh = [&](int i, int j) -> double {
+        double v = 0.0;
+        for (int leg = 0; leg < L; ++leg) {
+            // column i of A_meas restricted to this leg's rows: coefficient and local row index
+            double ci, cj;
+            int ai, aj;
+            if (ft) {
+                ci = i < 3 ? -1.0 : ((i >= 9 + 3 * leg && i < 12 + 3 * leg) ? 1.0 : 0.0); ai = i < 3 ? i : i - 9 - 3 * leg;
+                cj = j < 3 ? -1.0 : ((j >= 9 + 3 * leg && j < 12 + 3 * leg) ? 1.0 : 0.0); aj = j < 3 ? j : j - 9 - 3 * leg;
+            } else {
+                ci = (i >= 3 && i < 6) ? 1.0 : 0.0; ai = i - 3;
+                cj = (j >= 3 && j < 6) ? 1.0 : 0.0; aj = j - 3;
+            }
+            if (ci != 0.0 && cj != 0.0) v += ci * cj * symget(r + Rec::qm(nm) + 6 * leg, ai, aj, 3);
+        }
+        return v;
+    };
+    wfor(n2 + ns, [&](int e) {
+        if (e < n2) {
+            const int i = e / ns, j = e - ns * i;
+            double acc = 0.0;
+            for (int t = 0; t < ns; ++t) {
+                const double qv = qdyn(i, t);
+                if (qv != 0.0) acc += qv * adyn_entry(R, dt, t, j);
+            }
+            QA[e] = acc;
+        } else {
+            const int i = e - n2;
+            double acc = 0.0;
+            for (int t = 0; t < ns; ++t) acc += qdyn(i, t) * bdyn(t);
+            Qb[i] = acc;
+        }
+    });
+    wfor(n2 + ns, [&](int e) {
+        if (e < n2) {
+            const int i = e / ns, j = e - ns * i;
+            double acc = Mp[e] + hrh(i, j);
+            for (int t = 0; t < ns; ++t) {
+                const double at = adyn_entry(R, dt, t, i);
+                if (at != 0.0) acc += at * QA[ns * t + j];
+            }
+            if (vo && i < 3 && j < 3) acc += symget(r + Rec::QC, i, j, 3);
+            Lam[e] = acc;
+        } else {
+            const int i = e - n2;
+            double acc = -np[i];
+            for (int t = 0; t < ns; ++t) acc += adyn_entry(R, dt, t, i) * Qb[t];
+            for (int q = 0; q < nm; ++q) {  // (H' R y)_i
+                const int leg = q / 3, a = q - 3 * leg;
+                const double hi = ft ? (i < 3 ? (i == a ? -1.0 : 0.0) : (i == 9 + q ? 1.0 : 0.0)) : (i == 3 + a ? 1.0 : 0.0);
+                if (hi != 0.0) {
+                    double ry = 0.0;
+                    for (int d = 0; d < 3; ++d) ry += symget(r + Rec::qm(nm) + 6 * leg, a, d, 3) * r[Rec::BM + 3 * leg + d];
+                    acc += hi * ry;
+                }
+            }
+            if (vo && i < 3)
+                for (int d = 0; d < 3; ++d) acc += symget(r + Rec::QC, i, d, 3) * r[Rec::VOB + d];
+            r0[i] = acc;
+        }
+    });
+    if (vo) {  // G = QA + E'Qc E, and the same term on the right-hand side Qb
+        wfor(12, [&](int e) {
+            if (e < 9) QA[ns * (e / 3) + e % 3] += symget(r + Rec::QC, e / 3, e % 3, 3);
+            else {
+                const int i = e - 9;
+                double acc = 0.0;
+                for (int d = 0; d < 3; ++d) acc += symget(r + Rec::QC, i, d, 3) * r[Rec::VOB + d];
+                Qb[i] += acc;
+            }
+        });
+    }
+    const bool ok = winverse_definite(Lam, ns, wsc);
+    wmatmul<false, false>(T1, ns, QA, ns, Lam, ns, ns, ns, ns);  // G Lambda^-1
+    wfor(n2 + ns, [&](int e) {
+        if (e < n2) {
+            const int i = e / ns, j = e - ns * i;
+            double acc = qdyn(i, j);
+            if (vo && i < 3 && j < 3) acc += symget(r + Rec::QC, i, j, 3);
+            double sub = 0.0;
+            for (int t = 0; t < ns; ++t) sub += T1[ns * i + t] * QA[ns * j + t];
+            Mp[e] = acc - sub;
+        } else {
+            const int i = e - n2;
+            double sub = 0.0;
+            for (int t = 0; t < ns; ++t) sub += T1[ns * i + t] * r0[t];
+            np[i] = Qb[i] - sub;
+        }
+    });
+    return ok;
+}
+
 // marginalizeQP(step): fold window step `step` into (Mp, np)   (MheSrb.cpp:475-713)
 DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int step, double* sm) {
     const double* r = s.rec + ((size_t)b * c.wcap + (step % c.wcap)) * c.rec;
-    double* Mp = s.Mp + 81 * (size_t)b;
-    double* np = s.np_ + 9 * (size_t)b;
-    const int nm = c.nm, L = c.L;
+    const int nm = c.nm, L = c.L, ns = c.ns, ft = c.ft;
+    double* Mp = s.Mp + (size_t)ns * ns * b;
+    double* np = s.np_ + (size_t)ns * b;
     const bool vo = r[Rec::VOF] != 0.0;
 #if DEKF_DEVICE_BUILD
-    switch (L) {  // wave-uniform
-        case 1: return vo ? marginalize_regs<1, true>(c, s, b, r, sm) : marginalize_regs<1, false>(c, s, b, r, sm);
-        case 2: return vo ? marginalize_regs<2, true>(c, s, b, r, sm) : marginalize_regs<2, false>(c, s, b, r, sm);
-        case 3: return vo ? marginalize_regs<3, true>(c, s, b, r, sm) : marginalize_regs<3, false>(c, s, b, r, sm);
-        case 4: return vo ? marginalize_regs<4, true>(c, s, b, r, sm) : marginalize_regs<4, false>(c, s, b, r, sm);
-        default: break;
+    if (!ft) {
+        switch (L) {  // wave-uniform
+            case 1: return vo ? marginalize_regs<1, true>(c, s, b, r, sm) : marginalize_regs<1, false>(c, s, b, r, sm);
+            case 2: return vo ? marginalize_regs<2, true>(c, s, b, r, sm) : marginalize_regs<2, false>(c, s, b, r, sm);
+            case 3: return vo ? marginalize_regs<3, true>(c, s, b, r, sm) : marginalize_regs<3, false>(c, s, b, r, sm);
+            case 4: return vo ? marginalize_regs<4, true>(c, s, b, r, sm) : marginalize_regs<4, false>(c, s, b, r, sm);
+            default: break;
+        }
     }
 #endif
-    const int na = vo ? 12 : 9;
+    if (ft) return marginalize_info(c, s, b, r, sm);
+    // generic form (any state dimension): rows [Dyn (ns) | VO (3, when flagged) | Meas (nm)]
+    const int na = vo ? ns + 3 : ns;
     const int dim = na + nm;
-    double* Minv = sm;                 // 81
-    double* Am = Minv + 81;            // na x 9
-    double* AmMi = Am + 108;           // na x 9
-    double* S = AmMi + 108;            // dim x dim
-    double* wsc = S + dim * dim;       // dim*dim + dim
-    double* u = wsc + dim * dim + dim; // dim
-    double* Yu = u + dim;              // dim
-    double* Min = Yu + dim;            // 9: M^-1 n
+    double* Minv = sm;                      // ns x ns
+    double* Am = Minv + ns * ns;            // na x ns   ([A_dyn; A_cam])
+    double* AmMi = Am + (ns + 3) * ns;      // na x ns
+    double* S = AmMi + (ns + 3) * ns;       // dim x dim
+    double* wsc = S + (ns + 3 + nm) * (ns + 3 + nm);  // 2 dim
+    double* u = wsc + 2 * (ns + 3 + nm);    // dim
+    double* Yu = u + (ns + 3 + nm);         // dim
+    double* Min = Yu + (ns + 3 + nm);       // ns: M^-1 n
+    double* HMi = Min + ns;                 // nm x ns: A_meas M^-1
     const double* R = r + Rec::R;
     const double dt = c.dt;
-    wfor(81 + na * 9, [&](int e) {
-        if (e < 81) Minv[e] = Mp[e];
+    wfor(ns * ns + na * ns, [&](int e) {
+        if (e < ns * ns) Minv[e] = Mp[e];
         else {
-            int q = e - 81, i = q / 9, j = q - 9 * i;
-            Am[q] = i < 9 ? adyn_entry(R, dt, i, j) : ((i - 9) == j ? 1.0 : 0.0);
+            int q = e - ns * ns, i = q / ns, j = q - ns * i;
+            Am[q] = i < ns ? adyn_entry(R, dt, i, j) : ((i - ns) == j ? 1.0 : 0.0);
         }
     });
-    bool ok = winverse_definite(Minv, 9, wsc);
-    wmatmul<false, false>(AmMi, 9, Am, 9, Minv, 9, na, 9, 9);
-    wfor(dim * dim + 9, [&](int e) {
-        if (e >= dim * dim) {
-            int i = e - dim * dim;
+    bool ok = winverse_definite(Minv, ns, wsc);
+    wmatmul<false, false>(AmMi, ns, Am, ns, Minv, ns, na, ns, ns);
+    wfor(nm * ns + ns, [&](int e) {
+        if (e >= nm * ns) {
+            int i = e - nm * ns;
             double sacc = 0;
-            for (int t = 0; t < 9; ++t) sacc += Minv[9 * i + t] * np[t];
+            for (int t = 0; t < ns; ++t) sacc += Minv[ns * i + t] * np[t];
             Min[i] = sacc;
             return;
         }
+        int q = e / ns, t = e - q * ns;
+        HMi[e] = ameas_dot_strided(ft, Minv + t, ns, q);   // (A_meas M^-1)[q][t], M^-1 symmetric up to rounding
+    });
+    wfor(dim * dim, [&](int e) {
         int i = e / dim, j = e - i * dim;
         double v;
         if (i < na && j < na) {
             double sacc = 0;
-            for (int t = 0; t < 9; ++t) sacc += AmMi[9 * i + t] * Am[9 * j + t];
+            for (int t = 0; t < ns; ++t) sacc += AmMi[ns * i + t] * Am[ns * j + t];
             v = -sacc;
         } else if (i >= na && j >= na) {
-            v = -Minv[9 * (3 + (i - na) % 3) + 3 + (j - na) % 3];
+            v = -ameas_dot(ft, HMi + (i - na) * ns, j - na);
         } else {
             int a = i < na ? i : j, q = i < na ? j : i;
-            v = -AmMi[9 * a + 3 + (q - na) % 3];
+            v = -ameas_dot(ft, AmMi + ns * a, q - na);
         }
         S[e] = v;
     });
     // minus the inverse gains on the diagonal blocks: one lane per block
-    wfor(L + 2, [&](int blk) {
+    wfor(2 * L + 2, [&](int blk) {
         if (blk < L) {
             double qi[6];
             inv3_sym(r + Rec::qm(nm) + 6 * blk, qi);
@@ -525,11 +715,19 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
 #pragma unroll
                 for (int j = 0; j < 6; ++j) S[i * dim + j] -= Q[6 * i + j];
             for (int i = 0; i < 3; ++i) S[(6 + i) * dim + 6 + i] -= 1.0 / c.Q_bias_dt2[i];
-        } else if (vo) {
+        } else if (blk == L + 1) {
+            if (vo) {
+                double qi[6];
+                inv3_sym(r + Rec::QC, qi);
+                for (int a = 0; a < 3; ++a)
+                    for (int d = 0; d < 3; ++d) S[(ns + a) * dim + ns + d] -= symget(qi, a, d, 3);
+            }
+        } else if (ft) {  // process gain of a foot-position state
+            const int leg = blk - L - 2;
             double qi[6];
-            inv3_sym(r + Rec::QC, qi);
+            inv3_sym(r + Rec::qf(nm) + 6 * leg, qi);
             for (int a = 0; a < 3; ++a)
-                for (int d = 0; d < 3; ++d) S[(9 + a) * dim + 9 + d] -= symget(qi, a, d, 3);
+                for (int d = 0; d < 3; ++d) S[(9 + 3 * leg + a) * dim + 9 + 3 * leg + d] -= symget(qi, a, d, 3);
         }
     });
     // u = [ b_dyn ; vo bound ] + Am M^-1 n   |   b_meas + H M^-1 n
@@ -537,15 +735,15 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
         double v;
         if (i < na) {
             double sacc = 0;
-            for (int t = 0; t < 9; ++t) sacc += Am[9 * i + t] * Min[t];
+            for (int t = 0; t < ns; ++t) sacc += Am[ns * i + t] * Min[t];
             double rhs;
             if (i < 3) rhs = -0.5 * dt * dt * r[Rec::AS + i];
             else if (i < 6) rhs = -dt * r[Rec::AS + i - 3];
-            else if (i < 9) rhs = 0.0;
-            else rhs = r[Rec::VOB + i - 9];
+            else if (i < ns) rhs = 0.0;
+            else rhs = r[Rec::VOB + i - ns];
             v = rhs + sacc;
         } else {
-            v = r[Rec::BM + i - na] + Min[3 + (i - na) % 3];
+            v = r[Rec::BM + i - na] + ameas_dot(ft, Min, i - na);
         }
         u[i] = v;
     });
@@ -556,21 +754,21 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
         for (int t = 0; t < dim; ++t) sacc += S[i * dim + t] * u[t];
         Yu[i] = sacc;
     });
-    // M+ = -B' S^-1 B, n+ = B' S^-1 u with B = [-I9; -[I3 0] (VO); 0]
-    wfor(90, [&](int e) {
-        if (e < 81) {
-            int i = e / 9, j = e - 9 * i;
+    // M+ = -B' S^-1 B, n+ = B' S^-1 u with B = [-I; -[I3 0] (VO); 0]
+    wfor(ns * ns + ns, [&](int e) {
+        if (e < ns * ns) {
+            int i = e / ns, j = e - ns * i;
             double v = S[i * dim + j];
             if (vo) {
-                if (i < 3) v += S[(9 + i) * dim + j];
-                if (j < 3) v += S[i * dim + 9 + j];
-                if (i < 3 && j < 3) v += S[(9 + i) * dim + 9 + j];
+                if (i < 3) v += S[(ns + i) * dim + j];
+                if (j < 3) v += S[i * dim + ns + j];
+                if (i < 3 && j < 3) v += S[(ns + i) * dim + ns + j];
             }
             Mp[e] = -v;
         } else {
-            int i = e - 81;
+            int i = e - ns * ns;
             double v = Yu[i];
-            if (vo && i < 3) v += Yu[9 + i];
+            if (vo && i < 3) v += Yu[ns + i];
             np[i] = -v;
         }
     });
@@ -616,15 +814,24 @@ DEKF_FN void assemble_update(const DevCfg& c, const DevState& s, int b, int T, i
     if (T >= c.N) marginalize_step(c, s, b, T - c.N, sm);
 }
 
-// InitializeMHE (DecentralEst.cpp:200-351): first sample, prior as arrival cost
+// InitializeMHE (DecentralEst.cpp:200-351): first sample, prior as arrival cost.  With foot-position states the
+// prior mean of every foot is its first measurement R p_foot (:310-325), so n = -Q_prior x_prior is not zero.
 DEKF_FN void assemble_initialize(const DevCfg& c, const DevState& s, int b, double* sm) {
     get_measurement(c, s, b, 0, 0, sm);
     write_measurement_record(c, s, b, 0);
-    double* Mp = s.Mp + 81 * (size_t)b;
-    double* np = s.np_ + 9 * (size_t)b;
-    wfor(90, [&](int e) {
-        if (e < 81) Mp[e] = (e / 9 == e % 9) ? c.Q_prior[e / 9] : 0.0;
-        else np[e - 81] = 0.0;
+    DEKF_SYNC();
+    const int ns = c.ns;
+    double* Mp = s.Mp + (size_t)ns * ns * b;
+    double* np = s.np_ + (size_t)ns * b;
+    const double* r0 = s.rec + ((size_t)b * c.wcap + 0) * c.rec;
+    wfor(ns * ns + ns, [&](int e) {
+        if (e < ns * ns) {
+            const int i = e / ns;
+            Mp[e] = (i == e % ns) ? (i < 9 ? c.Q_prior[i] : c.Q_foot_init[(i - 9) % 3]) : 0.0;
+        } else {
+            const int i = e - ns * ns;
+            np[i] = i < 9 ? 0.0 : -c.Q_foot_init[(i - 9) % 3] * r0[Rec::BM + i - 9];
+        }
     });
 }
 

@@ -67,65 +67,82 @@ namespace dekf {
 DEKF_HD constexpr int mid_block(int K) { return (K - 1) / 2; }
 constexpr int SWS = 25;  // doubles per step of Sw (21 packed 6x6 + 3 bias diagonal + 1 pad: an odd stride keeps one-lane-per-step reads off the same banks)
 constexpr int SOLVE_TMP = 344;  // [162,171) scaled q; at factor time [0,162) and [176,338): two Gauss-Jordan ping-pong pairs
+// Where things sit inside q.tmp.  NS = 9 keeps the round-1 map (above); with foot-position states (NS = 9 + 3 L)
+// the scaled q comes first, then one factorisation scratch per side of the two-sided block LDL' (S, then S^-1:
+// NS^2, plus a pivot row / column for the lane-sequential build).
+template <int NS>
+struct TmpMap {
+    static constexpr int QSL = NS == 9 ? 162 : 0;
+    static constexpr int FAIL = NS == 9 ? 172 : NS;
+    static constexpr int SIDE0 = NS == 9 ? 0 : NS + 8;
+    static constexpr int SIDE1 = NS == 9 ? 176 : SIDE0 + NS * NS + 2 * NS;
+    static constexpr int LEN = NS == 9 ? SOLVE_TMP : SIDE1 + NS * NS + 2 * NS + 8;
+};
+DEKF_HD constexpr int solve_tmp_len(int ns) { return ns == 9 ? SOLVE_TMP : 2 * (ns * ns + 2 * ns) + ns + 16; }
 
 // how many doubles of LDS a solve needs in each placement mode
 struct SolveLayout {
-    int n_pad, m_pad, K;
+    int n_pad, m_pad, K, ns;
     int vec;        // iterates: x z y xt zt at xs xd tmp
-    int resident;   // D E lo hi(VO rows) Sv Sw Sc Sinv(full 9x9) Wk R
-    DEKF_HD void init(int N, int L) {
+    int resident;   // D E lo hi(VO rows) Sv Sw Sc [Sf] Sinv(full NS x NS) Wk R
+    DEKF_HD void init(int N, int L, int ft = 0) {
         int nm = 3 * L;
         K = N;
-        n_pad = N * (9 + nm + 12);
-        m_pad = N * (nm + 12);
-        vec = 2 * n_pad + 4 * m_pad + 18 * N + SOLVE_TMP;
-        resident = n_pad + 2 * m_pad + 3 * N + N * (6 * L + SWS + 6) + N * (81 + 81) + 9 * N;
+        ns = 9 + (ft ? nm : 0);
+        n_pad = N * (2 * ns + nm + 3);
+        m_pad = N * (nm + ns + 3);
+        vec = 2 * n_pad + 4 * m_pad + 2 * ns * N + solve_tmp_len(ns);
+        resident = n_pad + 2 * m_pad + 3 * N + N * (6 * L + SWS + 6 + (ft ? 6 * L : 0)) + N * 2 * ns * ns + 9 * N;
     }
     // LDS-resident factor only if two workgroups still fit in one CU's 160 KiB
     DEKF_HD bool factor_in_lds() const { return (size_t)(vec + resident) * 8 <= 80 * 1024; }
     // the factor-time product P A_dyn can alias the (then dead) xt|zt|at vectors when they are big enough
-    DEKF_HD bool pa_in_lds() const { return factor_in_lds() && (n_pad + 2 * m_pad >= (K - 1) * 81); }
+    DEKF_HD bool pa_in_lds() const { return factor_in_lds() && (n_pad + 2 * m_pad >= (K - 1) * ns * ns); }
     DEKF_HD size_t lds_bytes() const { return (size_t)(factor_in_lds() ? vec + resident : vec) * 8; }
 };
 
 // variable / row indices with the leg count known at compile time: every / and % by the
 // per-step block sizes becomes a multiply-shift instead of a ~40-instruction software divide
-template <int L>
+template <int L, int FT = 0>
 struct IdxT {
-    static constexpr int nm = 3 * L, SV = 21 + 3 * L, SC = 12 + 3 * L;
+    static constexpr int nm = 3 * L, NS = 9 + 3 * L * FT, SV = 2 * NS + 3 + 3 * L, SC = NS + 3 + 3 * L;
     DEKF_FN static int x(int k, int j) { return k * SV + j; }
-    DEKF_FN static int v(int k, int r) { return k * SV + 9 + r; }
-    DEKF_FN static int w(int k, int r) { return k * SV + 9 + nm + r; }
-    DEKF_FN static int c(int k, int a) { return k * SV + 18 + nm + a; }
+    DEKF_FN static int v(int k, int r) { return k * SV + NS + r; }
+    DEKF_FN static int w(int k, int r) { return k * SV + NS + nm + r; }
+    DEKF_FN static int c(int k, int a) { return k * SV + 2 * NS + nm + a; }
     // Rows are stored KIND-MAJOR in LDS: [Meas rows of all steps | Dyn rows of all steps | VO rows of all
     // steps], not step-major as in the reference's QP (k * SC + ...).  A wavefront works on one kind of
     // row with one lane per step, so consecutive lanes are 3 / 9 / nm doubles apart (conflict-free);
     // step-major they were SC = 24 doubles = 48 banks apart, which mod 32 banks leaves two distinct
     // banks for 16 lanes: every ds_read2_b64 of the row phase ran 8-way conflicted.
     int rdb, rvb;  // first Dyn row, first VO row
-    DEKF_FN explicit IdxT(int K) : rdb(K * nm), rvb(K * nm + 9 * (K - 1)) {}
+    DEKF_FN explicit IdxT(int K) : rdb(K * nm), rvb(K * nm + NS * (K - 1)) {}
     DEKF_FN int rm(int k, int r) const { return k * nm + r; }
-    DEKF_FN int rd(int k, int r) const { return rdb + 9 * k + r; }
+    DEKF_FN int rd(int k, int r) const { return rdb + NS * k + r; }
     DEKF_FN int rv(int k, int a) const { return rvb + 3 * k + a; }
 };
 
-template <int L, int NF = 0, bool FLDS = true>
+template <int L, int NF = 0, bool FLDS = true, int FT = 0>
 struct SolveCtx {
     static constexpr int LEGS = L;
     static constexpr int NFIXED = NF;  // != 0: horizon known at compile time (sweeps fully unrolled when K == NF)
     static constexpr bool FACTOR_LDS = FLDS;  // false: W_k streams from the HBM slab (deeper operand prefetch in the sweeps)
+    static constexpr int FOOT = FT;           // leg_odom_type 1: the foot positions are states (NS = 9 + 3 L)
+    static constexpr int NS = 9 + 3 * L * FT, NS2 = NS * NS;
     const DevCfg& c;
     const DevState& s;
     int b, K, kstart, n, m;
-    IdxT<L> ix;
+    IdxT<L, FT> ix;
     // LDS always
     double *x, *z, *y, *xt, *zt, *at, *xs, *xd, *tmp;
     double* cf;  // per row rho E D (aliases xt, which only the factorisation uses otherwise)
     double* gb;  // per step R' (dt^2/2 w_p + dt w_v): the Dyn rows' contribution to the bias columns (tail of xt)
     // LDS or HBM scratch
     double *D, *E, *lo, *hi, *Sv, *Sw, *Sc, *Sinv, *Wk, *R;
+    double* Sf;  // FOOT: inverses of the slack blocks of the foot-position Dyn rows, [K][L][6]
     // factor-time temporaries
     double *Wm, *Wd, *Wc, *PA;
+    double* Wf;  // FOOT: effective row weights of the foot-position Dyn rows
     const double *Mp, *np;
     double cc;   // cost scaling c
     double rho;  // current scalar rho
@@ -156,7 +173,7 @@ struct SolveCtx {
     }
     DEKF_FN void dec_row(int r, int& k, int& kind, int& o) const {
         if (r < ix.rdb) { kind = 0; k = r / ix.nm; o = r - k * ix.nm; }
-        else if (r < ix.rvb) { kind = 1; int t = r - ix.rdb; k = t / 9; o = t - 9 * k; }
+        else if (r < ix.rvb) { kind = 1; int t = r - ix.rdb; k = t / NS; o = t - NS * k; }
         else { kind = 2; int t = r - ix.rvb; k = t / 3; o = t - 3 * k; }
     }
     // slack variable of row (k, kind, o)
@@ -180,18 +197,20 @@ DEKF_FN double limit_scaling(double v) {
 // per step [Qm 6L | Qd 21 | Qc 6], then M (upper triangle, packed 45)
 template <class Q>
 DEKF_FN void stage_p(Q& q) {
-    constexpr int L = Q::LEGS, NM = 3 * L, PS = 6 * L + 27;
+    constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, PS = 6 * L + 27 + 6 * L * FT, MP = NS * (NS + 1) / 2;
     const int K = q.K;
     double* Pst = q.Pst;
-    wfor(K * PS + 45, [&](int e) {
+    wfor(K * PS + MP, [&](int e) {
         if (e < K * PS) {
             int k = e / PS, o = e - k * PS;
             const double* r = q.rec(k);
-            Pst[e] = o < 6 * L ? r[Rec::qm(NM) + o] : (o < 6 * L + 21 ? r[Rec::QD + o - 6 * L] : r[Rec::QC + o - 6 * L - 21]);
+            // [Qm 6L | Qd 21 | Qc 6 | Qf 6L (foot states)]: the last block is contiguous with Qm in the record
+            Pst[e] = o < 6 * L ? r[Rec::qm(NM) + o]
+                               : (o < 6 * L + 21 ? r[Rec::QD + o - 6 * L] : (o < 6 * L + 27 ? r[Rec::QC + o - 6 * L - 21] : r[Rec::qf(NM) + o - 6 * L - 27]));
         } else {
             int p = e - K * PS, i = 0;
-            while (p >= 9 - i) { p -= 9 - i; ++i; }
-            Pst[e] = q.Mp[9 * i + i + p];
+            while (p >= NS - i) { p -= NS - i; ++i; }
+            Pst[e] = q.Mp[NS * i + i + p];
         }
     });
     q.staged = true;
@@ -199,7 +218,7 @@ DEKF_FN void stage_p(Q& q) {
 
 template <class Q>
 DEKF_FN void solve_scale(Q& q) {
-    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM, PS = 6 * L + 27;
+    constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, SV = 2 * NS + 3 + NM, PS = 6 * L + 27 + 6 * L * FT;
     const int n = q.n, m = q.m, K = q.K, K1 = q.K - 1, nmeas = K * L;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
     double *D = q.D, *E = q.E, *Pst = q.Pst, *pc = q.x, *Dn = q.xt, *En = q.zt;
@@ -210,16 +229,18 @@ DEKF_FN void solve_scale(Q& q) {
     q.cc = 1.0;
     const double* Mst = Pst + K * PS;
     // Lane ownership is the row phase's: a lane owns one 3-row block and its 3 slack variables (Meas leg
-    // block, Dyn position or velocity rows as a lane pair, Dyn bias, VO), or one x entry (tiles by column
-    // kind).  One Ruiz pass is two tile phases:
+    // block, Dyn position or velocity rows as a lane pair, Dyn bias, VO, [foot-position Dyn block]), or one x
+    // entry (tiles by column kind).  One Ruiz pass is two tile phases:
     //   equil  new E of the owned rows, new D of the owned variables from the OLD D, E -> En, Dn
     //   adopt  D = Dn, E = En on the owned entries; inf-norms of the owned columns of D P D (read from Dn, so
     //          no lane reads an entry another lane is overwriting) -> pc; their sum for the cost scaling
     // i.e. 3 workgroup barriers per pass (one after equil, two in the sum) where the item-per-lane sweeps
     // with per-item kind decoding needed 6 and about 17 k cycles.
     const int ntm = (nmeas + 63) >> 6, ntp = (2 * K1 + 63) >> 6, ntd = (K1 + 63) >> 6, ntx = (3 * K + 63) >> 6;
-    const int ntiles = ntm + ntp + 2 * ntd + 3 * ntx;
-    // decode a tile/lane into an owned block: kind 0 Meas, 1 Dyn p/v, 2 bias, 3 VO, 4..6 x columns
+    const int ntf = FT ? (K1 * L + 63) >> 6 : 0, ntxf = FT ? (3 * L * K + 63) >> 6 : 0;  // foot Dyn blocks, foot columns
+    const int ntiles = ntm + ntp + 2 * ntd + 3 * ntx + ntf + ntxf;
+    // decode a tile/lane into an owned block: kind 0 Meas, 1 Dyn p/v, 2 bias, 3 VO, 4..6 x columns,
+    // 7 foot-position Dyn block (k, leg = sub), 8 foot-position column (k, sub = 3 leg + a)
     auto decode = [&](int tile, int lane, int& kind, int& k, int& sub) -> bool {
         if (tile < ntm) { int e = tile * 64 + lane; kind = 0; k = e / L; sub = e - k * L; return e < nmeas; }
         int td = tile - ntm;
@@ -227,16 +248,25 @@ DEKF_FN void solve_scale(Q& q) {
         td -= ntp;
         if (td < 2 * ntd) { bool vo = td >= ntd; kind = vo ? 3 : 2; k = (td - (vo ? ntd : 0)) * 64 + lane; sub = 0; return k < K1; }
         td -= 2 * ntd;
-        int ck = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2);
-        int e = (td - ck * ntx) * 64 + lane;
-        kind = 4 + ck; k = e / 3; sub = e - 3 * k;
-        return e < 3 * K;
+        if (td < 3 * ntx) {
+            int ck = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2);
+            int e = (td - ck * ntx) * 64 + lane;
+            kind = 4 + ck; k = e / 3; sub = e - 3 * k;
+            return e < 3 * K;
+        }
+        td -= 3 * ntx;
+        if (td < ntf) { int e = td * 64 + lane; kind = 7; k = e / L; sub = e - k * L; return e < K1 * L; }
+        td -= ntf;
+        int e = td * 64 + lane;
+        kind = 8; k = e / NM; sub = e - k * NM;
+        return e < NM * K;
     };
     auto row_base = [&](int kind, int k, int sub, int& r0, int& sv0) {
-        if (kind == 0) { r0 = ix.rm(k, 3 * sub); sv0 = k * SV + 9 + 3 * sub; }
-        else if (kind == 1) { r0 = ix.rd(k, 3 * sub); sv0 = k * SV + 9 + NM + 3 * sub; }
-        else if (kind == 2) { r0 = ix.rd(k, 6); sv0 = k * SV + 9 + NM + 6; }
-        else { r0 = ix.rv(k, 0); sv0 = k * SV + 18 + NM; }
+        if (kind == 0) { r0 = ix.rm(k, 3 * sub); sv0 = ix.v(k, 3 * sub); }
+        else if (kind == 1) { r0 = ix.rd(k, 3 * sub); sv0 = ix.w(k, 3 * sub); }
+        else if (kind == 2) { r0 = ix.rd(k, 6); sv0 = ix.w(k, 6); }
+        else if (kind == 3) { r0 = ix.rv(k, 0); sv0 = ix.c(k, 0); }
+        else { r0 = ix.rd(k, 9 + 3 * sub); sv0 = ix.w(k, 9 + 3 * sub); }
     };
     // Both lambdas read everything they need BEFORE their first store (a store through one pointer pins
     // every later load behind it: interleaved, a block cost one LDS round trip per row).
@@ -244,16 +274,20 @@ DEKF_FN void solve_scale(Q& q) {
     auto adopt = [&](int tile, int lane) -> double {
         int kind, k, sub;
         if (!decode(tile, lane, kind, k, sub)) return 0.0;
-        if (kind >= 4) {
-            const int j = 3 * (kind - 4) + sub, i = k * SV + j;
+        if ((kind >= 4 && kind <= 6) || kind == 8) {
+            const int j = kind == 8 ? 9 + sub : 3 * (kind - 4) + sub, i = k * SV + j;
             const double dj = Dn[i];
             double v = 0.0;
             if (k == 0) {
-                double mj[9], dt9[9];
+                if constexpr (FT) {
+                    for (int t = 0; t < NS; ++t) v = dmax(v, fabs(dj * symget(Mst, j, t, NS) * Dn[t]));
+                } else {
+                    double mj[9], dt9[9];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) { mj[t] = symget(Mst, j, t, 9); dt9[t] = Dn[t]; }
+                    for (int t = 0; t < 9; ++t) { mj[t] = symget(Mst, j, t, 9); dt9[t] = Dn[t]; }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * mj[t] * dt9[t]));
+                    for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * mj[t] * dt9[t]));
+                }
             }
             D[i] = dj;
             pc[i] = v;
@@ -266,7 +300,7 @@ DEKF_FN void solve_scale(Q& q) {
         for (int a = 0; a < 3; ++a) { en[a] = En[r0 + a]; dn[a] = Dn[sv0 + a]; }
         if (kind == 1) {
             const double* q21 = Pst + k * PS + 6 * L;
-            const double* d = Dn + k * SV + 9 + NM;
+            const double* d = Dn + ix.w(k, 0);
             double d6[6], p[3][6];
 #pragma unroll
             for (int t = 0; t < 6; ++t) d6[t] = d[t];
@@ -289,7 +323,7 @@ DEKF_FN void solve_scale(Q& q) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) v[a] = dn[a] * q.c.Q_bias_dt2[a] * dn[a];
         } else {
-            const double* q6 = Pst + k * PS + (kind == 0 ? 6 * sub : 6 * L + 21);
+            const double* q6 = Pst + k * PS + (kind == 0 ? 6 * sub : (kind == 3 ? 6 * L + 21 : 6 * L + 27 + 6 * sub));
             double p6[6];
 #pragma unroll
             for (int t = 0; t < 6; ++t) p6[t] = q6[t];
@@ -304,8 +338,8 @@ DEKF_FN void solve_scale(Q& q) {
     auto equil = [&](int tile, int lane, double cc) {
         int kind, k, sub;
         if (!decode(tile, lane, kind, k, sub)) return;
-        if (kind >= 4) {  // x column: inf-norm over the rows that touch it
-            const int a = sub, i = k * SV + 3 * (kind - 4) + a;
+        if ((kind >= 4 && kind <= 6) || kind == 8) {  // x column: inf-norm over the rows that touch it
+            const int a = kind == 8 ? sub % 3 : sub, i = k * SV + (kind == 8 ? 9 + sub : 3 * (kind - 4) + a);
             const bool hn = k < K1, hp = k > 0;
             const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
             const double di = D[i], pci = pc[i];
@@ -314,13 +348,19 @@ DEKF_FN void solve_scale(Q& q) {
                 const double n0 = E[ix.rd(kn, a)], n1 = E[ix.rv(kn, a)], p0 = E[ix.rd(kp, a)], p1 = E[ix.rv(kp, a)];
                 if (hn) an = dmax(n0, n1);
                 if (hp) an = dmax(an, dmax(p0, p1));
+                if constexpr (FT) {  // A_meas = [-I 0 0 .. I ..]: every leg's Meas rows touch the position
+#pragma unroll
+                    for (int leg = 0; leg < L; ++leg) an = dmax(an, E[ix.rm(k, 3 * leg + a)]);
+                }
             } else if (kind == 5) {
                 const double n0 = E[ix.rd(kn, 3 + a)], n1 = E[ix.rd(kn, a)], p0 = E[ix.rd(kp, 3 + a)];
+                if constexpr (!FT) {
 #pragma unroll
-                for (int leg = 0; leg < L; ++leg) an = dmax(an, E[ix.rm(k, 3 * leg + a)]);
+                    for (int leg = 0; leg < L; ++leg) an = dmax(an, E[ix.rm(k, 3 * leg + a)]);
+                }
                 if (hn) an = dmax(an, dmax(n0, dt * n1));
                 if (hp) an = dmax(an, p0);
-            } else {
+            } else if (kind == 6) {
                 const double* R = q.R + 9 * kn;
                 double bn = E[ix.rd(kn, 6 + a)];
                 const double p0 = E[ix.rd(kp, 6 + a)];
@@ -330,6 +370,11 @@ DEKF_FN void solve_scale(Q& q) {
                     bn = dmax(bn, dmax(hdt2 * ra * E[ix.rd(kn, r)], dt * ra * E[ix.rd(kn, 3 + r)]));
                 }
                 if (hn) an = bn;
+                if (hp) an = dmax(an, p0);
+            } else {  // foot-position column: its leg's Meas row, the Dyn rows of this and the previous step
+                const double m0 = E[ix.rm(k, sub)], n0 = E[ix.rd(kn, 9 + sub)], p0 = E[ix.rd(kp, 9 + sub)];
+                an = m0;
+                if (hn) an = dmax(an, n0);
                 if (hp) an = dmax(an, p0);
             }
             Dn[i] = di * rsqrt_fast(limit_scaling(dmax(cc * pci, an * di)));
@@ -343,7 +388,7 @@ DEKF_FN void solve_scale(Q& q) {
         for (int a = 0; a < 3; ++a) { e3[a] = E[r0 + a]; d3[a] = D[sv0 + a]; p3[a] = pc[sv0 + a]; }
         if (kind == 0) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], d[3 + a]);
+            for (int a = 0; a < 3; ++a) v[a] = FT ? dmax(d3[a], dmax(d[a], d[9 + 3 * sub + a])) : dmax(d3[a], d[3 + a]);
         } else if (kind == 1) {
             const double* R = q.R + 9 * k;
             double dk[9], dnx[6], Ra[9];
@@ -365,9 +410,12 @@ DEKF_FN void solve_scale(Q& q) {
         } else if (kind == 2) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], dmax(d[6 + a], d[SV + 6 + a]));
-        } else {
+        } else if (kind == 3) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], dmax(d[a], d[SV + a]));
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], dmax(d[9 + 3 * sub + a], d[SV + 9 + 3 * sub + a]));
         }
         double eo[3], dout[3];
 #pragma unroll
@@ -391,11 +439,117 @@ DEKF_FN void solve_scale(Q& q) {
         psum *= cc;
         // ---- cost normalisation: mean column norm of the re-scaled P against |q|_inf
         double qn = 0.0;
-        for (int j = 0; j < 9; ++j) qn = dmax(qn, fabs(cc * D[j] * g[j]));
+        for (int j = 0; j < NS; ++j) qn = dmax(qn, fabs(cc * D[j] * g[j]));
         double ct = 1.0 / limit_scaling(dmax(psum / (double)n, limit_scaling(qn)));
         q.cc = cc * ct;
     }
     DEKF_SYNC();
+}
+
+// Two-sided block LDL' for a state dimension other than 9 (foot-position states: NS = 9 + 3 L): same recurrences and
+// storage as step 3d of solve_factor, one wavefront per side, wave-level fences only.  The NS x NS inverse is the
+// register-resident Gauss-Jordan of the assemble kernel (gj_columns: lane j holds column j, the pivot column comes
+// over by v_readlane) — a 21-wide column no longer fits the 16-lane DPP row the 9 x 9 form broadcasts in.
+template <class Q>
+DEKF_FN bool factor_blocks_generic(Q& q) {
+    constexpr int NS = Q::NS, NS2 = Q::NS2;
+    using TM = TmpMap<NS>;
+    const int K = q.K, mid = mid_block(K);
+    double* fail = q.tmp + TM::FAIL;
+    if (DEKF_LANE() == 0) *fail = 0.0;
+    DEKF_SYNC();
+    // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]
+    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, double* ts) -> bool {
+#if DEKF_DEVICE_BUILD
+        const int lane = DEKF_LANE() & 63, l0 = lane, st = WAVE;
+#else
+        const int l0 = 0, st = 1;
+#endif
+        for (int p = l0; p < NS2; p += st) {
+            const int i = p / NS, j = p - NS * i;
+            double acc = q.Sinv[k * NS2 + p];
+            if (use_top) {
+                const double* Wp = q.Wk + (k - 1) * NS2 + NS * i;
+                const double* Cp = q.PA + (k - 1) * NS2 + NS * j;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                for (int t = 0; t + 2 < NS; t += 3) { s0 += Wp[t] * Cp[t]; s1 += Wp[t + 1] * Cp[t + 1]; s2 += Wp[t + 2] * Cp[t + 2]; }
+                acc -= s0 + (s1 + s2);
+            }
+            if (use_bot) {
+                const double* Wh = q.Wk + k * NS2 + NS * i;
+                const double* Ck = q.PA + k * NS2 + j;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                for (int t = 0; t + 2 < NS; t += 3) { s0 += Wh[t] * Ck[NS * t]; s1 += Wh[t + 1] * Ck[NS * (t + 1)]; s2 += Wh[t + 2] * Ck[NS * (t + 2)]; }
+                acc -= s0 + (s1 + s2);
+            }
+            ts[p] = acc;
+        }
+        wave_sync();
+        bool good;
+#if DEKF_DEVICE_BUILD
+        {
+            const int j = lane < NS ? lane : NS - 1;
+            double a[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) a[i] = ts[NS * i + j];
+            good = gj_columns<NS>(a, lane);
+            wave_sync();  // every lane has read its column of S
+            if (lane < NS) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    ts[NS * i + lane] = a[i];
+                    q.Sinv[k * NS2 + NS * i + lane] = a[i];
+                }
+            }
+        }
+#else
+        good = winverse_definite(ts, NS, ts + NS2);
+        for (int p = 0; p < NS2; ++p) q.Sinv[k * NS2 + p] = ts[p];
+#endif
+        wave_sync();
+        if (wmode != 0) {
+            const int kw = wmode == 1 ? k : k - 1;
+            const double* Ck = q.PA + kw * NS2;
+            for (int p = l0; p < NS2; p += st) {
+                const int i = p / NS, jj = p - NS * i;
+                const double* cr = wmode == 1 ? Ck + NS * i : Ck + i;  // row i of C, or column i (C')
+                const int cs = wmode == 1 ? 1 : NS;
+                const double* tc = ts + jj;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                for (int t = 0; t + 2 < NS; t += 3) {
+                    s0 += cr[t * cs] * tc[NS * t];
+                    s1 += cr[(t + 1) * cs] * tc[NS * (t + 1)];
+                    s2 += cr[(t + 2) * cs] * tc[NS * (t + 2)];
+                }
+                q.Wk[kw * NS2 + p] = s0 + (s1 + s2);
+            }
+        }
+        wave_sync();
+        return good;
+    };
+    static_assert(NS % 3 == 0, "state dimension is a multiple of 3");
+    two_waves(
+        [&] {
+            bool g = true;
+            for (int k = 0; k < mid; ++k) g = factor_block(k, k > 0, false, 1, q.tmp + TM::SIDE0) && g;
+            if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
+        },
+        [&] {
+            bool g = true;
+            for (int k = K - 1; k > mid; --k) g = factor_block(k, false, k < K - 1, 2, q.tmp + TM::SIDE1) && g;
+            if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
+        });
+    DEKF_SYNC();
+    two_waves(
+        [&] {
+            bool g = factor_block(mid, mid > 0, mid < K - 1, 0, q.tmp + TM::SIDE0);
+            if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
+        },
+        [&] {});
+    DEKF_SYNC();
+    const bool ok = *fail == 0.0;
+    DEKF_SYNC();
+    return ok;
 }
 
 // numeric factorisation for the current rho: slack-block inverses, effective row weights,
@@ -403,35 +557,37 @@ DEKF_FN void solve_scale(Q& q) {
 template <class Q>
 DEKF_FN bool solve_factor(Q& q) {
     const DevCfg& c = q.c;
-    constexpr int L = Q::LEGS;
+    constexpr int L = Q::LEGS, FT = Q::FOOT, NS = Q::NS, NS2 = Q::NS2;
     const int K = q.K;
     const auto& ix = q.ix;
     const double sigma = c.sigma, cc = q.cc;
     // 3a. slack blocks: one lane per block, P blocks from the staged copy (Sinv | Wk are dead here:
     //     the previous factor is being replaced)
-    constexpr int PS = 6 * L + 27;
+    constexpr int PS = 6 * L + 27 + 6 * L * FT, NB = L + 2 + L * FT;  // blocks per step: Meas legs, Dyn p+v+bias, VO, [foot Dyn]
     if (!q.staged) stage_p(q);
     q.staged = false;  // 3c overwrites the staging area
-    wfor(K * (L + 2), [&](int e) {
-        int k = e / (L + 2), blk = e - k * (L + 2);
-        const double* pk = q.Pst + k * PS;  // [Qm 6L | Qd 21 | Qc 6]
+    // a 3x3 slack block with a packed symmetric P block q6: rows r0.., slack variables sv0.. -> inverse Si, row weights Wt
+    auto block3 = [&](const double* q6, int r0, int sv0, double* Si_out, double* W_out) {
+        double gv[3], rr[3], S6[6], Si[6];
+        for (int a = 0; a < 3; ++a) {
+            rr[a] = q.rho_at(r0 + a);
+            gv[a] = rr[a] * q.E[r0 + a] * q.D[sv0 + a];
+        }
+        for (int a = 0; a < 3; ++a)
+            for (int d = a; d < 3; ++d)
+                S6[symidx(a, d, 3)] = cc * q.D[sv0 + a] * q6[symidx(a, d, 3)] * q.D[sv0 + d];
+        for (int a = 0; a < 3; ++a) S6[symidx(a, a, 3)] += sigma + gv[a] * q.E[r0 + a] * q.D[sv0 + a];
+        inv3_sym(S6, Si);
+        for (int t = 0; t < 6; ++t) Si_out[t] = Si[t];
+        for (int a = 0; a < 3; ++a)
+            for (int d = a; d < 3; ++d)
+                W_out[symidx(a, d, 3)] = (a == d ? rr[a] : 0.0) - gv[a] * Si[symidx(a, d, 3)] * gv[d];
+    };
+    wfor(K * NB, [&](int e) {
+        int k = e / NB, blk = e - k * NB;
+        const double* pk = q.Pst + k * PS;  // [Qm 6L | Qd 21 | Qc 6 | Qf 6L]
         if (blk < L) {
-            const double* q6 = pk + 6 * blk;
-            double gv[3], rr[3], S6[6], Si[6];
-            for (int a = 0; a < 3; ++a) {
-                int row = ix.rm(k, 3 * blk + a);
-                rr[a] = q.rho_at(row);
-                gv[a] = rr[a] * q.E[row] * q.D[ix.v(k, 3 * blk + a)];
-            }
-            for (int a = 0; a < 3; ++a)
-                for (int d = a; d < 3; ++d)
-                    S6[symidx(a, d, 3)] = cc * q.D[ix.v(k, 3 * blk + a)] * q6[symidx(a, d, 3)] * q.D[ix.v(k, 3 * blk + d)];
-            for (int a = 0; a < 3; ++a) S6[symidx(a, a, 3)] += sigma + gv[a] * q.E[ix.rm(k, 3 * blk + a)] * q.D[ix.v(k, 3 * blk + a)];
-            inv3_sym(S6, Si);
-            for (int t = 0; t < 6; ++t) q.Sv[(k * L + blk) * 6 + t] = Si[t];
-            for (int a = 0; a < 3; ++a)
-                for (int d = a; d < 3; ++d)
-                    q.Wm[(k * L + blk) * 6 + symidx(a, d, 3)] = (a == d ? rr[a] : 0.0) - gv[a] * Si[symidx(a, d, 3)] * gv[d];
+            block3(pk + 6 * blk, ix.rm(k, 3 * blk), ix.v(k, 3 * blk), q.Sv + (k * L + blk) * 6, q.Wm + (k * L + blk) * 6);
         } else if (k < K - 1 && blk == L) {
             const double* q21 = pk + 6 * L;
             double S[36], gv[9], rr[9];
@@ -466,22 +622,10 @@ DEKF_FN bool solve_factor(Q& q) {
                 wd[21 + a - 6] = rr[a] - gv[a] * gv[a] / sdiag;
             }
         } else if (k < K - 1 && blk == L + 1) {
-            const double* q6 = pk + 6 * L + 21;
-            double gv[3], rr[3], S6[6], Si[6];
-            for (int a = 0; a < 3; ++a) {
-                int row = ix.rv(k, a);
-                rr[a] = q.rho_at(row);
-                gv[a] = rr[a] * q.E[row] * q.D[ix.c(k, a)];
-            }
-            for (int a = 0; a < 3; ++a)
-                for (int d = a; d < 3; ++d)
-                    S6[symidx(a, d, 3)] = cc * q.D[ix.c(k, a)] * q6[symidx(a, d, 3)] * q.D[ix.c(k, d)];
-            for (int a = 0; a < 3; ++a) S6[symidx(a, a, 3)] += sigma + gv[a] * q.E[ix.rv(k, a)] * q.D[ix.c(k, a)];
-            inv3_sym(S6, Si);
-            for (int t = 0; t < 6; ++t) q.Sc[k * 6 + t] = Si[t];
-            for (int a = 0; a < 3; ++a)
-                for (int d = a; d < 3; ++d)
-                    q.Wc[k * 6 + symidx(a, d, 3)] = (a == d ? rr[a] : 0.0) - gv[a] * Si[symidx(a, d, 3)] * gv[d];
+            block3(pk + 6 * L + 21, ix.rv(k, 0), ix.c(k, 0), q.Sc + k * 6, q.Wc + k * 6);
+        } else if (FT && k < K - 1 && blk >= L + 2) {
+            const int leg = blk - L - 2;
+            block3(pk + 6 * L + 27 + 6 * leg, ix.rd(k, 9 + 3 * leg), ix.w(k, 9 + 3 * leg), q.Sf + (k * L + leg) * 6, q.Wf + (k * L + leg) * 6);
         }
     });
     DEKF_PROF_MARK(q, 6);
@@ -492,8 +636,51 @@ DEKF_FN bool solve_factor(Q& q) {
     //     over 1539 + 2439 + 1539 items with per-item index decoding: 57 k cycles per factorisation.)
     {
         const double dt = c.dt, hdt2 = 0.5 * dt * dt;
-        const int K1 = K - 1, ntx = (3 * K + 63) >> 6;
-        wtiles(3 * ntx, [&](int tile, int lane) {
+        const int K1 = K - 1, ntx = (3 * K + 63) >> 6, ntxf = FT ? (3 * L * K + 63) >> 6 : 0;
+        wtiles(3 * ntx + ntxf, [&](int tile, int lane) {
+            if (FT && tile >= 3 * ntx) {
+                // ---- column j = 9 + 3 leg + a of a foot-position state: it sits in its leg's Meas rows (+I, with -I on
+                //      the base position), in the Dyn rows of this step (+I) and of the previous one (-I)
+                const int e = (tile - 3 * ntx) * 64 + lane;
+                if (e >= 3 * L * K) return;
+                const int k = e / (3 * L), la = e - 3 * L * k, leg = la / 3, a = la - 3 * leg, j = 9 + la;
+                const bool hn = k < K1, hp = k > 0;
+                const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
+                const double dj = q.D[ix.x(k, j)];
+                double em[3], dp[3], df[3], en[3], ep[3], dfn[3], wm[6], wn[6], wp[6];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    em[t] = q.E[ix.rm(k, 3 * leg + t)];
+                    dp[t] = q.D[ix.x(k, t)];
+                    df[t] = q.D[ix.x(k, 9 + 3 * leg + t)];
+                    en[t] = q.E[ix.rd(kn, 9 + 3 * leg + t)];
+                    ep[t] = q.E[ix.rd(kp, 9 + 3 * leg + t)];
+                    dfn[t] = q.D[ix.x(hn ? k + 1 : k, 9 + 3 * leg + t)];
+                }
+#pragma unroll
+                for (int t = 0; t < 6; ++t) { wm[t] = q.Wm[(k * L + leg) * 6 + t]; wn[t] = q.Wf[(kn * L + leg) * 6 + t]; wp[t] = q.Wf[(kp * L + leg) * 6 + t]; }
+                for (int i = 0; i <= j; ++i) {  // upper part of column j of T_kk, mirrored
+                    double v = 0.0;
+                    if (i < 3) v = -em[i] * dp[i] * symget(wm, i, a, 3) * em[a] * dj;
+                    else if (i >= 9 + 3 * leg) {
+                        const int t = i - 9 - 3 * leg;
+                        v = em[t] * df[t] * symget(wm, t, a, 3) * em[a] * dj;
+                        if (hn) v += en[t] * df[t] * symget(wn, t, a, 3) * en[a] * dj;
+                        if (hp) v += ep[t] * df[t] * symget(wp, t, a, 3) * ep[a] * dj;
+                        if (i == j) v += sigma;
+                    }
+                    if (k == 0) v += cc * q.D[ix.x(0, i)] * q.Mp[NS * i + j] * dj;
+                    q.Sinv[k * NS2 + NS * i + j] = v;
+                    q.Sinv[k * NS2 + NS * j + i] = v;
+                }
+                if (hn) {  // column j of C_k: only the same foot of the next step
+                    for (int i = 0; i < NS; ++i) {
+                        const int t = i - 9 - 3 * leg;
+                        q.PA[k * NS2 + NS * i + j] = (t >= 0 && t < 3) ? -en[t] * dfn[t] * symget(wn, t, a, 3) * en[a] * dj : 0.0;
+                    }
+                }
+                return;
+            }
             const int kind = tile < ntx ? 0 : (tile < 2 * ntx ? 1 : 2);
             const int e3 = (tile - kind * ntx) * 64 + lane;
             if (e3 >= 3 * K) return;
@@ -552,7 +739,10 @@ DEKF_FN bool solve_factor(Q& q) {
                     for (int i = 0; i < 9; ++i) {
                         double cv = -en[i] * dn[i] * pa[i];
                         if (kind == 0 && i < 3) cv -= ev[i] * dn[i] * symget(wc, i, a, 3) * ev[a] * dj;
-                        q.PA[k * 81 + 9 * i + j] = cv;
+                        q.PA[k * NS2 + NS * i + j] = cv;
+                    }
+                    if constexpr (FT) {
+                        for (int i = 9; i < NS; ++i) q.PA[k * NS2 + NS * i + j] = 0.0;  // no coupling of a foot to the base across steps
                     }
                 }
             }
@@ -572,8 +762,18 @@ DEKF_FN bool solve_factor(Q& q) {
                     tc[i] += hp ? dx[i] * s * dj : 0.0;
                 }
             }
-            // ---- Meas rows (velocity block), arrival cost (block 0), sigma
-            if (kind == 1) {
+            // ---- Meas rows (velocity block; with foot-position states the position block), arrival cost (block 0), sigma
+            if constexpr (FT) {
+                if (kind == 0) {
+#pragma unroll
+                    for (int leg = 0; leg < L; ++leg) {
+                        const double* wm = q.Wm + (k * L + leg) * 6;
+                        const double ea = q.E[ix.rm(k, 3 * leg + a)];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) tc[i] += q.E[ix.rm(k, 3 * leg + i)] * dx[i] * symget(wm, i, a, 3) * ea * dj;
+                    }
+                }
+            } else if (kind == 1) {
 #pragma unroll
                 for (int leg = 0; leg < L; ++leg) {
                     const double* wm = q.Wm + (k * L + leg) * 6;
@@ -586,9 +786,9 @@ DEKF_FN bool solve_factor(Q& q) {
             for (int i = 0; i < 9; ++i) {
                 if (i > j) continue;
                 double v = tc[i] + (i == j ? sigma : 0.0);
-                if (k == 0) v += cc * dx[i] * q.Mp[9 * i + j] * dj;
-                q.Sinv[k * 81 + 9 * i + j] = v;  // full 9x9 storage, both triangles
-                q.Sinv[k * 81 + 9 * j + i] = v;
+                if (k == 0) v += cc * dx[i] * q.Mp[NS * i + j] * dj;
+                q.Sinv[k * NS2 + NS * i + j] = v;  // full NS x NS storage, both triangles
+                q.Sinv[k * NS2 + NS * j + i] = v;
             }
         });
         DEKF_SYNC();
@@ -601,6 +801,11 @@ DEKF_FN bool solve_factor(Q& q) {
     //       bottom  S_k = T_kk - What_k C_k,            What_{k-1} = C_{k-1}' S_k^-1 (k >  mid)
     //       middle  S_m = T_mm - W_{m-1} C_{m-1}' - What_m C_m
     //     W_k lives in Wk[k] for k < mid, What_k in Wk[k] for k >= mid (it couples block k+1 to k).
+    if constexpr (NS != 9) {
+        const bool okg = factor_blocks_generic(q);
+        DEKF_PROF_MARK(q, 8);
+        return okg;
+    } else {
     bool ok = true;
     const int mid = mid_block(K);
     const int nph = (mid > K - 1 - mid ? mid : K - 1 - mid);
@@ -829,6 +1034,7 @@ DEKF_FN bool solve_factor(Q& q) {
 #endif
     DEKF_PROF_MARK(q, 8);
     return ok;
+    }  // NS == 9
 }
 
 #include "mhe_admm_core.h"
@@ -841,16 +1047,18 @@ struct SolveInfo {
 // osqp_setup + osqp_solve + extraction.  window = steps kstart .. kstart+K-1 (newest = T).
 // FACTOR_LDS / PA_LDS are compile-time so that every pointer has a provable address space
 // (ds_read/ds_write instead of flat_load) — see SolveLayout::factor_in_lds / pa_in_lds.
-template <int L, bool FACTOR_LDS, bool PA_LDS, int NFIX = 0>
+template <int L, bool FACTOR_LDS, bool PA_LDS, int NFIX = 0, int FT = 0>
 DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, double* lds, double* gws) {
     // NFIX != 0: the horizon is a compile-time constant, so every LDS array sits at a constant offset
     // (folded into the ds_read/ds_write immediates instead of living in scalar registers)
     const int NH = NFIX ? NFIX : c.N;
+    constexpr int NS = 9 + 3 * L * FT, NS2 = NS * NS;
+    using TM = TmpMap<NS>;
     SolveLayout lay;
-    lay.init(NH, L);
+    lay.init(NH, L, FT);
     Gws g;
-    g.init(NH, L);
-    SolveCtx<L, NFIX, FACTOR_LDS> q{c, s, b, K, kstart, 0, 0, IdxT<L>(K)};
+    g.init(NH, L, FT);
+    SolveCtx<L, NFIX, FACTOR_LDS, FT> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
         double* p = lds;
         q.x = p; p += lay.n_pad;
@@ -858,12 +1066,14 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         q.y = p; p += lay.m_pad;
         q.xt = p; p += lay.n_pad;
         q.cf = q.xt;
-        q.gb = q.xt + lay.m_pad;  // 3 (N - 1) <= n_pad - m_pad = 9 N
+        q.gb = q.xt + lay.m_pad;  // 3 (N - 1) <= n_pad - m_pad = NS N
         q.zt = p; p += lay.m_pad;
         q.at = p; p += lay.m_pad;
-        q.xs = p; p += 9 * NH;
-        q.xd = p; p += 9 * NH;
-        q.tmp = p; p += SOLVE_TMP;
+        q.xs = p; p += NS * NH;
+        q.xd = p; p += NS * NH;
+        q.tmp = p; p += TM::LEN;
+        q.Sf = nullptr;
+        q.Wf = nullptr;
         if constexpr (FACTOR_LDS) {
             q.D = p; p += lay.n_pad;
             q.E = p; p += lay.m_pad;
@@ -872,22 +1082,25 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
             q.Sv = p; p += NH * 6 * L;
             q.Sw = p; p += NH * SWS;
             q.Sc = p; p += NH * 6;
-            q.Sinv = p; p += NH * 81;
-            q.Wk = p; p += NH * 81;
+            if constexpr (FT) { q.Sf = p; p += NH * 6 * L; }
+            q.Sinv = p; p += NH * NS2;
+            q.Wk = p; p += NH * NS2;
             q.R = p; p += NH * 9;
         } else {
             q.D = gws + g.D; q.E = gws + g.E; q.lo = gws + g.lo; q.hi = gws + g.hi;
             q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc;
+            if constexpr (FT) q.Sf = gws + g.Sf;
             q.Sinv = gws + g.Sinv; q.Wk = gws + g.Wk; q.R = gws + g.rho;  // rho slot is unused: R (9K <= m_pad)
         }
         q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
+        if constexpr (FT) q.Wf = gws + g.Wf;
         if constexpr (PA_LDS) q.PA = q.xt;
         else q.PA = gws + g.PA;
     }
-    q.n = (K - 1) * IdxT<L>::SV + 9 + IdxT<L>::nm;
-    q.m = (K - 1) * IdxT<L>::SC + IdxT<L>::nm;
-    q.Mp = s.Mp + 81 * (size_t)b;
-    q.np = s.np_ + 9 * (size_t)b;
+    q.n = (K - 1) * IdxT<L, FT>::SV + NS + IdxT<L, FT>::nm;
+    q.m = (K - 1) * IdxT<L, FT>::SC + IdxT<L, FT>::nm;
+    q.Mp = s.Mp + (size_t)NS2 * b;
+    q.np = s.np_ + (size_t)NS * b;
     q.cc = 1.0;
     q.Pst = q.Sinv;  // Sinv | Wk are adjacent in both placements and dead until a factorisation writes them
     q.staged = false;
@@ -922,9 +1135,8 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         at[r] = 0.0;  // u = rho z - y of the cold start
     });
     bool ok = solve_factor(q);
-    double qs[9];  // scaled linear cost on x_0 (registers for the checks, LDS copy for the per-lane look-ups)
-    for (int j = 0; j < 9; ++j) qs[j] = q.cc * q.D[ix.x(0, j)] * q.np[j];
-    wfor(9, [&](int j) { q.tmp[162 + j] = q.cc * q.D[ix.x(0, j)] * q.np[j]; });
+    // scaled linear cost on x_0 (LDS copy for the per-lane look-ups)
+    wfor(NS, [&](int j) { q.tmp[TM::QSL + j] = q.cc * q.D[ix.x(0, j)] * q.np[j]; });
     const double sigma = c.sigma, alpha = c.alpha;
     const double cinv = 1.0 / q.cc;
     int iter = 0;
@@ -969,9 +1181,9 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     info.rho = q.rho;
     // store_solution + update() tail: x_T = D x ; v_b = R (x_T[3:6] + gyro x p_imu_2_opti)
     const double* rT = q.rec(K - 1);
-    double xT[9];
+    double xT[NS];
     bool finite = ok;
-    for (int j = 0; j < 9; ++j) {
+    for (int j = 0; j < NS; ++j) {
         xT[j] = q.D[ix.x(K - 1, j)] * x[ix.x(K - 1, j)];
         if (!(fabs(xT[j]) <= 1e300)) finite = false;
     }
@@ -982,7 +1194,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         cross3(rT + Rec::GY, p_opti, wxp);
         for (int a = 0; a < 3; ++a) t[a] = xT[3 + a] + wxp[a];
         mv3(rT + Rec::R, t, vb);
-        for (int j = 0; j < 9; ++j) s.x_mhe[9 * (size_t)b + j] = xT[j];
+        for (int j = 0; j < NS; ++j) s.x_mhe[NS * (size_t)b + j] = xT[j];
         for (int a = 0; a < 3; ++a) s.v_b[3 * (size_t)b + a] = vb[a];
         s.status[b] = info.status;
         s.iters[b] = info.iters;

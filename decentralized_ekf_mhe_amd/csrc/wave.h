@@ -209,6 +209,7 @@ DEKF_FN void w0for(int n, F f) {
 }
 #else
 #define DEKF_IN_WAVE0() true
+inline void wave_sync() {}
 template <class F>
 inline void w0for(int n, F f) {
     for (int i = 0; i < n; ++i) f(i);

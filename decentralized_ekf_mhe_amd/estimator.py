@@ -112,7 +112,7 @@ class BatchedEstimator:
     # ---- results ---------------------------------------------------------------------
     def get(self):
         B = self.batch
-        out = dict(x=np.zeros((B, 9)), v_b=np.zeros((B, 3)), quat=np.zeros((B, 4)), p_vo=np.zeros((B, 3)),
+        out = dict(x=np.zeros((B, self.params.dim_state)), v_b=np.zeros((B, 3)), quat=np.zeros((B, 4)), p_vo=np.zeros((B, 3)),
                    status=np.zeros(B, np.int32))
         capi.check(self.lib.dekf_get(self.h, *[C.c_void_p(out[k].ctypes.data) for k in ("x", "v_b", "quat", "p_vo", "status")],
                                      capi.DEKF_HOST))
@@ -140,7 +140,8 @@ class BatchedEstimator:
         return P
 
     def kf_cov(self):
-        Cm = np.zeros((self.batch, 9, 9))
+        ns = self.params.dim_state
+        Cm = np.zeros((self.batch, ns, ns))
         capi.check(self.lib.dekf_get_kf_cov(self.h, C.c_void_p(Cm.ctypes.data), capi.DEKF_HOST))
         return Cm
 

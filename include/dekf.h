@@ -70,7 +70,8 @@ typedef struct dekf_params {
     double p_ib[3];
     int num_legs;       /* leg_odom.num_leg */
     int joints_per_leg; /* 3 on Go1 (hard-coded block<3,3> in the reference) */
-    int leg_odom_type;  /* 0 foot-velocity (supported); 1 foot-position (not yet) */
+    int leg_odom_type;  /* 0: foot-velocity measurements, dim_state 9.  1: foot positions are states,
+                         * dim_state = 9 + 3 num_legs (21 on Go1), DecentralEst.cpp:20 */
     double joint_position_std[DEKF_MAX_JOINTS];
     double joint_velocity_std[DEKF_MAX_JOINTS];
     double foot_slide_std[3];
@@ -168,7 +169,8 @@ dekf_status dekf_update(dekf_handle h, int T);
 dekf_status dekf_step(dekf_handle h, int T);
 
 /* ---- results: the public members read by EstSub.cpp:99-106 ---------------------- */
-/* x_mhe[B][9] (x_MHE_ / x_KF_), v_b[B][3] (v_MHE_b_ / v_KF_b_), quat[B][4] (EKF
+/* x_mhe[B][dim_state] (x_MHE_ / x_KF_; dim_state = 9 + 3 * leg_odom_type * num_legs: p_s, v_s, accel bias,
+ * then the foot positions of leg_odom_type 1), v_b[B][3] (v_MHE_b_ / v_KF_b_), quat[B][4] (EKF
  * quaternion_, wxyz), p_vo[B][3] (p_vo_accmulate_), status[B] (int, see below).
  * Any pointer may be NULL. */
 dekf_status dekf_get(dekf_handle h, double* x_mhe, double* v_b, double* quat, double* p_vo,
@@ -179,7 +181,7 @@ dekf_status dekf_get_ekf_cov(dekf_handle h, double* cov, dekf_mem where);
  * pri_res[B], dua_res[B] (unscaled OSQP residuals). Any pointer may be NULL. */
 dekf_status dekf_get_solver_info(dekf_handle h, int* iters, int* rho_updates, double* pri_res,
                                  double* dua_res, dekf_mem where);
-/* KF covariance C_KF_[B][9][9] (est_type 1). */
+/* KF covariance C_KF_[B][dim_state][dim_state] (est_type 1). */
 dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where);
 
 /* status[B] values written by dekf_update */

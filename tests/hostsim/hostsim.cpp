@@ -31,11 +31,11 @@ void* hs_create(const dekf_params* p, int B) {
     Sim* h = new Sim();
     if (fill_cfg(*p, B, h->c)) { delete h; return nullptr; }
     alloc_state(h->c, h->s, 1, [&](size_t bytes) { void* q = std::calloc(1, bytes ? bytes : 8); h->blocks.push_back(q); return q; });
-    Gws g; g.init(h->c.N, h->c.L);
+    Gws g; g.init(h->c.N, h->c.L, h->c.ft);
     h->gws_len = g.total;
-    SolveLayout lay; lay.init(h->c.N, h->c.L);
+    SolveLayout lay; lay.init(h->c.N, h->c.L, h->c.ft);
     int n = (int)(lay.lds_bytes() / 8);
-    int a = AsmScratch::len(h->c.L), k = KfScratch::len(h->c.L);
+    int a = AsmScratch::len(h->c.L, h->c.ft), k = KfScratch::len(h->c.L, h->c.ft);
     h->lds.assign((size_t)std::max(n, std::max(a, k)), 0.0);
     for (int b = 0; b < B; ++b) {
         for (int i = 0; i < 4; ++i) { h->s.ekf_q[(size_t)i * B + b] = h->c.ekf_q0[i]; h->s.quat[4 * b + i] = h->c.ekf_q0[i]; }
@@ -90,12 +90,23 @@ void hs_update(void* hv, int T) {
         if (h->c.est_type == 0) {
             assemble_update(h->c, h->s, b, T, h->pushes, h->lds.data());
             int kstart = T - h->c.N + 1 > 0 ? T - h->c.N + 1 : 0;
-            SolveLayout lay; lay.init(h->c.N, h->c.L);
+            SolveLayout lay; lay.init(h->c.N, h->c.L, h->c.ft);
             int K = T - kstart + 1;
 #define HS_SOLVE(LEGS)                                                                                      \
     if (lay.pa_in_lds()) solve_window<LEGS, true, true>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws); \
     else if (lay.factor_in_lds()) solve_window<LEGS, true, false>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws); \
     else solve_window<LEGS, false, false>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);
+#define HS_SOLVE_FOOT(LEGS)                                                                                              \
+    if (lay.factor_in_lds()) solve_window<LEGS, true, false, 0, 1>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);     \
+    else solve_window<LEGS, false, false, 0, 1>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);
+            if (h->c.ft) {
+                switch (h->c.L) {
+                    case 1: HS_SOLVE_FOOT(1) break;
+                    case 2: HS_SOLVE_FOOT(2) break;
+                    case 3: HS_SOLVE_FOOT(3) break;
+                    default: HS_SOLVE_FOOT(4) break;
+                }
+            } else
             switch (h->c.L) {
                 case 1: HS_SOLVE(1) break;
                 case 2: HS_SOLVE(2) break;
@@ -103,6 +114,7 @@ void hs_update(void* hv, int T) {
                 default: HS_SOLVE(4) break;
             }
 #undef HS_SOLVE
+#undef HS_SOLVE_FOOT
         } else {
             kf_update(h->c, h->s, b, h->pushes, h->lds.data());
         }
@@ -111,7 +123,7 @@ void hs_update(void* hv, int T) {
 }
 void hs_get(void* hv, double* x, double* vb, double* quat, double* p_vo, int* status, int* iters, int* rho_updates) {
     Sim* h = (Sim*)hv; size_t B = h->c.B;
-    if (x) std::memcpy(x, h->s.x_mhe, 9 * B * 8);
+    if (x) std::memcpy(x, h->s.x_mhe, (size_t)h->c.ns * B * 8);
     if (vb) std::memcpy(vb, h->s.v_b, 3 * B * 8);
     if (quat) std::memcpy(quat, h->s.quat, 4 * B * 8);
     if (p_vo) std::memcpy(p_vo, h->s.p_vo, 3 * B * 8);
@@ -125,17 +137,18 @@ void hs_get_ekf_cov(void* hv, double* P) {
 }
 void hs_get_arrival(void* hv, double* M, double* n) {
     Sim* h = (Sim*)hv; size_t B = h->c.B;
-    std::memcpy(M, h->s.Mp, 81 * B * 8); std::memcpy(n, h->s.np_, 9 * B * 8);
+    size_t ns = h->c.ns;
+    std::memcpy(M, h->s.Mp, ns * ns * B * 8); std::memcpy(n, h->s.np_, ns * B * 8);
 }
 // scaling vectors of the LAST instance solved (scratch slab 0): D[n], E[m]
 void hs_get_scaling(void* hv, int n, int m, double* D, double* E) {
     Sim* h = (Sim*)hv;
-    Gws g; g.init(h->c.N, h->c.L);
-    SolveLayout lay; lay.init(h->c.N, h->c.L);
+    Gws g; g.init(h->c.N, h->c.L, h->c.ft);
+    SolveLayout lay; lay.init(h->c.N, h->c.L, h->c.ft);
     const double* Dp = h->s.gws + g.D;
     const double* Ep = h->s.gws + g.E;
     if (lay.factor_in_lds()) {  // same carve order as solve_window
-        Dp = h->lds.data() + 2 * lay.n_pad + 4 * lay.m_pad + 18 * h->c.N + SOLVE_TMP;
+        Dp = h->lds.data() + 2 * lay.n_pad + 4 * lay.m_pad + 2 * lay.ns * h->c.N + solve_tmp_len(lay.ns);
         Ep = Dp + lay.n_pad;
     }
     std::memcpy(D, Dp, (size_t)n * 8); std::memcpy(E, Ep, (size_t)m * 8);

@@ -87,7 +87,7 @@ class HostSim:
 
     def get(self):
         B = self.B
-        x, vb, q, pv = np.zeros((B, 9)), np.zeros((B, 3)), np.zeros((B, 4)), np.zeros((B, 3))
+        x, vb, q, pv = np.zeros((B, self.p.dim_state)), np.zeros((B, 3)), np.zeros((B, 4)), np.zeros((B, 3))
         st, it, ru = (np.zeros(B, np.int32) for _ in range(3))
         lib().hs_get(self.h, _p(x), _p(vb), _p(q), _p(pv), _p(st), _p(it), _p(ru))
         return dict(x=x, v_b=vb, quat=q, p_vo=pv, status=st, iters=it, rho_updates=ru)
@@ -98,7 +98,8 @@ class HostSim:
         return P
 
     def arrival(self):
-        M, n = np.zeros((self.B, 9, 9)), np.zeros((self.B, 9))
+        ns = self.p.dim_state
+        M, n = np.zeros((self.B, ns, ns)), np.zeros((self.B, ns))
         lib().hs_get_arrival(self.h, _p(M), _p(n))
         return M, n
 

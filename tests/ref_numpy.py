@@ -45,26 +45,42 @@ def kkt_exact(H, g, A, l, u):
 
 
 class Model:
-    """Constants of DecentralizedEstimation::initialize for leg_odom_type 0."""
+    """Constants of DecentralizedEstimation::initialize; both leg-odometry types: 0 foot-velocity pseudo-measurements
+    (9 states), 1 foot positions as extra states (9 + 3 L; DecentralEst.cpp:20, 101-113, 310-325, 432-451, 550-563)."""
 
     def __init__(self, p):
         self.p = p
         self.L, self.nj, self.N = p.num_legs, p.joints_per_leg, p.N
+        self.ft = p.leg_odom_type
+        self.ns = 9 + 3 * self.L * self.ft
         self.dt = 1.0 / p.rate
         sq = lambda a, n=3: np.diag(np.array(a[:n]) ** 2)
         self.C_p, self.C_accel, self.C_bias = sq(p.p_process_std), sq(p.accel_input_std), sq(p.accel_bias_std)
         self.C_gyro = sq(p.gyro_input_std)
         self.C_enc_pos, self.C_enc_vel = sq(p.joint_position_std, self.nj), sq(p.joint_velocity_std, self.nj)
-        self.C_swing = sq(p.foot_swing_std)
+        self.C_swing, self.C_slide = sq(p.foot_swing_std), sq(p.foot_slide_std)
         self.Q_vo = np.diag(1.0 / np.array(p.vo_p_std[:3]) ** 2)
-        self.C_prior = np.diag(np.concatenate([np.array(p.p_init_std[:3]), np.array(p.v_init_std[:3]),
-                                               np.array(p.accel_bias_init_std[:3])]) ** 2)
-        self.A_meas = np.zeros((3 * self.L, 9))
+        prior = [np.array(p.p_init_std[:3]), np.array(p.v_init_std[:3]), np.array(p.accel_bias_init_std[:3])]
+        prior += [np.array(p.foot_init_std[:3])] * (self.L * self.ft)
+        self.C_prior = np.diag(np.concatenate(prior) ** 2)
+        self.A_meas = np.zeros((3 * self.L, self.ns))
         for i in range(self.L):
-            self.A_meas[3 * i:3 * i + 3, 3:6] = np.eye(3)
+            if self.ft:
+                self.A_meas[3 * i:3 * i + 3, 0:3] = -np.eye(3)
+                self.A_meas[3 * i:3 * i + 3, 9 + 3 * i:12 + 3 * i] = np.eye(3)
+            else:
+                self.A_meas[3 * i:3 * i + 3, 3:6] = np.eye(3)
+
+    def x_prior(self, b_meas0):
+        """prior mean: zero, except that every foot starts at its first measurement R p_foot (:310-325)"""
+        x = np.zeros(self.ns)
+        if self.ft:
+            x[9:] = b_meas0
+        return x
 
     def sample(self, s, k, b, quat):
-        """measurement-side quantities of step k: R, a_s, omega, b_meas, C_meas"""
+        """measurement-side quantities of step k: R, a_s, omega, b_meas, C_meas (+ the contact flags, which decide
+        the process noise of the foot states of the NEXT dynamics step)"""
         R = quat_to_rot(np.asarray(quat, float))
         a_s = R @ s["accel"][k, b] + np.array([0, 0, -9.81])
         om = s["gyro"][k, b]
@@ -72,47 +88,63 @@ class Model:
         C_meas = np.zeros((3 * self.L, 3 * self.L))
         for i in range(self.L):
             J, pf, qd = s["J"][k, b, i], s["p_foot"][k, b, i], s["qdot"][k, b, i]
-            b_meas[3 * i:3 * i + 3] = -R @ J @ qd - R @ np.cross(om, pf)
+            blk = slice(3 * i, 3 * i + 3)
+            if self.ft:
+                b_meas[blk] = R @ pf
+                C_meas[blk, blk] = R @ (J @ self.C_enc_pos @ J.T) @ R.T
+                continue
+            b_meas[blk] = -R @ J @ qd - R @ np.cross(om, pf)
             if s["contact"][k, b, i] == 0.0:
-                C_meas[3 * i:3 * i + 3, 3 * i:3 * i + 3] = self.C_swing
+                C_meas[blk, blk] = self.C_swing
             else:
                 G = np.hstack([-J, -skew(om) @ J, skew(pf)])
                 Cm = np.zeros((2 * self.nj + 3,) * 2)
                 Cm[:self.nj, :self.nj] = self.C_enc_vel
                 Cm[self.nj:2 * self.nj, self.nj:2 * self.nj] = self.C_enc_pos
                 Cm[2 * self.nj:, 2 * self.nj:] = self.C_gyro
-                C_meas[3 * i:3 * i + 3, 3 * i:3 * i + 3] = R @ G @ Cm @ G.T @ R.T
+                C_meas[blk, blk] = R @ G @ Cm @ G.T @ R.T
+        self.last_contact = np.array(s["contact"][k, b], float)
         return R, a_s, om, b_meas, C_meas
 
-    def dynamics(self, R, a_s):
-        dt = self.dt
-        A = np.eye(9)
+    def dynamics(self, R, a_s, contact=None):
+        """A, b and the process covariance G C_in G' of one step (foot states: identity dynamics, dt^2 R C R' with
+        C = foot_slide in contact, foot_swing otherwise)"""
+        dt, ns = self.dt, self.ns
+        A = np.eye(ns)
         A[0:3, 3:6] = dt * np.eye(3)
         A[0:3, 6:9] = -dt * dt / 2 * R
         A[3:6, 6:9] = -dt * R
-        b = np.concatenate([-dt * dt / 2 * a_s, -dt * a_s, np.zeros(3)])
-        G = np.zeros((9, 9))
+        b = np.concatenate([-dt * dt / 2 * a_s, -dt * a_s, np.zeros(ns - 6)])
+        G = np.zeros((ns, ns))
         G[0:3, 0:3] = dt * R
         G[0:3, 3:6] = 0.5 * dt * dt * R
         G[3:6, 3:6] = dt * R
         G[6:9, 6:9] = dt * np.eye(3)
-        Cin = np.zeros((9, 9))
+        Cin = np.zeros((ns, ns))
         Cin[0:3, 0:3], Cin[3:6, 3:6], Cin[6:9, 6:9] = self.C_p, self.C_accel, self.C_bias
+        for i in range(self.L * self.ft):
+            blk = slice(9 + 3 * i, 12 + 3 * i)
+            G[blk, blk] = dt * R
+            Cin[blk, blk] = self.C_slide if contact[i] != 0.0 else self.C_swing
         return A, b, G @ Cin @ G.T
 
 
 def kalman_filter(p, s, b, quats, ref_double_init=False):
-    """Textbook KF on the same model; returns x[K,9], C[K,9,9].
+    """Textbook KF on the same model; returns x[K,ns], C[K,ns,ns].
     ref_double_init=True reproduces est_type 1 of the reference exactly: initialize() runs
     InitializeKF() AND UpdateKF() (DecentralEst.cpp:140-141), i.e. the first sample is
     predicted-through and corrected a second time before update(1)."""
     m = Model(p)
+    ns = m.ns
     K = s["imu_t"].shape[0]
-    xs, Cs = np.zeros((K, 9)), np.zeros((K, 9, 9))
-    x, Cc = np.zeros(9), m.C_prior.copy()
+    xs, Cs = np.zeros((K, ns)), np.zeros((K, ns, ns))
+    x, Cc = None, m.C_prior.copy()
     prev = None
     for k in range(K):
         R, a_s, om, b_meas, C_meas = m.sample(s, k, b, quats[k])
+        contact = m.last_contact
+        if k == 0:
+            x = m.x_prior(b_meas)
         if k > 0:
             A, bd, Cd = m.dynamics(*prev)
             x = A @ x - bd
@@ -120,17 +152,17 @@ def kalman_filter(p, s, b, quats, ref_double_init=False):
         S = m.A_meas @ Cc @ m.A_meas.T + C_meas
         Kg = Cc @ m.A_meas.T @ np.linalg.inv(S)
         x = x + Kg @ (b_meas - m.A_meas @ x)
-        Cc = (np.eye(9) - Kg @ m.A_meas) @ Cc
+        Cc = (np.eye(ns) - Kg @ m.A_meas) @ Cc
         if k == 0 and ref_double_init:
-            A, bd, Cd = m.dynamics(R, a_s)
+            A, bd, Cd = m.dynamics(R, a_s, contact)
             x = A @ x - bd
             Cc = A @ Cc @ A.T + Cd
             S = m.A_meas @ Cc @ m.A_meas.T + C_meas
             Kg = Cc @ m.A_meas.T @ np.linalg.inv(S)
             x = x + Kg @ (b_meas - m.A_meas @ x)
-            Cc = (np.eye(9) - Kg @ m.A_meas) @ Cc
+            Cc = (np.eye(ns) - Kg @ m.A_meas) @ Cc
         xs[k], Cs[k] = x, Cc
-        prev = (R, a_s)
+        prev = (R, a_s, contact)
     return xs, Cs
 
 
@@ -188,16 +220,19 @@ class VoTrack:
 def window_qp(p, s, b, quats, T, vo=False, return_track=False):
     """The UN-MARGINALISED QP after update(T) over ALL steps 0..T (for T < N this is the window itself), in the
     layout of SURVEY.md Appendix A: variables [x0 v0 | w0 c0 x1 v1 | ...], rows [M0 | D0 V0 M1 | ...].
-    vo=True: VO rows carry the equality bounds VoTrack writes, the others stay +-1e30."""
+    vo=True: VO rows carry the equality bounds VoTrack writes, the others stay +-1e30.  Both leg-odometry types."""
     m = Model(p)
     L = m.L
-    nm, ns, nc = 3 * L, 9, 3
+    nm, ns, nc = 3 * L, m.ns, 3
     sv, sc = ns + nm + ns + nc, nm + ns + nc
     n = (ns + nm) + T * sv
     mm = nm + T * sc
     H, g = np.zeros((n, n)), np.zeros(n)
     A, l, u = np.zeros((mm, n)), np.zeros(mm), np.zeros(mm)
-    samples = [m.sample(s, k, b, quats[k]) for k in range(T + 1)]
+    samples, contacts = [], []
+    for k in range(T + 1):
+        samples.append(m.sample(s, k, b, quats[k]))
+        contacts.append(m.last_contact)
     track = VoTrack(m.N, m.dt)
     for k in range(T + 1):
         if vo and k >= 1 and s["vo_mask"][k, b]:
@@ -213,7 +248,9 @@ def window_qp(p, s, b, quats, T, vo=False, return_track=False):
     def wo(k):  # w_k, c_k live in the block created at update(k+1)
         return (ns + nm) + k * sv
 
-    H[0:9, 0:9] = np.linalg.inv(m.C_prior)
+    Qp = np.linalg.inv(m.C_prior)
+    H[0:ns, 0:ns] = Qp
+    g[0:ns] = -Qp @ m.x_prior(samples[0][3])
     for k in range(T + 1):
         R, a_s, om, b_meas, C_meas = samples[k]
         r0 = 0 if k == 0 else nm + (k - 1) * sc + ns + nc
@@ -222,15 +259,18 @@ def window_qp(p, s, b, quats, T, vo=False, return_track=False):
         l[r0:r0 + nm] = u[r0:r0 + nm] = b_meas
         H[vo_(k):vo_(k) + nm, vo_(k):vo_(k) + nm] = np.linalg.inv(C_meas)
         if k < T:
-            Ad, bd, Cd = m.dynamics(R, a_s)
+            Ad, bd, Cd = m.dynamics(R, a_s, contacts[k])
             rd = nm + k * sc
             A[rd:rd + ns, xo(k):xo(k) + ns] = Ad
             A[rd:rd + ns, wo(k):wo(k) + ns] = -np.eye(ns)
             A[rd:rd + ns, xo(k + 1):xo(k + 1) + ns] = -np.eye(ns)
             l[rd:rd + ns] = u[rd:rd + ns] = bd
-            Qd = np.zeros((9, 9))
+            Qd = np.zeros((ns, ns))
             Qd[0:6, 0:6] = np.linalg.inv(Cd[0:6, 0:6])
             Qd[6:9, 6:9] = np.diag(1.0 / np.array(p.accel_bias_std[:3]) ** 2) / m.dt ** 2
+            for i in range(L * m.ft):
+                blk = slice(9 + 3 * i, 12 + 3 * i)
+                Qd[blk, blk] = np.linalg.inv(Cd[blk, blk])
             H[wo(k):wo(k) + ns, wo(k):wo(k) + ns] = Qd
             rc = rd + ns
             co = wo(k) + ns

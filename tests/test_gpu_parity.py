@@ -186,7 +186,7 @@ def test_call_order_errors():
     with pytest.raises(capi.DekfError) as e:
         est.update(1)
     assert e.value.status == capi.DEKF_ERR_ORDER
-    bad = _params(go1_params, leg_odom_type=1)
+    bad = _params(go1_params, leg_odom_type=2)
     with pytest.raises(capi.DekfError) as e:
         BatchedEstimator(bad, 2)
     assert e.value.status == capi.DEKF_ERR_INVALID
