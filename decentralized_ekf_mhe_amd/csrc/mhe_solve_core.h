@@ -458,32 +458,57 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
     double* fail = q.tmp + TM::FAIL;
     if (DEKF_LANE() == 0) *fail = 0.0;
     DEKF_SYNC();
-    // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]
-    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, double* ts) -> bool {
+    // Operand staging in LDS.  The factor lives in the workgroup's HBM slab (S^-1 and W alone are 141 KB for Go1), and a
+    // block needs W and C of its predecessor for the Schur update, then its own C for W = C S^-1: three 21 x 21 x 21
+    // products whose operands, read from the slab element by element, cost a memory round trip per handful of loads
+    // (92 k cycles per block measured).  xt | zt | at are dead during a factorisation (phase_rows<RESTART> rebuilds them),
+    // so each side keeps two NS x NS panels there: `wa` = W of the block just finished, `ca` = its C — exactly what the next
+    // block of that side subtracts.  Per block the slab is then touched four times, coalesced: T_kk in, C in, S^-1 out, W out.
+    // (only when the factor is NOT in LDS already, and only if the dead vectors are long enough: short windows are not)
+    double* stage[2] = {q.xt, q.xt + 2 * NS2 + 8};
+    const bool staged = !Q::FACTOR_LDS && 2 * (2 * NS2 + 8) <= (int)(q.xs - q.xt);
 #if DEKF_DEVICE_BUILD
-        const int lane = DEKF_LANE() & 63, l0 = lane, st = WAVE;
+    const int lane = DEKF_LANE() & 63, l0 = lane, st = WAVE;
 #else
-        const int l0 = 0, st = 1;
+    const int l0 = 0, st = 1;
 #endif
-        for (int p = l0; p < NS2; p += st) {
-            const int i = p / NS, j = p - NS * i;
-            double acc = q.Sinv[k * NS2 + p];
-            if (use_top) {
-                const double* Wp = q.Wk + (k - 1) * NS2 + NS * i;
-                const double* Cp = q.PA + (k - 1) * NS2 + NS * j;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-                for (int t = 0; t + 2 < NS; t += 3) { s0 += Wp[t] * Cp[t]; s1 += Wp[t + 1] * Cp[t + 1]; s2 += Wp[t + 2] * Cp[t + 2]; }
-                acc -= s0 + (s1 + s2);
-            }
-            if (use_bot) {
-                const double* Wh = q.Wk + k * NS2 + NS * i;
-                const double* Ck = q.PA + k * NS2 + j;
-                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-                for (int t = 0; t + 2 < NS; t += 3) { s0 += Wh[t] * Ck[NS * t]; s1 += Wh[t + 1] * Ck[NS * (t + 1)]; s2 += Wh[t + 2] * Ck[NS * (t + 2)]; }
-                acc -= s0 + (s1 + s2);
-            }
-            ts[p] = acc;
+    auto copy_panel = [&](double* dst, const double* src) {
+        for (int p = l0; p < NS2; p += st) dst[p] = src[p];
+    };
+    // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]
+    // have_prev: wa / ca of this side already hold the predecessor's W and C
+    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, double* ts, int side, bool have_prev) -> bool {
+        double* wa = stage[side];
+        double* ca = stage[side] + NS2;
+        if (staged && !have_prev) {  // (not taken today: every caller arrives with its predecessor's panels staged)
+            if (use_top) { copy_panel(stage[0], q.Wk + (k - 1) * NS2); copy_panel(stage[0] + NS2, q.PA + (k - 1) * NS2); }
+            if (use_bot) { copy_panel(stage[1], q.Wk + k * NS2); copy_panel(stage[1] + NS2, q.PA + k * NS2); }
         }
+        const double* Wt = staged ? stage[0] : q.Wk + (use_top ? k - 1 : 0) * NS2;
+        const double* Ct = staged ? stage[0] + NS2 : q.PA + (use_top ? k - 1 : 0) * NS2;
+        const double* Wb = staged ? stage[1] : q.Wk + k * NS2;
+        const double* Cb = staged ? stage[1] + NS2 : q.PA + k * NS2;
+        for (int p = l0; p < NS2; p += st) ts[p] = q.Sinv[k * NS2 + p];
+        wave_sync();
+        auto schur = [&](const double* W, const double* C, bool top) {
+            for (int p = l0; p < NS2; p += st) {
+                const int i = p / NS, j = p - NS * i;
+                const double* wr = W + NS * i;
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                if (top) {  // W_{k-1} C_{k-1}'
+                    const double* cr = C + NS * j;
+                    for (int t = 0; t + 2 < NS; t += 3) { s0 += wr[t] * cr[t]; s1 += wr[t + 1] * cr[t + 1]; s2 += wr[t + 2] * cr[t + 2]; }
+                } else {    // What_k C_k
+                    const double* cc = C + j;
+                    for (int t = 0; t + 2 < NS; t += 3) { s0 += wr[t] * cc[NS * t]; s1 += wr[t + 1] * cc[NS * (t + 1)]; s2 += wr[t + 2] * cc[NS * (t + 2)]; }
+                }
+                ts[p] -= s0 + (s1 + s2);
+            }
+        };
+        // the top side's panels are in stage[0], the bottom side's in stage[1] (the meeting block reads both)
+        if (use_top) schur(Wt, Ct, true);
+        if (use_top && use_bot) wave_sync();
+        if (use_bot) schur(Wb, Cb, false);
         wave_sync();
         bool good;
 #if DEKF_DEVICE_BUILD
@@ -496,23 +521,21 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
             wave_sync();  // every lane has read its column of S
             if (lane < NS) {
 #pragma unroll
-                for (int i = 0; i < NS; ++i) {
-                    ts[NS * i + lane] = a[i];
-                    q.Sinv[k * NS2 + NS * i + lane] = a[i];
-                }
+                for (int i = 0; i < NS; ++i) ts[NS * i + lane] = a[i];
             }
         }
 #else
         good = winverse_definite(ts, NS, ts + NS2);
-        for (int p = 0; p < NS2; ++p) q.Sinv[k * NS2 + p] = ts[p];
 #endif
+        if (staged && wmode != 0) copy_panel(ca, q.PA + (wmode == 1 ? k : k - 1) * NS2);
         wave_sync();
+        copy_panel(q.Sinv + k * NS2, ts);
         if (wmode != 0) {
             const int kw = wmode == 1 ? k : k - 1;
-            const double* Ck = q.PA + kw * NS2;
+            const double* cs0 = staged ? ca : q.PA + kw * NS2;
             for (int p = l0; p < NS2; p += st) {
                 const int i = p / NS, jj = p - NS * i;
-                const double* cr = wmode == 1 ? Ck + NS * i : Ck + i;  // row i of C, or column i (C')
+                const double* cr = wmode == 1 ? cs0 + NS * i : cs0 + i;  // row i of C, or column i (C')
                 const int cs = wmode == 1 ? 1 : NS;
                 const double* tc = ts + jj;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
@@ -521,7 +544,9 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
                     s1 += cr[(t + 1) * cs] * tc[NS * (t + 1)];
                     s2 += cr[(t + 2) * cs] * tc[NS * (t + 2)];
                 }
-                q.Wk[kw * NS2 + p] = s0 + (s1 + s2);
+                const double wv = s0 + (s1 + s2);
+                if (staged) wa[p] = wv;
+                q.Wk[kw * NS2 + p] = wv;
             }
         }
         wave_sync();
@@ -531,18 +556,19 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
     two_waves(
         [&] {
             bool g = true;
-            for (int k = 0; k < mid; ++k) g = factor_block(k, k > 0, false, 1, q.tmp + TM::SIDE0) && g;
+            for (int k = 0; k < mid; ++k) g = factor_block(k, k > 0, false, 1, q.tmp + TM::SIDE0, 0, k > 0) && g;
             if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
         },
         [&] {
             bool g = true;
-            for (int k = K - 1; k > mid; --k) g = factor_block(k, false, k < K - 1, 2, q.tmp + TM::SIDE1) && g;
+            for (int k = K - 1; k > mid; --k) g = factor_block(k, false, k < K - 1, 2, q.tmp + TM::SIDE1, 1, k < K - 1) && g;
             if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
         });
     DEKF_SYNC();
     two_waves(
         [&] {
-            bool g = factor_block(mid, mid > 0, mid < K - 1, 0, q.tmp + TM::SIDE0);
+            // the panels of both sides are still staged when the side ran at least one block
+            bool g = factor_block(mid, mid > 0, mid < K - 1, 0, q.tmp + TM::SIDE0, 0, true);
             if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
         },
         [&] {});

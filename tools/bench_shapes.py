@@ -54,3 +54,5 @@ if __name__ == "__main__":
     run("pogox N=100", pogox_params, 1024, 60)
     run("go1 KF mode (est_type 1: recursion instead of the QP)", go1_params, 4096, 200, est_type=1)
     run("go1 KF mode, batch 65536", go1_params, 65536, 100, est_type=1)
+    run("go1 with foot-position states (leg_odom_type 1, 21-dim blocks)", go1_params, 4096, 40, leg_odom_type=1)
+    run("go1 foot-position states, KF mode", go1_params, 4096, 100, leg_odom_type=1, est_type=1)

@@ -4,7 +4,7 @@
 debug buffer only) on the bench workload and prints the share of each section.  Never quote the
 absolute time of this build; read the shares.
 
-    DEKF_LIB=decentralized_ekf_mhe_amd/csrc/libdekf_prof.so python tools/profile_sections.py [batch [ticks [go1|cassie|pogox]]]
+    DEKF_LIB=decentralized_ekf_mhe_amd/csrc/libdekf_prof.so python tools/profile_sections.py [batch [ticks [go1|cassie|pogox|go1foot]]]
     DEKF_TIMELINE=1 DEKF_LIB=.../libdekf_tl.so python tools/profile_sections.py 4096 70   # -DDEKF_PROFILE -DDEKF_PROFILE_TL
 """
 import ctypes as C
@@ -31,8 +31,10 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
     shape = sys.argv[3] if len(sys.argv) > 3 else "go1"
-    p = {"go1": go1_params, "cassie": cassie_params, "pogox": pogox_params}[shape]()
+    p = {"go1": go1_params, "cassie": cassie_params, "pogox": pogox_params, "go1foot": go1_params}[shape]()
     p.ekf_rate = p.rate
+    if shape == "go1foot":
+        p.leg_odom_type = 1  # foot positions as states: 21-dim blocks, factor streamed from the HBM slab
     s = make_streams(p, B, K)
     sd = streams_to_device(s)
     est = BatchedEstimator(p, B)
