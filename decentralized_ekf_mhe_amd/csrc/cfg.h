@@ -95,9 +95,10 @@ struct Idx {
 // global-memory scratch of one solve (doubles), K_max = N steps, NS = 9 + 3 L ft states per step
 struct Gws {
     // D (n) | E (m) | lo (m) | hi (m) | rho (m) | Sv (K*6L) | Sw (K*25) | Sc (K*6) | Sf (K*6L ft) |
-    // Wm (K*6L) | Wd (K*24) | Wc (K*6) | Wf (K*6L ft) | PA (K*NS^2) | Sinv (K*NS^2) | Wk (K*NS^2)
+    // Wm (K*6L) | Wd (K*24) | Wc (K*6) | Wf (K*6L ft) | PA (K*NS^2) | Sinv (K*NS^2) | Wk (K*NS^2) |
+    // x (n) | z (m) | y (m) | zt (m) | cf (m): the row-phase state between chunks of iterations, three-workgroup placement only
     int n_pad, m_pad, K;
-    int D, E, lo, hi, rho, Sv, Sw, Sc, Sf, Wm, Wd, Wc, Wf, PA, Sinv, Wk, total;
+    int D, E, lo, hi, rho, Sv, Sw, Sc, Sf, Wm, Wd, Wc, Wf, PA, Sinv, Wk, x, z, y, zt, cf, total;
     DEKF_HD void init(int N, int L, int ft = 0) {
         K = N;
         const int nm = 3 * L, ns = 9 + (ft ? nm : 0), b2 = ns * ns;
@@ -120,6 +121,11 @@ struct Gws {
         PA = o; o += K * b2;
         Sinv = o; o += K * b2;
         Wk = o; o += K * b2;
+        x = o; o += n_pad;
+        z = o; o += m_pad;
+        y = o; o += m_pad;
+        zt = o; o += m_pad;
+        cf = o; o += m_pad;
         total = o;
     }
 };

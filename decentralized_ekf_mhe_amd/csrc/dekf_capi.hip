@@ -27,6 +27,10 @@ __global__ void k_mhe_assemble(DevCfg c, DevState s, int T, int pushes);
     __global__ void k_mhe_solve_gg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);
 __global__ void k_mhe_solve_ll_4_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
 __global__ void k_mhe_solve_lg_2_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
+#ifndef DEKF_NO_R3
+__global__ void k_mhe_solve_r3_4_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
+__global__ void k_mhe_solve_r3_2_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
+#endif
 DEKF_DECL_SOLVE(1)
 DEKF_DECL_SOLVE(2)
 DEKF_DECL_SOLVE(3)
@@ -69,6 +73,10 @@ struct dekf_handle_s {
     size_t stage_bytes = 0;
     int solve_grid = 0, gws_len = 0;
     void (*solve_kernel)(DevCfg, DevState, int, int, int) = nullptr;
+    // full windows (K == N) of the fixed-horizon shapes: the three-workgroups-per-CU kernel (kernels.hip), its own grid and LDS size
+    void (*solve_kernel_full)(DevCfg, DevState, int, int, int) = nullptr;
+    int solve_grid_full = 0;
+    size_t lds_solve_full = 0;
     size_t lds_solve = 0, lds_asm = 0, lds_kf = 0;
     int ekf_count = 0, pushes = 0, next_T = 0;
     bool initialized = false;
@@ -246,11 +254,24 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
         per_cu = 1;
     long slots = (long)per_cu * prop.multiProcessorCount;
     h->solve_grid = (int)(slots < batch ? slots : batch);
+#ifndef DEKF_NO_R3
+    if (!c.ft && c.N == 20 && (c.L == 4 || c.L == 2) && lay.r3_fits(c.L) && !getenv("DEKF_DISABLE_R3")) {
+        h->solve_kernel_full = c.L == 4 ? k_mhe_solve_r3_4_n20 : k_mhe_solve_r3_2_n20;
+        h->lds_solve_full = lay.r3_lds_bytes();
+        int pcf = 1;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pcf, (const void*)h->solve_kernel_full, DEKF_SOLVE_THREADS, h->lds_solve_full) != hipSuccess || pcf < 1)
+            pcf = 1;
+        const long sf = (long)pcf * prop.multiProcessorCount;
+        h->solve_grid_full = (int)(sf < batch ? sf : batch);
+        if (pcf <= per_cu) h->solve_kernel_full = nullptr;  // no residency gained: keep one kernel
+    }
+#endif
+    const int solve_slots = h->solve_kernel_full && h->solve_grid_full > h->solve_grid ? h->solve_grid_full : h->solve_grid;
     Gws g;
     g.init(c.N, c.L, c.ft);
     h->gws_len = g.total;
     bool ok = true;
-    alloc_state(h->c, h->s, h->solve_grid, [&](size_t bytes) -> void* {
+    alloc_state(h->c, h->s, solve_slots, [&](size_t bytes) -> void* {
         void* q = nullptr;
         if (!ok) return nullptr;
         if (hipMalloc(&q, bytes ? bytes : 8) != hipSuccess) { ok = false; return nullptr; }
@@ -431,7 +452,11 @@ dekf_status dekf_update(dekf_handle h, int T) {
         int kstart = T - h->c.N + 1 > 0 ? T - h->c.N + 1 : 0;
         {
             Timed t(h, 2);
-            h->solve_kernel<<<h->solve_grid, DEKF_SOLVE_THREADS, h->lds_solve, h->stream>>>(h->c, h->s, kstart, T - kstart + 1, h->gws_len);
+            const int K = T - kstart + 1;
+            if (h->solve_kernel_full && K == h->c.N)
+                h->solve_kernel_full<<<h->solve_grid_full, DEKF_SOLVE_THREADS, h->lds_solve_full, h->stream>>>(h->c, h->s, kstart, K, h->gws_len);
+            else
+                h->solve_kernel<<<h->solve_grid, DEKF_SOLVE_THREADS, h->lds_solve, h->stream>>>(h->c, h->s, kstart, K, h->gws_len);
         }
     } else {
         Timed t(h, 1);
@@ -542,7 +567,7 @@ dekf_status dekf_launch_info(dekf_handle h, int* solve_workgroups, int* compute_
     if (!h) return fail(DEKF_ERR_INVALID, "null handle");
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, h->device));
-    if (solve_workgroups) *solve_workgroups = h->solve_grid;
+    if (solve_workgroups) *solve_workgroups = h->solve_kernel_full ? h->solve_grid_full : h->solve_grid;
     if (compute_units) *compute_units = prop.multiProcessorCount;
     if (clock_hz) *clock_hz = (double)prop.clockRate * 1e3;
     return DEKF_OK;

@@ -361,7 +361,10 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
     const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15;
     const int i = li < 9 ? li : 8;
     const bool act = li < 9, leg = row < 2, top = (row & 1) == 0;
-    double *xs = q.xs, *xd = q.xd, *x = q.x;
+    // the x blocks of x and D: inside the full variable vector (stride SV per step), or compact (R3: [K][9] in LDS)
+    constexpr int XST = Q::R3 ? 9 : SV;
+    double *xs = q.xs, *xd = q.xd, *x = Q::R3 ? q.xb : q.x;
+    const double* Dx = Q::R3 ? q.Db : q.D;
     struct Ops { double w[9], rhs; };
     // ---------------- forward: step s = 1..M
     const double* fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
@@ -408,14 +411,14 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
         double s9[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) s9[t] = q.Sinv[M * 81 + 9 * i + t];
-        const double dm = q.D[M * SV + i], xm = x[M * SV + i];
+        const double dm = Dx[M * XST + i], xm = x[M * XST + i];
         const double src = all_rows_from_row1(v);                 // f^_{M+1} everywhere
         const double r = chain_matvec_dpp(src, w, row == 0 ? v : 0.0);
         if (row == 3 && act) xd[9 * (M + 1) + i] = r;              // -g_{M+1}
         const double um = -chain_matvec_dpp(r, s9, 0.0);           // row 0: S_M^-1 (f_M - W^_M f^_{M+1})
         if (row == 0 && act) {
             xd[9 * M + i] = dm * um;
-            x[M * SV + i] = alpha * um + (1.0 - alpha) * xm;
+            x[M * XST + i] = alpha * um + (1.0 - alpha) * xm;
         }
         v = row1_from_row0(um);                                    // rows 0 and 1 start from u_M
     }
@@ -424,9 +427,9 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
         struct Bops { double w[9], ng, dsc, xo; };
         const bool own = leg && act;
         double* xdp = own ? xd + 9 * M + i : dummy;       // block M; step s is at +- s blocks
-        double* xp = own ? x + M * SV + i : dummy;
-        const double* Dp = own ? q.D + M * SV + i : dummy;
-        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -SV : SV) : 0;
+        double* xp = own ? x + M * XST + i : dummy;
+        const double* Dp = own ? Dx + M * XST + i : dummy;
+        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0;
         const double* Wp = q.Wk + (top ? M : M - 1) * 81 + i;  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
         const int wstep = top ? -81 : 81;
         auto bload = [&](int s, Bops& o) {
@@ -1188,6 +1191,249 @@ DEKF_FN void row_tile_finish(Q& q, const RowTile& t, double alpha, double sigma)
         for (int a = 0; a < 3; ++a) ar[a] = E[t.r0 + a] * (xk[o + a] - xk[9 + o + a]);
         row_block_compute<3, false>(q, t.r0, t.sv0, ar, t, t.pre, alpha, sigma, t.vo);
     }
+}
+#endif
+
+#if DEKF_DEVICE_BUILD
+// ---------------------------------------------------------------- three workgroups per CU (R3)
+// What limits the solve kernel's throughput is how many instances a CU holds (the solve is a dependent chain that leaves
+// three of four wavefronts waiting), and what limits THAT is LDS: 79.7 KiB per instance allow two.  Of those, 36 KiB are
+// lane-private: a row block's state (slack x, z, y, t) and its constants (E, rho E D, D, bounds, slack-block inverse) are only
+// ever touched by the lane that owns the block.  Here they live in that lane's REGISTERS for a whole chunk of iterations (all
+// iterations up to the next termination check / rho adaptation), and in the workgroup's HBM slab in between, where the rare
+// phases (residuals, refactorisation, restart) find them.  LDS keeps what crosses lanes: x blocks, xs, xd, w, gb, the factor.
+// 45 KiB per instance: three workgroups per CU (measured with an aliased-layout build before this was written: +33 %).
+//
+// WAVE-SPECIALISED LOOPS.  Wavefront 0 runs nothing but the block-tridiagonal solve; wavefronts 1-3 own the row tiles and the
+// x-column tiles.  Each side has its own loop with the same sequence of workgroup barriers (s_barrier counts arrivals, it does
+// not care where a wavefront's program counter is), so the 80 state registers are not live in the solve's code and the solve's
+// operand sets are not live in the row code: both fit the 168 VGPRs that three wavefronts per SIMD leave each.
+//   barrier B1: xs complete   (workers: x columns)      ->  wavefront 0: solve
+//   barrier B2: xd complete   (wavefront 0: solve)      ->  workers: rows from registers, w and gb to LDS
+//   barrier B3: w, gb complete (workers)                ->  workers: x columns of the next iteration
+struct RowRegs {
+    int kind;  // 0 Meas leg block (equality), 1 Dyn position / velocity half on a lane pair, 2 VO or bias or Meas block on the generic path; -1 none
+    int k, r0, sv0;
+    bool vel, meas;  // kind 1: velocity half; kind 2: a Meas block folded into the VO / bias tile
+    int xo;          // kind 2: offset of the block's x entries inside a step (0 VO, 6 bias, 3 Meas)
+    double e[3], c2[3], cf[3], lo[3], hi[3];
+    double t[3], xs[3], z[3], y[3];
+    double a[6], b[9];
+    DEKF_FN void apply(const double* in, double* out) const {
+        double pin[3] = {0.0, 0.0, 0.0};
+        if (kind == 1) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) pin[j] = pair_swap(in[j]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            double acc = 0.0;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc += a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)] * in[j];
+            if (kind == 1) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc += b[3 * i + j] * pin[j];
+            }
+            out[i] = acc;
+        }
+    }
+};
+// Tiles: wavefront 1 the first 64 Meas leg blocks, wavefront 2 the Dyn lane pairs, wavefront 3 the VO and bias blocks plus the
+// Meas blocks beyond 64 (Go1: 16) on the generic projection path — for an equality block that path gives bit-identical results
+// (hi = lo: the clamp returns lo, rho_of returns rho_eq).
+template <class Q>
+DEKF_FN void row_regs_load(const Q& q, int w, int lane, RowRegs& t) {
+    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
+    const int K = q.K, K1 = K - 1, nmeas = K * L;
+    t.kind = -1; t.k = 0; t.r0 = 0; t.sv0 = 0; t.vel = false; t.meas = false; t.xo = 0;
+    bool vo = false;
+    const double* sp = q.Sv;
+    if (w == 1) {
+        if (lane >= nmeas) return;
+        const int k = lane / L, leg = lane - k * L;
+        t.kind = 0; t.k = k; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg; t.xo = 3;
+        sp = q.Sv + lane * 6;
+    } else if (w == 2) {
+        const int k = lane >> 1;
+        if (k >= K1) return;
+        t.kind = 1; t.k = k; t.vel = lane & 1; t.r0 = q.ix.rd(k, t.vel ? 3 : 0); t.sv0 = k * SV + 9 + NM + (t.vel ? 3 : 0);
+    } else {
+        if (lane < 2 * K1) {
+            vo = lane < K1;
+            const int k = vo ? lane : lane - K1;
+            t.kind = 2; t.k = k; t.xo = vo ? 0 : 6; t.r0 = vo ? q.ix.rv(k, 0) : q.ix.rd(k, 6); t.sv0 = k * SV + (vo ? 18 + NM : 9 + NM + 6);
+        } else {
+            const int e = 64 + lane - 2 * K1;
+            if (e >= nmeas) return;
+            const int k = e / L, leg = e - k * L;
+            t.kind = 2; t.meas = true; t.k = k; t.xo = 3; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg;
+            sp = q.Sv + e * 6;
+        }
+    }
+    if (t.kind == 1) {
+        const DynPairMat S(q.Sw + t.k * SWS, t.vel);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t.a[i] = S.a[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.b[i] = S.b[i];
+    } else if (t.kind == 2 && !t.meas) {
+        const VoOrBiasMat S(q.Sc + t.k * 6, q.Sw + t.k * SWS + 21, vo);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t.a[i] = S.p[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t.a[i] = sp[i];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int r = t.r0 + j, sv = t.sv0 + j;
+        const double d = q.D[sv];
+        t.e[j] = q.E[r];
+        t.c2[j] = d * t.e[j];
+        t.cf[j] = q.cf[r];
+        t.lo[j] = q.lo[r];
+        t.hi[j] = (t.kind == 2 && vo) ? q.hi[r - q.ix.rvb] : t.lo[j];  // an equality block on the generic path: hi = lo
+        t.t[j] = q.zt[r];
+        t.xs[j] = q.x[sv];
+        t.z[j] = q.z[r];
+        t.y[j] = q.y[r];
+    }
+}
+template <class Q>
+DEKF_FN void row_regs_store(Q& q, const RowRegs& t) {
+    if (t.kind < 0) return;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int r = t.r0 + j, sv = t.sv0 + j;
+        q.zt[r] = t.t[j];
+        q.x[sv] = t.xs[j];
+        q.z[r] = t.z[j];
+        q.y[r] = t.y[j];
+    }
+}
+// one iteration of a row block: the arithmetic of row_block_compute, operand for operand, with the state in registers
+template <class Q>
+DEKF_FN void row_regs_iter(Q& q, RowRegs& t, double alpha, double sigma) {
+    if (t.kind < 0) return;
+    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double* xk = q.xd + 9 * t.k;
+    double ar[3], Rk[9];
+    if (t.kind == 1) {
+        const double* R = q.R + 9 * t.k;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rk[i] = R[i];
+        const bool vel = t.vel;
+        const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
+        const int o = vel ? 3 : 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const double rb = Rk[3 * a] * xk[6] + Rk[3 * a + 1] * xk[7] + Rk[3 * a + 2] * xk[8];
+            ar[a] = t.e[a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+        }
+    } else if (t.kind == 0 || t.meas) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ar[a] = t.e[a] * xk[3 + a];
+    } else {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) ar[a] = t.e[a] * (xk[t.xo + a] - xk[9 + t.xo + a]);
+    }
+    const bool eq = t.kind != 2;
+    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+    double v[3], sl[3], un[3], rhs[3], tn[3], wo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) v[j] = t.cf[j] * ar[j];
+    t.apply(v, sl);
+    const double rv_blk = eq ? rho_eq : q.rho_of(t.lo[0], t.hi[0]);
+    const double rinv_blk = eq ? 0.0 : rcp_fast(rv_blk);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double sj = t.t[j] + sl[j];
+        const double ztn = ar[j] - t.c2[j] * sj;
+        const double xn = alpha * sj + (1.0 - alpha) * t.xs[j];
+        const double zh = alpha * ztn + (1.0 - alpha) * t.z[j];
+        const double zn = eq ? t.lo[j] : dmin(dmax(zh + rinv_blk * t.y[j], t.lo[j]), t.hi[j]);
+        const double yn = t.y[j] + rv_blk * (zh - zn);
+        un[j] = rv_blk * zn - yn;
+        rhs[j] = sigma * xn - t.c2[j] * un[j];
+        t.xs[j] = xn;
+        t.z[j] = zn;
+        t.y[j] = yn;
+    }
+    t.apply(rhs, tn);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t.t[j] = tn[j];
+        wo[j] = t.e[j] * (un[j] + t.cf[j] * tn[j]);
+        q.at[t.r0 + j] = wo[j];
+    }
+    if (t.kind == 1) {
+        double u[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double pw = pair_swap(wo[r]);
+            u[r] = t.vel ? hdt2 * pw + dt * wo[r] : hdt2 * wo[r] + dt * pw;
+        }
+        if (!t.vel) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) q.gb[3 * t.k + a] = Rk[a] * u[0] + Rk[3 + a] * u[1] + Rk[6 + a] * u[2];
+        }
+    }
+}
+// x-column tile `kind` (0 position, 1 velocity, 2 bias) on the compact x blocks
+template <class Q>
+DEKF_FN void xcols_tile_r3(Q& q, int kind, int lane, double sigma) {
+    const int K = q.K;
+    if (lane >= 3 * K) return;
+    const double* qsl = q.tmp + TmpMap<9>::QSL;
+    const double* at = q.at;
+    auto w = [&](int r) { return at[r]; };
+    const int k = lane / 3, a = lane - 3 * k, j = 3 * kind + a, i = 9 * k + j;
+    const double xv = q.xb[i], dv = q.Db[i], qv = qsl[j];
+    double g;
+    if (kind == 0) g = gather_pcol(q, k, a, w);
+    else if (kind == 1) g = gather_vcol(q, k, a, w);
+    else {
+        const bool hn = k < K - 1, hp = k > 0;
+        const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
+        const double n0 = w(q.ix.rd(kn, 6 + a)), n1 = q.gb[3 * kn + a], p0 = w(q.ix.rd(kp, 6 + a));
+        g = (hn ? n0 - n1 : 0.0) - (hp ? p0 : 0.0);
+    }
+    q.xs[i] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
+}
+template <int NF, class Q>
+DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
+    constexpr int L = Q::LEGS, SV = 21 + 3 * L;
+    static_assert(3 * NF <= 64 && 2 * (NF - 1) <= 64, "one tile per kind");
+    static_assert(NF * L <= 64 || (NF * L - 64) + 2 * (NF - 1) <= 64, "the Meas blocks beyond 64 fit the VO / bias wavefront");
+    const int w = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), lane = DEKF_LANE() & 63;
+    // x blocks of the slab copy -> LDS (the restart / cold start / previous chunk left them there)
+    wfor(9 * NF, [&](int e) { const int k = e / 9; q.xb[e] = q.x[k * SV + e - 9 * k]; });
+    if (w == 0) {
+        for (int it = 0; it < iters; ++it) {
+            DEKF_SYNC();  // B1
+            __builtin_amdgcn_s_setprio(3);
+            sweeps_one_wave<NF>(q, alpha);
+            __builtin_amdgcn_s_setprio(0);
+            DEKF_SYNC();  // B2
+            DEKF_SYNC();  // B3
+        }
+    } else {
+        RowRegs t;
+        row_regs_load(q, w, lane, t);
+        const int xkind = w == 1 ? 1 : (w == 2 ? 2 : 0);  // velocity columns (the longest gather) next to the shortest row tile
+        for (int it = 0; it < iters; ++it) {
+            xcols_tile_r3(q, xkind, lane, sigma);
+            DEKF_SYNC();  // B1
+            DEKF_SYNC();  // B2
+            if (w == 2) __builtin_amdgcn_s_setprio(2);
+            row_regs_iter(q, t, alpha, sigma);
+            if (w == 2) __builtin_amdgcn_s_setprio(0);
+            DEKF_SYNC();  // B3
+        }
+        row_regs_store(q, t);
+    }
+    DEKF_SYNC();
+    wfor(9 * NF, [&](int e) { const int k = e / 9; q.x[k * SV + e - 9 * k] = q.xb[e]; });
 }
 #endif
 

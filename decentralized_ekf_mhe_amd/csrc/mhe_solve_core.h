@@ -98,6 +98,17 @@ struct SolveLayout {
     DEKF_HD bool factor_in_lds() const { return (size_t)(vec + resident) * 8 <= 80 * 1024; }
     // the factor-time product P A_dyn can alias the (then dead) xt|zt|at vectors when they are big enough
     DEKF_HD bool pa_in_lds() const { return factor_in_lds() && (n_pad + 2 * m_pad >= (K - 1) * ns * ns); }
+    // Three-workgroup placement (R3, fixed-horizon kernels with the full window only): the row phase keeps its state and its
+    // constants in REGISTERS for a whole chunk of iterations, so LDS holds only what crosses lanes:
+    //   R | xb Db (x blocks, compact) | [at xs xd gb + pad] = factor-time PA | tmp | Sinv | Wk
+    DEKF_HD int r3_pa_region() const { int a = m_pad + 2 * ns * K + 3 * K, b = (K - 1) * ns * ns; return a > b ? a : b; }
+    DEKF_HD int r3_doubles() const { return 9 * K + 2 * ns * K + r3_pa_region() + solve_tmp_len(ns) + 2 * K * ns * ns; }
+    DEKF_HD size_t r3_lds_bytes() const { return (size_t)r3_doubles() * 8; }
+    // the Ruiz passes run in LDS before any of the above is live: D E Dn in front of Sinv, Pst | pc | En inside Sinv | Wk
+    DEKF_HD bool r3_fits(int L) const {
+        const int front = r3_doubles() - 2 * K * ns * ns - 9 * K, ps = K * (6 * L + 27) + ns * (ns + 1) / 2;
+        return 2 * n_pad + m_pad <= front && ps + n_pad + m_pad <= 2 * K * ns * ns && 3 * r3_lds_bytes() + 3 * 1024 <= 160 * 1024;
+    }
     DEKF_HD size_t lds_bytes() const { return (size_t)(factor_in_lds() ? vec + resident : vec) * 8; }
 };
 
@@ -122,8 +133,9 @@ struct IdxT {
     DEKF_FN int rv(int k, int a) const { return rvb + 3 * k + a; }
 };
 
-template <int L, int NF = 0, bool FLDS = true, int FT = 0>
+template <int L, int NF = 0, bool FLDS = true, int FT = 0, bool R3_ = false>
 struct SolveCtx {
+    static constexpr bool R3 = R3_;  // three workgroups per CU: row state in registers, x blocks compact in LDS (xb, Db)
     static constexpr int LEGS = L;
     static constexpr int NFIXED = NF;  // != 0: horizon known at compile time (sweeps fully unrolled when K == NF)
     static constexpr bool FACTOR_LDS = FLDS;  // false: W_k streams from the HBM slab (deeper operand prefetch in the sweeps)
@@ -135,6 +147,7 @@ struct SolveCtx {
     IdxT<L, FT> ix;
     // LDS always
     double *x, *z, *y, *xt, *zt, *at, *xs, *xd, *tmp;
+    double *xb, *Db;  // R3: the x blocks of x and of D, [K][NS], the only part of them an iteration shares between lanes
     double* cf;  // per row rho E D (aliases xt, which only the factorisation uses otherwise)
     double* gb;  // per step R' (dt^2/2 w_p + dt w_v): the Dyn rows' contribution to the bias columns (tail of xt)
     // LDS or HBM scratch
@@ -221,7 +234,7 @@ DEKF_FN void solve_scale(Q& q) {
     constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, SV = 2 * NS + 3 + NM, PS = 6 * L + 27 + 6 * L * FT;
     const int n = q.n, m = q.m, K = q.K, K1 = q.K - 1, nmeas = K * L;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-    double *D = q.D, *E = q.E, *Pst = q.Pst, *pc = q.x, *Dn = q.xt, *En = q.zt;
+    double *D = q.D, *E = q.E, *Pst = q.Pst, *pc = q.x, *Dn = q.xt, *En = q.zt;  // (R3: the caller points all of these at LDS)
     const double* g = q.np;
     const auto& ix = q.ix;
     stage_p(q);
@@ -1073,7 +1086,7 @@ struct SolveInfo {
 // osqp_setup + osqp_solve + extraction.  window = steps kstart .. kstart+K-1 (newest = T).
 // FACTOR_LDS / PA_LDS are compile-time so that every pointer has a provable address space
 // (ds_read/ds_write instead of flat_load) — see SolveLayout::factor_in_lds / pa_in_lds.
-template <int L, bool FACTOR_LDS, bool PA_LDS, int NFIX = 0, int FT = 0>
+template <int L, bool FACTOR_LDS, bool PA_LDS, int NFIX = 0, int FT = 0, bool R3 = false>
 DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, double* lds, double* gws) {
     // NFIX != 0: the horizon is a compile-time constant, so every LDS array sits at a constant offset
     // (folded into the ds_read/ds_write immediates instead of living in scalar registers)
@@ -1084,9 +1097,34 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     lay.init(NH, L, FT);
     Gws g;
     g.init(NH, L, FT);
-    SolveCtx<L, NFIX, FACTOR_LDS, FT> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
+    SolveCtx<L, NFIX, FACTOR_LDS, FT, R3> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
+    q.xb = nullptr;
+    q.Db = nullptr;
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
         double* p = lds;
+        if constexpr (R3) {
+            static_assert(!R3 || (FACTOR_LDS && PA_LDS && NFIX != 0 && FT == 0), "R3: fixed horizon, 9 states, factor in LDS");
+            q.R = p; p += 9 * NH;
+            q.xb = p; p += NS * NH;
+            q.Db = p; p += NS * NH;
+            q.PA = p;  // at | xs | xd | gb are dead while a factorisation runs
+            q.at = p;
+            q.xs = p + lay.m_pad;
+            q.xd = q.xs + NS * NH;
+            q.gb = q.xd + NS * NH;
+            p += lay.r3_pa_region();
+            q.tmp = p; p += TM::LEN;
+            q.Sinv = p; p += NH * NS2;
+            q.Wk = p; p += NH * NS2;
+            q.Sf = nullptr; q.Wf = nullptr;
+            // everything a lane keeps to itself between iterations lives in the workgroup's HBM slab while it is not in registers
+            q.x = gws + g.x; q.z = gws + g.z; q.y = gws + g.y; q.zt = gws + g.zt; q.cf = gws + g.cf;
+            q.xt = nullptr;
+            q.D = gws + g.D; q.E = gws + g.E; q.lo = gws + g.lo; q.hi = gws + g.hi;
+            q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc;
+            q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
+        }
+        if constexpr (!R3) {
         q.x = p; p += lay.n_pad;
         q.z = p; p += lay.m_pad;
         q.y = p; p += lay.m_pad;
@@ -1122,6 +1160,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         if constexpr (FT) q.Wf = gws + g.Wf;
         if constexpr (PA_LDS) q.PA = q.xt;
         else q.PA = gws + g.PA;
+        }
     }
     q.n = (K - 1) * IdxT<L, FT>::SV + NS + IdxT<L, FT>::nm;
     q.m = (K - 1) * IdxT<L, FT>::SC + IdxT<L, FT>::nm;
@@ -1142,8 +1181,27 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         for (int i = 0; i < 16; ++i) q.prof[i] = 0.0;
 #endif
     wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });
+    if constexpr (R3) {
+        // The Ruiz passes need their vectors in LDS (ten passes of neighbour look-ups); none of the iteration's arrays is live
+        // yet, so D, E, Dn sit in front of S^-1 and pc, En behind the staged P blocks inside S^-1 | W.  Then D, E move to the slab.
+        constexpr int PSL = NFIX * (6 * L + 27) + NS * (NS + 1) / 2;
+        double *Dg = q.D, *Eg = q.E, *xg = q.x, *ztg = q.zt;
+        q.D = q.xb;
+        q.E = q.D + lay.n_pad;
+        q.xt = q.E + lay.m_pad;          // Dn
+        q.x = q.Sinv + PSL;              // pc
+        q.zt = q.x + lay.n_pad;          // En
+        if (c.scaling > 0) solve_scale(q);
+        else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
+        const double *Dl = q.D, *El = q.E;
+        wfor_nosync(n + m, [&](int e) { if (e < n) Dg[e] = Dl[e]; else Eg[e - n] = El[e - n]; });
+        DEKF_SYNC();  // (release fence + barrier: the copies are read back by other lanes below)
+        q.D = Dg; q.E = Eg; q.x = xg; q.zt = ztg; q.xt = nullptr;
+        wfor(K * NS, [&](int e) { int k = e / NS, j = e - NS * k; q.Db[e] = Dg[ix.x(k, j)]; q.xb[e] = 0.0; });
+    } else {
     if (c.scaling > 0) solve_scale(q);
     else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
+    }
     DEKF_PROF_MARK(q, 0);
     q.rho = dmin(dmax(c.rho0, RHO_MIN), RHO_MAX);
     // scaled bounds, cold start
@@ -1170,11 +1228,25 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     if (ok) phase_rows<true>(q, alpha, sigma);  // cold start: cf, t = 0, w = 0 (the factorisation scratch aliased xt | zt | at)
     DEKF_PROF_MARK(q, 1);
     while (ok && !done && iter < c.max_iter) {
+#if DEKF_DEVICE_BUILD
+        if constexpr (R3) {
+            // every iteration up to the next event (termination check, rho adaptation, iteration cap) in one call: the row
+            // phase's state stays in registers in between (mhe_admm_core.h: admm_chunk_r3)
+            int nxt = c.max_iter;
+            if (c.check_termination > 0) { const int e = (iter / c.check_termination + 1) * c.check_termination; nxt = e < nxt ? e : nxt; }
+            if (c.adaptive_rho && c.adaptive_rho_interval > 0) { const int e = (iter / c.adaptive_rho_interval + 1) * c.adaptive_rho_interval; nxt = e < nxt ? e : nxt; }
+            admm_chunk_r3<NFIX>(q, nxt - iter, alpha, sigma);
+            iter = nxt;
+            DEKF_PROF_MARK(q, 9);
+        } else
+#endif
+        {
         ++iter;
         phase_xcols(q, sigma);
         DEKF_PROF_MARK(q, 2);
         phase_sweeps_rows(q, alpha, sigma);
         DEKF_PROF_MARK(q, 9);
+        }
         bool can_check = c.check_termination > 0 && (iter % c.check_termination == 0);
         bool adapt_now = c.adaptive_rho && c.adaptive_rho_interval > 0 && (iter % c.adaptive_rho_interval == 0);
         if (can_check || adapt_now || iter == c.max_iter) {
