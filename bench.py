@@ -280,6 +280,7 @@ def run_bench(args, env, rank, world):
                          "flops_per_step": fl["total"], "flops_per_admm_iteration": fl["per_iteration"],
                          "flop_peak_tflops": FP64_VECTOR_TFLOPS,
                          "flop_frac": fl["total"] * per_gpu_rate / (FP64_VECTOR_TFLOPS * 1e12),
+                         "solve_workgroups": li["solve_workgroups"], "workgroups_per_cu": li["solve_workgroups"] / max(li["compute_units"], 1),
                          "chain_floor_cycles_per_solve": chain_floor, "measured_cycles_per_solve": cycles_per_solve,
                          "chain_floor_frac": chain_floor / cycles_per_solve if cycles_per_solve > 0 else None},
             "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items()},

@@ -78,13 +78,13 @@ extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) k_mhe_solve_
 // Full windows of the two fixed-horizon shapes: THREE workgroups per CU (mhe_admm_core.h, admm_chunk_r3: row state in registers,
 // 45 KiB of LDS per instance, 168 VGPRs).  The window-fill ticks (K < N) keep the two-workgroup kernels above.
 #ifndef DEKF_NO_R3
-extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 3) k_mhe_solve_r3_4_n20(DevCfg c, DevState s, int kstart, int K,
+extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_R3_WAVES) k_mhe_solve_r3_4_n20(DevCfg c, DevState s, int kstart, int K,
                                                                                    int gws_len) {
     extern __shared__ double lds[];
     double* gws = s.gws + (size_t)blockIdx.x * gws_len;
     for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<4, true, true, 20, 0, true>(c, s, b, kstart, K, lds, gws);
 }
-extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 3) k_mhe_solve_r3_2_n20(DevCfg c, DevState s, int kstart, int K,
+extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_R3_WAVES) k_mhe_solve_r3_2_n20(DevCfg c, DevState s, int kstart, int K,
                                                                                    int gws_len) {
     extern __shared__ double lds[];
     double* gws = s.gws + (size_t)blockIdx.x * gws_len;

@@ -28,6 +28,63 @@ DEKF_FN void kf_predict(const DevCfg& c, const DevState& s, int b, const double*
     double* xn = AC + n2;   // ns
     const double* R = r + Rec::R;
     const double dt = c.dt;
+    // G C_in G' (DecentralEst.cpp:742-751, 784), entry (i, j)
+    auto gcg = [&](int i, int j) -> double {
+        const int bi = i / 3, bj = j / 3, a = i % 3, d = j % 3;
+        auto rcr = [&](const double* cv) {
+            double v = 0;
+            for (int t = 0; t < 3; ++t) v += R[3 * a + t] * cv[t] * R[3 * d + t];
+            return v;
+        };
+        if (bi == 0 && bj == 0) return dt * dt * rcr(c.C_p) + 0.25 * dt * dt * dt * dt * rcr(c.C_accel);
+        if ((bi == 0 && bj == 1) || (bi == 1 && bj == 0)) return 0.5 * dt * dt * dt * rcr(c.C_accel);
+        if (bi == 1 && bj == 1) return dt * dt * rcr(c.C_accel);
+        if (bi == 2 && bj == 2 && a == d) return dt * dt * c.C_accel_bias[a];
+        if (bi >= 3 && bi == bj) return symget(r + Rec::qf(c.nm) + 6 * (bi - 3), a, d, 3);  // stored as dt^2 R C R'
+        return 0.0;
+    };
+#if DEKF_DEVICE_BUILD
+    if (ns == 9 && DEKF_NLANES() == 64) {
+        // The dense covariance contraction C <- A C A' on the matrix core (the one place of the path where it pays:
+        // tools/probes/cov_mfma_probe.hip, profiles/r02_cov_mfma_probe.txt — 0.70x the time of the LDS-staged form, 0.33x when
+        // ALU-bound; for the EKF's 4x4 the matrix core is 3-7x SLOWER than one lane per instance).  One v_mfma_f64_16x16x4_f64 tile
+        // holds the 9x9 blocks zero-padded; K = 9 -> three K chunks.  Operand maps: A-operand lane l = M[i = l & 15][k = l >> 4],
+        // B-operand lane l = M[k = l >> 4][j = l & 15], result lane l reg r = D[(l >> 4) + 4 r][l & 15]:
+        //   T = C A'   A-operand C[i][k],  B-operand A'[k][j] = A[j][k]      chunk c of T as a B-operand IS result register c
+        //   C' = A T   A-operand A[i][k],  B-operand T                       (the accumulator re-enters without a move)
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        const int l = DEKF_LANE(), lo = l & 15, hi = l >> 4;
+        double a_op[3], c_op[3];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const int k = 4 * ch + hi;
+            const bool in = lo < 9 && k < 9;
+            a_op[ch] = in ? adyn_entry(R, dt, lo, k) : 0.0;
+            c_op[ch] = in ? C[9 * (in ? lo : 0) + (in ? k : 0)] : 0.0;
+        }
+        double xnew = 0.0;
+        if (l < 9) {
+            double acc = 0;
+            for (int t = 0; t < 9; ++t) acc += adyn_entry(R, dt, l, t) * x[t];
+            const double bd = l < 3 ? -0.5 * dt * dt * r[Rec::AS + l] : (l < 6 ? -dt * r[Rec::AS + l - 3] : 0.0);
+            xnew = acc - bd;
+        }
+        v4d tt = {0.0, 0.0, 0.0, 0.0}, o = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) tt = __builtin_amdgcn_mfma_f64_16x16x4f64(c_op[ch], a_op[ch], tt, 0, 0, 0);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) o = __builtin_amdgcn_mfma_f64_16x16x4f64(a_op[ch], tt[ch], o, 0, 0, 0);
+        // every lane's operand loads completed before the first MFMA issued, so C and x can be overwritten in place
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr) {
+            const int row = hi + 4 * rr;
+            if (lo < 9 && row < 9) C[9 * row + lo] = o[rr] + gcg(row, lo);
+        }
+        if (l < 9) x[l] = xnew;
+        DEKF_SYNC();
+        return;
+    }
+#endif
     wfor(n2 + ns, [&](int e) {
         if (e < n2) A[e] = adyn_entry(R, dt, e / ns, e % ns);
         else {
@@ -44,19 +101,7 @@ DEKF_FN void kf_predict(const DevCfg& c, const DevState& s, int b, const double*
         int i = e / ns, j = e - ns * i;
         double acc = 0;
         for (int t = 0; t < ns; ++t) acc += AC[ns * i + t] * A[ns * j + t];
-        // G C_in G' (DecentralEst.cpp:742-751, 784)
-        int bi = i / 3, bj = j / 3, a = i % 3, d = j % 3;
-        auto rcr = [&](const double* cv) {
-            double v = 0;
-            for (int t = 0; t < 3; ++t) v += R[3 * a + t] * cv[t] * R[3 * d + t];
-            return v;
-        };
-        if (bi == 0 && bj == 0) acc += dt * dt * rcr(c.C_p) + 0.25 * dt * dt * dt * dt * rcr(c.C_accel);
-        else if ((bi == 0 && bj == 1) || (bi == 1 && bj == 0)) acc += 0.5 * dt * dt * dt * rcr(c.C_accel);
-        else if (bi == 1 && bj == 1) acc += dt * dt * rcr(c.C_accel);
-        else if (bi == 2 && bj == 2 && a == d) acc += dt * dt * c.C_accel_bias[a];
-        else if (bi >= 3 && bi == bj) acc += symget(r + Rec::qf(c.nm) + 6 * (bi - 3), a, d, 3);  // stored as dt^2 R C R'
-        C[e] = acc;
+        C[e] = acc + gcg(i, j);
     });
 }
 

@@ -1408,30 +1408,62 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
     const int w = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), lane = DEKF_LANE() & 63;
     // x blocks of the slab copy -> LDS (the restart / cold start / previous chunk left them there)
     wfor(9 * NF, [&](int e) { const int k = e / 9; q.xb[e] = q.x[k * SV + e - 9 * k]; });
+    // -DDEKF_PROFILE -DDEKF_PROFILE_TL: per-wavefront intervals, summed over the iterations (tools/profile_sections.py, DEKF_TIMELINE=1)
+    //   prof[w]: w0 the solve, workers the x-column tile | prof[4 + w]: w0 its wait from B2 to B1, workers the row tile |
+    //   prof[8 + w]: workers' wait for the solve (B1 to B2)
+#if defined(DEKF_PROFILE_TL)
+#define DEKF_R3_T(var) const long long var = clock64()
+#else
+#define DEKF_R3_T(var) ((void)0)
+#endif
     if (w == 0) {
         for (int it = 0; it < iters; ++it) {
+            DEKF_R3_T(t0);
             DEKF_SYNC();  // B1
+            DEKF_R3_T(t1);
             __builtin_amdgcn_s_setprio(3);
             sweeps_one_wave<NF>(q, alpha);
             __builtin_amdgcn_s_setprio(0);
+#if defined(DEKF_PROFILE_TL)
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            DEKF_R3_T(t2);
             DEKF_SYNC();  // B2
             DEKF_SYNC();  // B3
+            DEKF_R3_T(t3);
+            DEKF_TL_ADD(q, 0, t1, t2);
+            DEKF_TL_ADD(q, 4, t2, t3);
+            DEKF_TL_ADD(q, 8, t0, t1);
         }
     } else {
         RowRegs t;
         row_regs_load(q, w, lane, t);
         const int xkind = w == 1 ? 1 : (w == 2 ? 2 : 0);  // velocity columns (the longest gather) next to the shortest row tile
         for (int it = 0; it < iters; ++it) {
+            DEKF_R3_T(t0);
             xcols_tile_r3(q, xkind, lane, sigma);
+#if defined(DEKF_PROFILE_TL)
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            DEKF_R3_T(t1);
             DEKF_SYNC();  // B1
             DEKF_SYNC();  // B2
+            DEKF_R3_T(t2);
             if (w == 2) __builtin_amdgcn_s_setprio(2);
             row_regs_iter(q, t, alpha, sigma);
             if (w == 2) __builtin_amdgcn_s_setprio(0);
+#if defined(DEKF_PROFILE_TL)
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            DEKF_R3_T(t3);
             DEKF_SYNC();  // B3
+            DEKF_TL_ADD(q, w, t0, t1);
+            DEKF_TL_ADD(q, 4 + w, t2, t3);
+            DEKF_TL_ADD(q, 8 + w, t1, t2);
         }
         row_regs_store(q, t);
     }
+#undef DEKF_R3_T
     DEKF_SYNC();
     wfor(9 * NF, [&](int e) { const int k = e / 9; q.x[k * SV + e - 9 * k] = q.xb[e]; });
 }

@@ -101,13 +101,19 @@ struct SolveLayout {
     // Three-workgroup placement (R3, fixed-horizon kernels with the full window only): the row phase keeps its state and its
     // constants in REGISTERS for a whole chunk of iterations, so LDS holds only what crosses lanes:
     //   R | xb Db (x blocks, compact) | [at xs xd gb + pad] = factor-time PA | tmp | Sinv | Wk
-    DEKF_HD int r3_pa_region() const { int a = m_pad + 2 * ns * K + 3 * K, b = (K - 1) * ns * ns; return a > b ? a : b; }
+#ifndef DEKF_R3_WAVES
+#define DEKF_R3_WAVES 3     // resident workgroups per CU the R3 kernels are compiled for (launch bound: wavefronts per SIMD)
+#endif
+#ifndef DEKF_R3_PA_LDS
+#define DEKF_R3_PA_LDS 1    // 0: the factor-time product P A in the HBM slab (40 KiB of LDS per instance: a fourth workgroup fits)
+#endif
+    DEKF_HD int r3_pa_region() const { int a = m_pad + 2 * ns * K + 3 * K, b = DEKF_R3_PA_LDS ? (K - 1) * ns * ns : 0; return a > b ? a : b; }
     DEKF_HD int r3_doubles() const { return 9 * K + 2 * ns * K + r3_pa_region() + solve_tmp_len(ns) + 2 * K * ns * ns; }
     DEKF_HD size_t r3_lds_bytes() const { return (size_t)r3_doubles() * 8; }
-    // the Ruiz passes run in LDS before any of the above is live: D E Dn in front of Sinv, Pst | pc | En inside Sinv | Wk
+    // the Ruiz passes run in LDS before any of the above is live: D E in front of Sinv, Pst | pc | En | Dn inside Sinv | Wk
     DEKF_HD bool r3_fits(int L) const {
         const int front = r3_doubles() - 2 * K * ns * ns - 9 * K, ps = K * (6 * L + 27) + ns * (ns + 1) / 2;
-        return 2 * n_pad + m_pad <= front && ps + n_pad + m_pad <= 2 * K * ns * ns && 3 * r3_lds_bytes() + 3 * 1024 <= 160 * 1024;
+        return n_pad + m_pad <= front && ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && DEKF_R3_WAVES * (r3_lds_bytes() + 512) <= 160 * 1024;
     }
     DEKF_HD size_t lds_bytes() const { return (size_t)(factor_in_lds() ? vec + resident : vec) * 8; }
 };
@@ -441,6 +447,9 @@ DEKF_FN void solve_scale(Q& q) {
     };
     wtiles(ntiles, [&](int tile, int lane) { (void)adopt(tile, lane); });  // column norms of P for D = 1
     DEKF_SYNC();
+    double gq[NS];  // the linear cost sits in HBM: read it once, not once per pass (a global round trip each)
+#pragma unroll
+    for (int j = 0; j < NS; ++j) gq[j] = g[j];
     for (int it = 0; it < q.c.scaling; ++it) {
         const double cc = q.cc;
         wtiles(ntiles, [&](int tile, int lane) { equil(tile, lane, cc); });
@@ -452,7 +461,8 @@ DEKF_FN void solve_scale(Q& q) {
         psum *= cc;
         // ---- cost normalisation: mean column norm of the re-scaled P against |q|_inf
         double qn = 0.0;
-        for (int j = 0; j < NS; ++j) qn = dmax(qn, fabs(cc * D[j] * g[j]));
+#pragma unroll
+        for (int j = 0; j < NS; ++j) qn = dmax(qn, fabs(cc * D[j] * gq[j]));
         double ct = 1.0 / limit_scaling(dmax(psum / (double)n, limit_scaling(qn)));
         q.cc = cc * ct;
     }
@@ -1107,7 +1117,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
             q.R = p; p += 9 * NH;
             q.xb = p; p += NS * NH;
             q.Db = p; p += NS * NH;
-            q.PA = p;  // at | xs | xd | gb are dead while a factorisation runs
+            q.PA = DEKF_R3_PA_LDS ? p : gws + g.PA;  // at | xs | xd | gb are dead while a factorisation runs
             q.at = p;
             q.xs = p + lay.m_pad;
             q.xd = q.xs + NS * NH;
@@ -1183,14 +1193,14 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });
     if constexpr (R3) {
         // The Ruiz passes need their vectors in LDS (ten passes of neighbour look-ups); none of the iteration's arrays is live
-        // yet, so D, E, Dn sit in front of S^-1 and pc, En behind the staged P blocks inside S^-1 | W.  Then D, E move to the slab.
+        // yet, so D, E sit in front of S^-1 and pc, En, Dn behind the staged P blocks inside S^-1 | W.  Then D, E move to the slab.
         constexpr int PSL = NFIX * (6 * L + 27) + NS * (NS + 1) / 2;
         double *Dg = q.D, *Eg = q.E, *xg = q.x, *ztg = q.zt;
         q.D = q.xb;
         q.E = q.D + lay.n_pad;
-        q.xt = q.E + lay.m_pad;          // Dn
         q.x = q.Sinv + PSL;              // pc
         q.zt = q.x + lay.n_pad;          // En
+        q.xt = q.zt + lay.m_pad;         // Dn
         if (c.scaling > 0) solve_scale(q);
         else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
         const double *Dl = q.D, *El = q.E;

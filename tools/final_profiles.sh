@@ -6,6 +6,7 @@
 #   kernel_trace_timed.json       average of the 100 timed solve launches from the kernel trace
 #   sections.txt                  in-kernel section shares (needs csrc/libdekf_prof.so, see profile_sections.py)
 #   sq_counters.json, traffic.json  PMC passes (tools/collect_sq.sh, tools/collect_traffic.sh)
+#   mfma_k_kf_update.json         matrix-core counters of the KF kernel (tools/collect_mfma.sh)
 # usage (from the repo root on the GPU box):  bash tools/final_profiles.sh
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/final
@@ -25,7 +26,7 @@ if tr:
     rows = list(csv.DictReader(open(tr[0])))
     def dur(name):
         return [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in rows if r["Kernel_Name"].startswith(name)]
-    solve_name = next(r["Kernel_Name"] for r in rows if r["Kernel_Name"].startswith("k_mhe_solve"))
+    solve_name = [r["Kernel_Name"] for r in rows if r["Kernel_Name"].startswith("k_mhe_solve")][-1]
     sv, asm = dur("k_mhe_solve"), dur("k_mhe_assemble")
     res = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 100 --warmup 30 --no-cpu-baseline",
            "kernel": solve_name, "launches_total": len(sv), "avg_ms_all_launches": sum(sv) / len(sv),
@@ -40,6 +41,7 @@ if [ -f decentralized_ekf_mhe_amd/csrc/libdekf_prof.so ]; then
 fi
 bash tools/collect_sq.sh > $OUT/sq_stdout.log 2>&1; cp gpurun_out/sq_k_mhe_solve.json $OUT/sq_counters.json 2>/dev/null
 bash tools/collect_traffic.sh > $OUT/traffic_stdout.log 2>&1; cp gpurun_out/traffic_k_mhe_solve.json $OUT/traffic.json 2>/dev/null
+bash tools/collect_mfma.sh > $OUT/mfma_stdout.log 2>&1; cp gpurun_out/mfma_k_kf_update.json $OUT/mfma_k_kf_update.json 2>/dev/null
 timeout 900 python3 tools/stress_parity.py > $OUT/stress_parity.jsonl 2> $OUT/stress.err
 timeout 900 python3 tools/bench_shapes.py > $OUT/bench_shapes.jsonl 2> $OUT/shapes.err
 ls -la $OUT
