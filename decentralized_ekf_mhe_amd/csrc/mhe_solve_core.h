@@ -1172,6 +1172,18 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         else q.PA = gws + g.PA;
         }
     }
+    if constexpr (FACTOR_LDS) {
+        // The factor-time row weights W_m, W_d, W_c [, W_f] (written by step 3a, read by 3b-3c of solve_factor) live in the W array,
+        // which stays dead until the block LDL' (3d) writes it; the staged P blocks they are computed from sit in front of it, inside
+        // S^-1.  (They used to make a round trip through the HBM slab per factorisation: most of the kernel's excess traffic.)
+        constexpr int PSL = 6 * L + 27 + 6 * L * FT, WLEN = 6 * L + 30 + 6 * L * FT;
+        if (NH * PSL + NS * (NS + 1) / 2 <= NH * NS2 && NH * WLEN <= NH * NS2) {
+            q.Wm = q.Wk;
+            q.Wd = q.Wm + NH * 6 * L;
+            q.Wc = q.Wd + NH * 24;
+            if constexpr (FT) q.Wf = q.Wc + NH * 6;
+        }
+    }
     q.n = (K - 1) * IdxT<L, FT>::SV + NS + IdxT<L, FT>::nm;
     q.m = (K - 1) * IdxT<L, FT>::SC + IdxT<L, FT>::nm;
     q.Mp = s.Mp + (size_t)NS2 * b;
