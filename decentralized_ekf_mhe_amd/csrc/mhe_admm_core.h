@@ -1216,9 +1216,9 @@ struct RowRegs {
     int k, r0, sv0;
     bool vel, meas;  // kind 1: velocity half; kind 2: a Meas block folded into the VO / bias tile
     int xo;          // kind 2: offset of the block's x entries inside a step (0 VO, 6 bias, 3 Meas)
-    double e[3], c2[3], cf[3], lo[3], hi[3];
+    double e[3], c2[3], cf[3], lo[3];
     double t[3], xs[3], z[3], y[3];
-    double a[6], b[9];
+    double a[6], b[9];  // slack-block inverse: own part, coupling to the partner lane (kind 1); kind 2: b[0..2] = upper bounds
     DEKF_FN void apply(const double* in, double* out) const {
         double pin[3] = {0.0, 0.0, 0.0};
         if (kind == 1) {
@@ -1292,7 +1292,7 @@ DEKF_FN void row_regs_load(const Q& q, int w, int lane, RowRegs& t) {
         t.c2[j] = d * t.e[j];
         t.cf[j] = q.cf[r];
         t.lo[j] = q.lo[r];
-        t.hi[j] = (t.kind == 2 && vo) ? q.hi[r - q.ix.rvb] : t.lo[j];  // an equality block on the generic path: hi = lo
+        if (t.kind == 2) t.b[j] = vo ? q.hi[r - q.ix.rvb] : t.lo[j];  // an equality block on the generic path: hi = lo
         t.t[j] = q.zt[r];
         t.xs[j] = q.x[sv];
         t.z[j] = q.z[r];
@@ -1343,7 +1343,7 @@ DEKF_FN void row_regs_iter(Q& q, RowRegs& t, double alpha, double sigma) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) v[j] = t.cf[j] * ar[j];
     t.apply(v, sl);
-    const double rv_blk = eq ? rho_eq : q.rho_of(t.lo[0], t.hi[0]);
+    const double rv_blk = eq ? rho_eq : q.rho_of(t.lo[0], t.b[0]);
     const double rinv_blk = eq ? 0.0 : rcp_fast(rv_blk);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -1351,7 +1351,7 @@ DEKF_FN void row_regs_iter(Q& q, RowRegs& t, double alpha, double sigma) {
         const double ztn = ar[j] - t.c2[j] * sj;
         const double xn = alpha * sj + (1.0 - alpha) * t.xs[j];
         const double zh = alpha * ztn + (1.0 - alpha) * t.z[j];
-        const double zn = eq ? t.lo[j] : dmin(dmax(zh + rinv_blk * t.y[j], t.lo[j]), t.hi[j]);
+        const double zn = eq ? t.lo[j] : dmin(dmax(zh + rinv_blk * t.y[j], t.lo[j]), t.b[j]);
         const double yn = t.y[j] + rv_blk * (zh - zn);
         un[j] = rv_blk * zn - yn;
         rhs[j] = sigma * xn - t.c2[j] * un[j];
