@@ -459,6 +459,127 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
         }
     }
 }
+
+// The same one-wavefront, four-row solve for a RUN-TIME (even) window length: the steps are loops, the operands of the next
+// RING - 1 steps are in flight in a ring of register sets (the compiler waits for everything outstanding at a loop back-edge, so
+// one load latency is exposed per RING steps).  Used by the generic instantiations — PogoX's 100-step window, whose factor
+// streams from the HBM slab (DEKF_GG_RING sets), other horizons, the window-fill ticks — instead of the three-phase two-wavefront
+// form (legs | g + meeting block | legs): no barrier inside, the g streams ride along for free.
+template <class Q>
+DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
+    constexpr int SV = 21 + 3 * Q::LEGS;
+    constexpr int RING = Q::FACTOR_LDS ? 4 : DEKF_GG_RING;
+    const int K = q.K, M = mid_block(K), NOUT = K - 1 - M;  // K even: K - 2 - M == M, both forward legs M steps
+    const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15;
+    const int i = li < 9 ? li : 8;
+    const bool act = li < 9, leg = row < 2, top = (row & 1) == 0;
+    double *xs = q.xs, *xd = q.xd, *x = q.x;
+    struct Ops { double w[9], rhs; };
+    // ---------------- forward: step s = 1..M
+    const double* fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
+    const int fstep = top ? 81 : -81;
+    q.tmp[260 + lane] = 0.0;  // a zero the rows without a right-hand side can load
+    const int rstep = top ? 9 : -9;
+    const double* fr = leg ? xs + (top ? 9 : 9 * (K - 2)) + i : q.tmp + 260 + lane;
+    const int frstep = leg ? rstep : 0;
+    double* dummy = q.tmp + 176 + lane;
+    const bool gown = !leg && act;
+    double* gst = gown ? xd + (top ? 0 : 9 * (K - 1)) + i : dummy;  // where rows 2, 3 put -g of step 1
+    const int gstep = gown ? rstep : 0;
+    auto fload = [&](int s, Ops& o) {
+        const double* W = fm + (s - 1) * fstep;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o.w[t] = W[t];
+        o.rhs = fr[(s - 1) * frstep];
+    };
+    double v = xs[(top ? 0 : 9 * (K - 1)) + i];  // f_0 = b_0 / f^_{K-1} = b_{K-1}
+    {
+        Ops r[RING];
+        auto fstepf = [&](const Ops& c, Ops& n, int s, int ahead) {
+            if (s + ahead <= M) fload(s + ahead, n);
+            const double src = rows23_from_rows01(v);
+            const double res = chain_matvec_dpp(src, c.w, c.rhs);
+            v = res;
+            gst[(s - 1) * gstep] = res;
+        };
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)
+            if (M >= u + 1) fload(u + 1, r[u]);
+        int s = 1;
+        for (; s + RING - 1 <= M; s += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) fstepf(r[u], r[(u + RING - 1) % RING], s + u, RING - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)
+            if (s + u <= M) fstepf(r[u], r[RING - 1], s + u, RING);
+    }
+    // ---------------- meeting block (row 0) and the last g of the bottom half (row 3)
+    {
+        double w[9];
+        const double* W = row == 0 ? q.Wk + M * 81 + 9 * i : q.Sinv + (M + 1) * 81 + 9 * i;
+        const double z = (row == 0 || row == 3) ? 1.0 : 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) w[t] = z * W[t];
+        double s9[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) s9[t] = q.Sinv[M * 81 + 9 * i + t];
+        const double dm = q.D[M * SV + i], xm = x[M * SV + i];
+        const double src = all_rows_from_row1(v);                 // f^_{M+1} everywhere
+        const double res = chain_matvec_dpp(src, w, row == 0 ? v : 0.0);
+        if (row == 3 && act) xd[9 * (M + 1) + i] = res;            // -g_{M+1}
+        const double um = -chain_matvec_dpp(res, s9, 0.0);         // row 0: S_M^-1 (f_M - W^_M f^_{M+1})
+        if (row == 0 && act) {
+            xd[9 * M + i] = dm * um;
+            x[M * SV + i] = alpha * um + (1.0 - alpha) * xm;
+        }
+        v = row1_from_row0(um);                                    // rows 0 and 1 start from u_M
+    }
+    // ---------------- outward: step s = 1..NOUT, row 0 block M - s (s <= M), row 1 block M + s
+    {
+        struct Bops { double w[9], ng, dsc, xo; };
+        const bool own = leg && act;
+        double* xdp = own ? xd + 9 * M + i : dummy;
+        double* xp = own ? x + M * SV + i : dummy;
+        const double* Dp = q.D + (own ? M * SV + i : 0);     // (D may sit in HBM: no LDS dummy here, idle lanes re-read D[0])
+        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -SV : SV) : 0;
+        const double* Wp = q.Wk + (top ? M : M - 1) * 81 + i;  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
+        const int wstep = top ? -81 : 81;
+        auto bload = [&](int s, Bops& o) {
+            const int sl = s <= M ? s : (top ? M : s);  // row 0 has one step less: its last load repeats block 0
+            const double* W = Wp + sl * wstep;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
+            o.ng = xdp[sl * xdstep];
+            o.dsc = Dp[sl * xstep];
+            o.xo = xp[sl * xstep];
+        };
+        Bops r[RING];
+        auto bstepf = [&](const Bops& c, Bops& n, int s, int ahead) {
+            if (s + ahead <= NOUT) bload(s + ahead, n);
+            const double res = chain_matvec_dpp(v, c.w, -c.ng);
+            v = res;
+            if (s <= M) {
+                xdp[s * xdstep] = c.dsc * res;
+                xp[s * xstep] = alpha * res + (1.0 - alpha) * c.xo;
+            } else if (!top && own) {  // the bottom leg is one block longer
+                xdp[s * xdstep] = c.dsc * res;
+                xp[s * xstep] = alpha * res + (1.0 - alpha) * c.xo;
+            }
+        };
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)
+            if (NOUT >= u + 1) bload(u + 1, r[u]);
+        int s = 1;
+        for (; s + RING - 1 <= NOUT; s += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) bstepf(r[u], r[(u + RING - 1) % RING], s + u, RING - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)
+            if (s + u <= NOUT) bstepf(r[u], r[RING - 1], s + u, RING);
+    }
+}
 #endif
 
 // ---------------------------------------------------------------- S for state blocks wider than a DPP row
@@ -716,6 +837,16 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
             DEKF_PROF_MARK(q, 5);
             return;
         }
+    }
+    if (K >= 4 && (K & 1) == 0) {  // even run-time window: one wavefront, four rows, no barrier inside
+        if (__builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6) == 0) {
+            __builtin_amdgcn_s_setprio(3);
+            sweeps_one_wave_rt(q, alpha);
+            __builtin_amdgcn_s_setprio(0);
+        }
+        DEKF_SYNC();
+        DEKF_PROF_MARK(q, 5);
+        return;
     }
     __builtin_amdgcn_s_setprio(3);  // the legs are the critical path and share their SIMDs
 #endif
