@@ -37,7 +37,7 @@ FP64_VECTOR_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector peak (the path com
 # dependent-issue floor of one 9x9 chain step: nine v_fmac_f64_dpp, each occupying its SIMD for 16 cycles
 # (quarter-rate DPP f64), back to back on one wavefront (tools/probes/dpp_chain_probe.hip)
 CHAIN_STEP_FLOOR_CYCLES = 9 * 16
-TRAFFIC_FILE = os.path.join("profiles", "traffic_k_mhe_solve.json")
+TRAFFIC_FILE = os.path.join("profiles", "r02_traffic_k_mhe_solve.json")  # refreshed by tools/final_profiles.sh for the kernel of this round
 
 
 def measured_traffic():
