@@ -1372,8 +1372,12 @@ struct RowRegs {
 // Tiles: wavefront 1 the first 64 Meas leg blocks, wavefront 2 the Dyn lane pairs, wavefront 3 the VO and bias blocks plus the
 // Meas blocks beyond 64 (Go1: 16) on the generic projection path — for an equality block that path gives bit-identical results
 // (hi = lo: the clamp returns lo, rho_of returns rho_eq).
+// Loading a block IS the restart after a (re)factorisation (row_block_restart: rho E D, t = S^-1 (sigma x_s - E D u),
+// w = E (u + rho E D t) from x_s, z, y and the block's new inverse) — the same expressions, so t and w also come out as the last
+// iteration left them when a chunk merely continues after a termination check.  Neither t nor rho E D ever go to the slab, and
+// the three-workgroup kernels run no separate restart phase.  Writes w (and gb) to LDS: a workgroup barrier follows.
 template <class Q>
-DEKF_FN void row_regs_load(const Q& q, int w, int lane, RowRegs& t) {
+DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
     constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     t.kind = -1; t.k = 0; t.r0 = 0; t.sv0 = 0; t.vel = false; t.meas = false; t.xo = 0;
@@ -1415,19 +1419,49 @@ DEKF_FN void row_regs_load(const Q& q, int w, int lane, RowRegs& t) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) t.a[i] = sp[i];
     }
+    double dd[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int r = t.r0 + j, sv = t.sv0 + j;
         const double d = q.D[sv];
         t.e[j] = q.E[r];
         t.c2[j] = d * t.e[j];
-        t.cf[j] = q.cf[r];
         t.lo[j] = q.lo[r];
         if (t.kind == 2) t.b[j] = vo ? q.hi[r - q.ix.rvb] : t.lo[j];  // an equality block on the generic path: hi = lo
-        t.t[j] = q.zt[r];
         t.xs[j] = q.x[sv];
         t.z[j] = q.z[r];
         t.y[j] = q.y[r];
+        dd[j] = d;
+    }
+    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+    double un[3], rhs[3], tn[3], wo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const double rv = t.kind != 2 ? rho_eq : q.rho_of(t.lo[j], t.b[j]);
+        t.cf[j] = rv * t.e[j] * dd[j];
+        un[j] = rv * t.z[j] - t.y[j];
+        rhs[j] = sigma * t.xs[j] - t.e[j] * dd[j] * un[j];
+    }
+    t.apply(rhs, tn);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        t.t[j] = tn[j];
+        wo[j] = t.e[j] * (un[j] + t.cf[j] * tn[j]);
+        q.at[t.r0 + j] = wo[j];
+    }
+    if (t.kind == 1) {
+        const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+        const double* R = q.R + 9 * t.k;
+        double u[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const double pw = pair_swap(wo[r]);
+            u[r] = t.vel ? hdt2 * pw + dt * wo[r] : hdt2 * wo[r] + dt * pw;
+        }
+        if (!t.vel) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) q.gb[3 * t.k + a] = R[a] * u[0] + R[3 + a] * u[1] + R[6 + a] * u[2];
+        }
     }
 }
 template <class Q>
@@ -1436,7 +1470,6 @@ DEKF_FN void row_regs_store(Q& q, const RowRegs& t) {
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int r = t.r0 + j, sv = t.sv0 + j;
-        q.zt[r] = t.t[j];
         q.x[sv] = t.xs[j];
         q.z[r] = t.z[j];
         q.y[r] = t.y[j];
@@ -1548,6 +1581,7 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
 #define DEKF_R3_T(var) ((void)0)
 #endif
     if (w == 0) {
+        DEKF_SYNC();  // B0: w, gb of the (re)start complete
         for (int it = 0; it < iters; ++it) {
             DEKF_R3_T(t0);
             DEKF_SYNC();  // B1
@@ -1568,7 +1602,8 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
         }
     } else {
         RowRegs t;
-        row_regs_load(q, w, lane, t);
+        row_regs_load(q, w, lane, sigma, t);
+        DEKF_SYNC();  // B0
         const int xkind = w == 1 ? 1 : (w == 2 ? 2 : 0);  // velocity columns (the longest gather) next to the shortest row tile
         for (int it = 0; it < iters; ++it) {
             DEKF_R3_T(t0);

@@ -1249,7 +1249,9 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     const double cinv = 1.0 / q.cc;
     int iter = 0;
     bool done = false;
+    if constexpr (!R3) {  // (R3: the first chunk's load of the row blocks is the restart)
     if (ok) phase_rows<true>(q, alpha, sigma);  // cold start: cf, t = 0, w = 0 (the factorisation scratch aliased xt | zt | at)
+    }
     DEKF_PROF_MARK(q, 1);
     while (ok && !done && iter < c.max_iter) {
 #if DEKF_DEVICE_BUILD
@@ -1293,7 +1295,9 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
                     info.rho_updates++;
                     DEKF_SYNC();
                     ok = solve_factor(q);
+                    if constexpr (!R3) {
                     if (ok) phase_rows<true>(q, alpha, sigma);  // cf, t, w for the new rho (the scratch aliased xt | zt | at)
+                    }
                     DEKF_PROF_MARK(q, 11);
                 }
             }
