@@ -670,16 +670,24 @@ DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
         }
     };
     if (smax > 0) {
-        Ops o0, o1;
-        load(1, o0);
-        for (int s = 1; s <= smax; s += 2) {
-            if (s + 1 <= smax) load(s + 1, o1);
-            step(s, o0);
-            if (s + 1 <= smax) {
-                if (s + 2 <= smax) load(s + 2, o0);
-                step(s + 1, o1);
+        // ring of three operand sets, two steps of prefetch in flight: the factor of these shapes streams from the HBM slab
+        // (two sets, one step ahead, left a memory round trip exposed in every step: 1.1-1.3 k cycles per step measured)
+        constexpr int RING = 3;
+        Ops r[RING];
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)
+            if (smax >= u + 1) load(u + 1, r[u]);
+        int s = 1;
+        for (; s + RING - 1 <= smax; s += RING) {
+#pragma unroll
+            for (int u = 0; u < RING; ++u) {
+                if (s + u + RING - 1 <= smax) load(s + u + RING - 1, r[(u + RING - 1) % RING]);
+                step(s + u, r[u]);
             }
         }
+#pragma unroll
+        for (int u = 0; u < RING - 1; ++u)
+            if (s + u <= smax) step(s + u, r[u]);
     }
 #else
     for (int side = 0; side < 2; ++side) {
