@@ -345,6 +345,21 @@ DEKF_FN double all_rows_from_row1(double v) {  // [r0 r1 r2 r3] -> [r1 r1 r1 r1]
     return __hiloint2double((int)d[0], (int)c[0]);
 }
 
+DEKF_FN double all_rows_from_row0(double v) {  // [r0 r1 r2 r3] -> [r0 r0 r0 r0]
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // first result: [r0 r0 r2 r2]
+    auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    auto c = __builtin_amdgcn_permlane32_swap(a[0], a[0], false, false);
+    auto d = __builtin_amdgcn_permlane32_swap(b[0], b[0], false, false);
+    return __hiloint2double((int)d[0], (int)c[0]);
+}
+DEKF_FN double rows01_from_rows23(double v) {  // [r0 r1 r2 r3] -> [r2 r3 r2 r3]
+    unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return __hiloint2double((int)b[1], (int)a[1]);
+}
+
 // The whole two-sided block-tridiagonal solve on ONE wavefront, its four 16-lane rows in lock step, with no
 // workgroup barrier inside (the two-wavefront form needs three: legs | meeting block + g | legs):
 //   row 0  top leg        f_k = b_k - W_{k-1} f_{k-1}          row 2  g_{k-1} = S_{k-1}^-1 f_{k-1} (top half)
@@ -356,7 +371,7 @@ DEKF_FN double all_rows_from_row1(double v) {  // [r0 r1 r2 r3] -> [r1 r1 r1 r1]
 // Needs an even compile-time horizon (both forward legs equally long) and the full window.
 template <int NF, class Q>
 DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
-    constexpr int SV = 21 + 3 * Q::LEGS, K = NF, M = mid_block(NF), NOUT = K - 1 - M;
+    constexpr int SV = 21 + 3 * Q::LEGS, K = NF, M = mid_block(NF);
     static_assert(NF % 2 == 0 && K - 2 - M == M, "equal forward legs");
     const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15;
     const int i = li < 9 ? li : 8;
@@ -401,61 +416,57 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
             gst[(s - 1) * gstep] = r;     // -g_{s-1} (row 2) / -g_{K-s} (row 3)
         }
     }
-    // ---------------- meeting block (row 0) and the last g of the bottom half (row 3)
+    // ---------------- joint middle: blocks M and M + 1 together (solve_factor left P12 in W[M] and P22 in S^-1[M + 1])
+    //   row 0: P11 f_M        row 1: P22 f^_{M+1}        row 2: P12 f^_{M+1}        row 3: P12' f_M
+    //   u_M = row 0 + row 2,  u_{M+1} = row 1 + row 3
     {
         double w[9];
-        const double* W = row == 0 ? q.Wk + M * 81 + 9 * i : q.Sinv + (M + 1) * 81 + 9 * i;
-        const double z = (row == 0 || row == 3) ? 1.0 : 0.0;
+        const double* W = row == 0 ? q.Sinv + M * 81 + 9 * i : (row == 1 ? q.Sinv + (M + 1) * 81 + 9 * i : q.Wk + M * 81 + (row == 2 ? 9 * i : i));
+        const int wst = row == 3 ? 9 : 1;  // row 3 reads P12 transposed
 #pragma unroll
-        for (int t = 0; t < 9; ++t) w[t] = z * W[t];
-        double s9[9];
-#pragma unroll
-        for (int t = 0; t < 9; ++t) s9[t] = q.Sinv[M * 81 + 9 * i + t];
-        const double dm = Dx[M * XST + i], xm = x[M * XST + i];
-        const double src = all_rows_from_row1(v);                 // f^_{M+1} everywhere
-        const double r = chain_matvec_dpp(src, w, row == 0 ? v : 0.0);
-        if (row == 3 && act) xd[9 * (M + 1) + i] = r;              // -g_{M+1}
-        const double um = -chain_matvec_dpp(r, s9, 0.0);           // row 0: S_M^-1 (f_M - W^_M f^_{M+1})
-        if (row == 0 && act) {
-            xd[9 * M + i] = dm * um;
-            x[M * XST + i] = alpha * um + (1.0 - alpha) * xm;
+        for (int t = 0; t < 9; ++t) w[t] = W[t * wst];
+        const int blk = top ? M : M + 1;                          // rows 0 / 1 own blocks M / M + 1
+        const double dm = Dx[blk * XST + i], xm = x[blk * XST + i];
+        const double f0 = all_rows_from_row0(v), f1 = all_rows_from_row1(v);
+        const double src = (row == 0 || row == 3) ? f0 : f1;
+        const double part = -chain_matvec_dpp(src, w, 0.0);       // (chain_matvec_dpp returns rhs - W v)
+        const double um = part + rows01_from_rows23(part);        // rows 0, 1: u_M, u_{M+1}
+        if (leg && act) {
+            xd[9 * blk + i] = dm * um;
+            x[blk * XST + i] = alpha * um + (1.0 - alpha) * xm;
         }
-        v = row1_from_row0(um);                                    // rows 0 and 1 start from u_M
+        v = um;
     }
-    // ---------------- outward: step s = 1..NOUT, row 0 block M - s (s <= M), row 1 block M + s
+    // ---------------- outward: step s = 1..M, row 0 block M - s, row 1 block M + 1 + s
     {
         struct Bops { double w[9], ng, dsc, xo; };
+        static_assert(K - 2 - M == M, "both outward legs M steps");
         const bool own = leg && act;
-        double* xdp = own ? xd + 9 * M + i : dummy;       // block M; step s is at +- s blocks
-        double* xp = own ? x + M * XST + i : dummy;
-        const double* Dp = own ? Dx + M * XST + i : dummy;
+        const int b0 = top ? M : M + 1;
+        double* xdp = own ? xd + 9 * b0 + i : dummy;       // the leg's start block; step s is at +- s blocks
+        double* xp = own ? x + b0 * XST + i : dummy;
+        const double* Dp = own ? Dx + b0 * XST + i : dummy;
         const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0;
-        const double* Wp = q.Wk + (top ? M : M - 1) * 81 + i;  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
+        const double* Wp = q.Wk + M * 81 + i;              // row 0: W_{M-s}', row 1: W^_{M+s}'
         const int wstep = top ? -81 : 81;
         auto bload = [&](int s, Bops& o) {
-            const int sl = s <= M ? s : (top ? M : s);  // row 0 has one step less: its last load repeats block 0
-            const double* W = Wp + sl * wstep;
+            const double* W = Wp + s * wstep;
 #pragma unroll
             for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
-            o.ng = xdp[sl * xdstep];
-            o.dsc = Dp[sl * xstep];
-            o.xo = xp[sl * xstep];
+            o.ng = xdp[s * xdstep];
+            o.dsc = Dp[s * xstep];
+            o.xo = xp[s * xstep];
         };
         Bops o[2];
         bload(1, o[0]);
 #pragma unroll
-        for (int s = 1; s <= NOUT; ++s) {
+        for (int s = 1; s <= M; ++s) {
             const Bops& c = o[(s - 1) & 1];
-            if (s < NOUT) bload(s + 1, o[s & 1]);
+            if (s < M) bload(s + 1, o[s & 1]);
             const double r = chain_matvec_dpp(v, c.w, -c.ng);
             v = r;
-            if (s <= M) {
-                xdp[s * xdstep] = c.dsc * r;
-                xp[s * xstep] = alpha * r + (1.0 - alpha) * c.xo;
-            } else if (!top && own) {  // the bottom leg is one block longer
-                xdp[s * xdstep] = c.dsc * r;
-                xp[s * xstep] = alpha * r + (1.0 - alpha) * c.xo;
-            }
+            xdp[s * xdstep] = c.dsc * r;
+            xp[s * xstep] = alpha * r + (1.0 - alpha) * c.xo;
         }
     }
 }
