@@ -258,7 +258,9 @@ def run_bench(args, env, rank, world):
         # cycles one workgroup spends per solve: a launch runs B / grid solves back to back on each persistent workgroup
         li = est.launch_info()
         cycles_per_solve = avg_solve_s * li["clock_hz"] / max(1.0, float(np.ceil(B / max(li["solve_workgroups"], 1))))
-        chain_floor = mean_iters * (int(p.N) + 1) * CHAIN_STEP_FLOOR_CYCLES
+        # dependent mat-vec steps of one block-tridiagonal solve: (N - 2) / 2 forward + 1 joint middle + (N - 2) / 2 outward
+        # on each side of the two-sided solve, the two sides in lock step
+        chain_floor = mean_iters * (int(p.N) - 1) * CHAIN_STEP_FLOOR_CYCLES
         traffic, traffic_src = measured_traffic() if (B == 4096 and world == 1 and env.real) else (None, None)
         line = {
             "metric": "estimator-steps/sec (EKF+MHE, 20-step window)",
