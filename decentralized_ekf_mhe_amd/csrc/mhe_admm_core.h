@@ -1063,12 +1063,7 @@ struct VoOrBiasMat {
 // rows): each lane keeps its 3 rows of S (own 3x3 symmetric part + 3x3 coupling part) and gets the
 // partner's 3-vector through DPP quad_perm [1,0,3,2] — no LDS, no barrier.  One lane per 6-block made
 // this tile the critical path of the row phase (2.3x the instructions of a Meas lane on 19 lanes).
-DEKF_FN double pair_swap(double v) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
-}
+// (pair_swap: wave.h)
 struct DynPairMat {
     double a[6];  // own rows x own columns (symmetric, packed)
     double b[9];  // own rows x partner columns

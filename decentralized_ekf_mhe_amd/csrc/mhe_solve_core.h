@@ -445,11 +445,192 @@ DEKF_FN void solve_scale(Q& q) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { En[r0 + a] = eo[a]; Dn[sv0 + a] = dout[a]; }
     };
+#if DEKF_DEVICE_BUILD
+    auto fused = [&](int tile, int lane, double cc, const double* Dr, const double* Er, double* Dw, double* Ew) -> double {
+        int kind, k, sub;
+        if (!decode(tile, lane, kind, k, sub)) return 0.0;
+        if ((kind >= 4 && kind <= 6) || kind == 8) {  // x column: inf-norm over the rows that touch it
+            const int a = kind == 8 ? sub % 3 : sub, i = k * SV + (kind == 8 ? 9 + sub : 3 * (kind - 4) + a);
+            const bool hn = k < K1, hp = k > 0;
+            const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
+            const double di = Dr[i], pci = pc[i];
+            double an = 0.0;
+            if (kind == 4) {
+                const double n0 = Er[ix.rd(kn, a)], n1 = Er[ix.rv(kn, a)], p0 = Er[ix.rd(kp, a)], p1 = Er[ix.rv(kp, a)];
+                if (hn) an = dmax(n0, n1);
+                if (hp) an = dmax(an, dmax(p0, p1));
+                if constexpr (FT) {  // A_meas = [-I 0 0 .. I ..]: every leg's Meas rows touch the position
+#pragma unroll
+                    for (int leg = 0; leg < L; ++leg) an = dmax(an, Er[ix.rm(k, 3 * leg + a)]);
+                }
+            } else if (kind == 5) {
+                const double n0 = Er[ix.rd(kn, 3 + a)], n1 = Er[ix.rd(kn, a)], p0 = Er[ix.rd(kp, 3 + a)];
+                if constexpr (!FT) {
+#pragma unroll
+                    for (int leg = 0; leg < L; ++leg) an = dmax(an, Er[ix.rm(k, 3 * leg + a)]);
+                }
+                if (hn) an = dmax(an, dmax(n0, dt * n1));
+                if (hp) an = dmax(an, p0);
+            } else if (kind == 6) {
+                const double* R = q.R + 9 * kn;
+                double bn = Er[ix.rd(kn, 6 + a)];
+                const double p0 = Er[ix.rd(kp, 6 + a)];
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const double ra = fabs(R[3 * r + a]);
+                    bn = dmax(bn, dmax(hdt2 * ra * Er[ix.rd(kn, r)], dt * ra * Er[ix.rd(kn, 3 + r)]));
+                }
+                if (hn) an = bn;
+                if (hp) an = dmax(an, p0);
+            } else {  // foot-position column: its leg's Meas row, the Dyn rows of this and the previous step
+                const double m0 = Er[ix.rm(k, sub)], n0 = Er[ix.rd(kn, 9 + sub)], p0 = Er[ix.rd(kp, 9 + sub)];
+                an = m0;
+                if (hn) an = dmax(an, n0);
+                if (hp) an = dmax(an, p0);
+            }
+            Dw[i] = di * rsqrt_fast(limit_scaling(dmax(cc * pci, an * di)));
+            return 0.0;  // pc of an x column: 0 for k > 0 (stays 0), the arrival-cost block of x_0 after the barrier (fused_x0)
+        }
+        int r0, sv0;
+        row_base(kind, k, sub, r0, sv0);
+        const double* d = Dr + k * SV;
+        double e3[3], d3[3], p3[3], v[3];  // own rows / slacks; v = inf-norm of the row of A D (before E)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { e3[a] = Er[r0 + a]; d3[a] = Dr[sv0 + a]; p3[a] = pc[sv0 + a]; }
+        if (kind == 0) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = FT ? dmax(d3[a], dmax(d[a], d[9 + 3 * sub + a])) : dmax(d3[a], d[3 + a]);
+        } else if (kind == 1) {
+            const double* R = q.R + 9 * k;
+            double dk[9], dnx[6], Ra[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) { dk[t] = d[t]; Ra[t] = fabs(R[t]); }
+#pragma unroll
+            for (int t = 0; t < 6; ++t) dnx[t] = d[SV + t];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double vp = dmax(dmax(d3[a], dk[a]), dmax(dt * dk[3 + a], dnx[a]));
+                double vv = dmax(dmax(d3[a], dk[3 + a]), dnx[3 + a]);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    vp = dmax(vp, hdt2 * Ra[3 * a + j] * dk[6 + j]);
+                    vv = dmax(vv, dt * Ra[3 * a + j] * dk[6 + j]);
+                }
+                v[a] = sub ? vv : vp;
+            }
+        } else if (kind == 2) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], dmax(d[6 + a], d[SV + 6 + a]));
+        } else if (kind == 3) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], dmax(d[a], d[SV + a]));
+        } else {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) v[a] = dmax(d3[a], dmax(d[9 + 3 * sub + a], d[SV + 9 + 3 * sub + a]));
+        }
+        double eo[3], dout[3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            eo[a] = e3[a] * rsqrt_fast(limit_scaling(e3[a] * v[a]));
+            dout[a] = d3[a] * rsqrt_fast(limit_scaling(dmax(cc * p3[a], e3[a] * d3[a])));  // slack column: one entry, in its row
+        }
+        // ---- adopt, fused: inf-norms of the owned slack columns of D P D from the scaling just computed (the partner half of
+        //      a Dyn lane pair comes over by DPP); every load above and below is issued before the first store
+        double vv3[3];
+        if (kind == 1) {
+            const double* q21 = Pst + k * PS + 6 * L;
+            double d6[6], pq[3][6];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const double other = pair_swap(dout[t]);
+                d6[t] = sub ? other : dout[t];
+                d6[3 + t] = sub ? dout[t] : other;
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const double p0 = q21[a < t ? symidx(a, t, 6) : symidx(t, a, 6)];
+                    const double p1 = q21[3 + a < t ? symidx(3 + a, t, 6) : symidx(t, 3 + a, 6)];
+                    pq[a][t] = sub ? p1 : p0;
+                }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                double m = 0.0;
+#pragma unroll
+                for (int t = 0; t < 6; ++t) m = dmax(m, fabs(pq[a][t] * d6[t]));
+                vv3[a] = m * dout[a];
+            }
+        } else if (kind == 2) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) vv3[a] = dout[a] * q.c.Q_bias_dt2[a] * dout[a];
+        } else {
+            const double* q6 = Pst + k * PS + (kind == 0 ? 6 * sub : (kind == 3 ? 6 * L + 21 : 6 * L + 27 + 6 * sub));
+            double p6[6];
+#pragma unroll
+            for (int t = 0; t < 6; ++t) p6[t] = q6[t];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+                vv3[a] = dmax(fabs(p6[symidx(0, a, 3)] * dout[0]), dmax(fabs(p6[1 < a ? symidx(1, a, 3) : symidx(a, 1, 3)] * dout[1]), fabs(p6[symidx(a, 2, 3)] * dout[2]))) * dout[a];
+        }
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { Ew[r0 + a] = eo[a]; Dw[sv0 + a] = dout[a]; pc[sv0 + a] = vv3[a]; }
+        return vv3[0] + vv3[1] + vv3[2];
+    };
+    // the arrival-cost block (x_0 columns): needs the new scaling of all of x_0, i.e. the barrier behind `fused`
+    auto fused_x0 = [&](int tile, int lane, const double* Dw) -> double {
+        int kind, k, sub;
+        if (tile < ntm + ntp + 2 * ntd || tile >= ntm + ntp + 2 * ntd + 3 * ntx) return 0.0;
+        if (!decode(tile, lane, kind, k, sub) || k != 0) return 0.0;
+        const int j = 3 * (kind - 4) + sub;
+        const double dj = Dw[j];
+        double mj[9], dt9[9], v = 0.0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { mj[t] = symget(Mst, j, t, 9); dt9[t] = Dw[t]; }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * mj[t] * dt9[t]));
+        pc[j] = v;
+        return v;
+    };
+#endif
     wtiles(ntiles, [&](int tile, int lane) { (void)adopt(tile, lane); });  // column norms of P for D = 1
     DEKF_SYNC();
     double gq[NS];  // the linear cost sits in HBM: read it once, not once per pass (a global round trip each)
 #pragma unroll
     for (int j = 0; j < NS; ++j) gq[j] = g[j];
+#if DEKF_DEVICE_BUILD
+    if constexpr (FT == 0) {
+        // One Ruiz pass = ONE tile phase (equilibrate + the new column norms of the owned slack blocks, ping-pong between the two
+        // pairs of scaling vectors instead of a copy), a barrier, the nine x_0 lanes' arrival-cost norms, the sum.  Same
+        // arithmetic, same lanes, same order of the sum as the two-phase form below (which the lane-sequential build and the
+        // foot-state shapes keep): bit-identical D, E, c.
+        double *Dr = D, *Er = E, *Dw = Dn, *Ew = En;
+        for (int it = 0; it < q.c.scaling; ++it) {
+            const double cc = q.cc;
+            double psum = 0.0;
+            wtiles(ntiles, [&](int tile, int lane) { psum += fused(tile, lane, cc, Dr, Er, Dw, Ew); });
+            DEKF_SYNC();
+            wtiles(ntiles, [&](int tile, int lane) { psum += fused_x0(tile, lane, Dw); });
+            psum = wave_sum(psum);
+            group_combine<1, true>(&psum);
+            psum *= cc;
+            double qn = 0.0;
+#pragma unroll
+            for (int j = 0; j < NS; ++j) qn = dmax(qn, fabs(cc * Dw[j] * gq[j]));
+            double ct = 1.0 / limit_scaling(dmax(psum / (double)n, limit_scaling(qn)));
+            q.cc = cc * ct;
+            double* t0 = Dr; Dr = Dw; Dw = t0;
+            double* t1 = Er; Er = Ew; Ew = t1;
+        }
+        if (Dr != D) {  // odd number of passes: the result sits in the other pair
+            DEKF_SYNC();
+            const double *Ds = Dr, *Es = Er;
+            wfor(n + m, [&](int e) { if (e < n) D[e] = Ds[e]; else E[e - n] = Es[e - n]; });
+        }
+        DEKF_SYNC();
+        return;
+    }
+#endif
     for (int it = 0; it < q.c.scaling; ++it) {
         const double cc = q.cc;
         wtiles(ntiles, [&](int tile, int lane) { equil(tile, lane, cc); });

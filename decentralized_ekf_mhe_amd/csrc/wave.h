@@ -249,6 +249,15 @@ DEKF_FN double readlane_f64(double v, int lane) {
 #endif
 DEKF_FN int wave_count() { return DEKF_NLANES() > WAVE ? DEKF_NLANES() >> 6 : 1; }
 #if DEKF_DEVICE_BUILD
+// exchange a double with the partner lane of an adjacent lane pair (DPP quad_perm [1, 0, 3, 2]): no LDS, no barrier
+DEKF_FN double pair_swap(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0xB1, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0xB1, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+#endif
+#if DEKF_DEVICE_BUILD
 template <class F>
 DEKF_FN void wtiles(int ntiles, F f) {
     const int nw = DEKF_NLANES() > WAVE ? DEKF_NLANES() >> 6 : 1;
