@@ -379,7 +379,7 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
     // the x blocks of x and D: inside the full variable vector (stride SV per step), or compact (R3: [K][9] in LDS)
     constexpr int XST = Q::R3 ? 9 : SV;
     double *xs = q.xs, *xd = q.xd, *x = Q::R3 ? q.xb : q.x;
-    const double* Dx = Q::R3 ? q.Db : q.D;
+    const double* Dx = q.D;  // (always inside the full scaling vector: stride SV)
     struct Ops { double w[9], rhs; };
     // ---------------- forward: step s = 1..M
     const double* fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
@@ -426,7 +426,7 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) w[t] = W[t * wst];
         const int blk = top ? M : M + 1;                          // rows 0 / 1 own blocks M / M + 1
-        const double dm = Dx[blk * XST + i], xm = x[blk * XST + i];
+        const double dm = Dx[blk * SV + i], xm = x[blk * XST + i];
         const double f0 = all_rows_from_row0(v), f1 = all_rows_from_row1(v);
         const double src = (row == 0 || row == 3) ? f0 : f1;
         const double part = -chain_matvec_dpp(src, w, 0.0);       // (chain_matvec_dpp returns rhs - W v)
@@ -445,8 +445,8 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
         const int b0 = top ? M : M + 1;
         double* xdp = own ? xd + 9 * b0 + i : dummy;       // the leg's start block; step s is at +- s blocks
         double* xp = own ? x + b0 * XST + i : dummy;
-        const double* Dp = own ? Dx + b0 * XST + i : dummy;
-        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0;
+        const double* Dp = own ? Dx + b0 * SV + i : dummy;
+        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0, dstep = own ? (top ? -SV : SV) : 0;
         const double* Wp = q.Wk + M * 81 + i;              // row 0: W_{M-s}', row 1: W^_{M+s}'
         const int wstep = top ? -81 : 81;
         auto bload = [&](int s, Bops& o) {
@@ -454,7 +454,7 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
             o.ng = xdp[s * xdstep];
-            o.dsc = Dp[s * xstep];
+            o.dsc = Dp[s * dstep];
             o.xo = xp[s * xstep];
         };
         Bops o[2];
@@ -1566,7 +1566,7 @@ DEKF_FN void xcols_tile_r3(Q& q, int kind, int lane, double sigma) {
     const double* at = q.at;
     auto w = [&](int r) { return at[r]; };
     const int k = lane / 3, a = lane - 3 * k, j = 3 * kind + a, i = 9 * k + j;
-    const double xv = q.xb[i], dv = q.Db[i], qv = qsl[j];
+    const double xv = q.xb[i], dv = q.D[k * (21 + 3 * Q::LEGS) + j], qv = qsl[j];
     double g;
     if (kind == 0) g = gather_pcol(q, k, a, w);
     else if (kind == 1) g = gather_vcol(q, k, a, w);

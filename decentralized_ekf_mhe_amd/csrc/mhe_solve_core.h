@@ -100,7 +100,8 @@ struct SolveLayout {
     DEKF_HD bool pa_in_lds() const { return factor_in_lds() && (n_pad + 2 * m_pad >= (K - 1) * ns * ns); }
     // Three-workgroup placement (R3, fixed-horizon kernels with the full window only): the row phase keeps its state and its
     // constants in REGISTERS for a whole chunk of iterations, so LDS holds only what crosses lanes:
-    //   R | xb Db (x blocks, compact) | [at xs xd gb + pad] = factor-time PA | tmp | Sinv | Wk
+    //   R | D E (the scaling vectors: every phase reads them) | xb (x blocks, compact) | [at xs xd gb + pad] = factor-time PA |
+    //   tmp | Sinv | Wk
 #ifndef DEKF_R3_WAVES
 #define DEKF_R3_WAVES 3     // resident workgroups per CU the R3 kernels are compiled for (launch bound: wavefronts per SIMD)
 #endif
@@ -108,12 +109,12 @@ struct SolveLayout {
 #define DEKF_R3_PA_LDS 1    // 0: the factor-time product P A in the HBM slab (40 KiB of LDS per instance: a fourth workgroup fits)
 #endif
     DEKF_HD int r3_pa_region() const { int a = m_pad + 2 * ns * K + 3 * K, b = DEKF_R3_PA_LDS ? (K - 1) * ns * ns : 0; return a > b ? a : b; }
-    DEKF_HD int r3_doubles() const { return 9 * K + 2 * ns * K + r3_pa_region() + solve_tmp_len(ns) + 2 * K * ns * ns; }
+    DEKF_HD int r3_doubles() const { return 9 * K + n_pad + m_pad + ns * K + r3_pa_region() + solve_tmp_len(ns) + 2 * K * ns * ns; }
     DEKF_HD size_t r3_lds_bytes() const { return (size_t)r3_doubles() * 8; }
-    // the Ruiz passes run in LDS before any of the above is live: D E in front of Sinv, Pst | pc | En | Dn inside Sinv | Wk
+    // the Ruiz passes' temporaries (pc | En | Dn) sit behind the staged P blocks inside Sinv | Wk, which are not live yet
     DEKF_HD bool r3_fits(int L) const {
-        const int front = r3_doubles() - 2 * K * ns * ns - 9 * K, ps = K * (6 * L + 27) + ns * (ns + 1) / 2;
-        return n_pad + m_pad <= front && ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && DEKF_R3_WAVES * (r3_lds_bytes() + 512) <= 160 * 1024;
+        const int ps = K * (6 * L + 27) + ns * (ns + 1) / 2;
+        return ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && DEKF_R3_WAVES * (r3_lds_bytes() + 512) <= 160 * 1024;
     }
     DEKF_HD size_t lds_bytes() const { return (size_t)(factor_in_lds() ? vec + resident : vec) * 8; }
 };
@@ -141,7 +142,7 @@ struct IdxT {
 
 template <int L, int NF = 0, bool FLDS = true, int FT = 0, bool R3_ = false>
 struct SolveCtx {
-    static constexpr bool R3 = R3_;  // three workgroups per CU: row state in registers, x blocks compact in LDS (xb, Db)
+    static constexpr bool R3 = R3_;  // three workgroups per CU: row state in registers, x blocks compact in LDS (xb)
     static constexpr int LEGS = L;
     static constexpr int NFIXED = NF;  // != 0: horizon known at compile time (sweeps fully unrolled when K == NF)
     static constexpr bool FACTOR_LDS = FLDS;  // false: W_k streams from the HBM slab (deeper operand prefetch in the sweeps)
@@ -153,7 +154,7 @@ struct SolveCtx {
     IdxT<L, FT> ix;
     // LDS always
     double *x, *z, *y, *xt, *zt, *at, *xs, *xd, *tmp;
-    double *xb, *Db;  // R3: the x blocks of x and of D, [K][NS], the only part of them an iteration shares between lanes
+    double* xb;       // R3: the x blocks of x, [K][NS], the only part of x an iteration shares between lanes
     double* cf;  // per row rho E D (aliases xt, which only the factorisation uses otherwise)
     double* gb;  // per step R' (dt^2/2 w_p + dt w_v): the Dyn rows' contribution to the bias columns (tail of xt)
     // LDS or HBM scratch
@@ -1329,14 +1330,14 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     g.init(NH, L, FT);
     SolveCtx<L, NFIX, FACTOR_LDS, FT, R3> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
     q.xb = nullptr;
-    q.Db = nullptr;
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
         double* p = lds;
         if constexpr (R3) {
             static_assert(!R3 || (FACTOR_LDS && PA_LDS && NFIX != 0 && FT == 0), "R3: fixed horizon, 9 states, factor in LDS");
             q.R = p; p += 9 * NH;
+            q.D = p; p += lay.n_pad;
+            q.E = p; p += lay.m_pad;
             q.xb = p; p += NS * NH;
-            q.Db = p; p += NS * NH;
             q.PA = DEKF_R3_PA_LDS ? p : gws + g.PA;  // at | xs | xd | gb are dead while a factorisation runs
             q.at = p;
             q.xs = p + lay.m_pad;
@@ -1350,7 +1351,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
             // everything a lane keeps to itself between iterations lives in the workgroup's HBM slab while it is not in registers
             q.x = gws + g.x; q.z = gws + g.z; q.y = gws + g.y; q.zt = gws + g.zt; q.cf = gws + g.cf;
             q.xt = nullptr;
-            q.D = gws + g.D; q.E = gws + g.E; q.lo = gws + g.lo; q.hi = gws + g.hi;
+            q.lo = gws + g.lo; q.hi = gws + g.hi;
             q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc;
             q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
         }
@@ -1424,22 +1425,17 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
 #endif
     wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });
     if constexpr (R3) {
-        // The Ruiz passes need their vectors in LDS (ten passes of neighbour look-ups); none of the iteration's arrays is live
-        // yet, so D, E sit in front of S^-1 and pc, En, Dn behind the staged P blocks inside S^-1 | W.  Then D, E move to the slab.
+        // D and E stay in LDS for the whole solve; the Ruiz passes' temporaries pc, En, Dn sit behind the staged P blocks inside
+        // S^-1 | W, which are not live before the first factorisation.
         constexpr int PSL = NFIX * (6 * L + 27) + NS * (NS + 1) / 2;
-        double *Dg = q.D, *Eg = q.E, *xg = q.x, *ztg = q.zt;
-        q.D = q.xb;
-        q.E = q.D + lay.n_pad;
+        double *xg = q.x, *ztg = q.zt;
         q.x = q.Sinv + PSL;              // pc
         q.zt = q.x + lay.n_pad;          // En
         q.xt = q.zt + lay.m_pad;         // Dn
         if (c.scaling > 0) solve_scale(q);
         else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
-        const double *Dl = q.D, *El = q.E;
-        wfor_nosync(n + m, [&](int e) { if (e < n) Dg[e] = Dl[e]; else Eg[e - n] = El[e - n]; });
-        DEKF_SYNC();  // (release fence + barrier: the copies are read back by other lanes below)
-        q.D = Dg; q.E = Eg; q.x = xg; q.zt = ztg; q.xt = nullptr;
-        wfor(K * NS, [&](int e) { int k = e / NS, j = e - NS * k; q.Db[e] = Dg[ix.x(k, j)]; q.xb[e] = 0.0; });
+        q.x = xg; q.zt = ztg; q.xt = nullptr;
+        wfor(K * NS, [&](int e) { q.xb[e] = 0.0; });
     } else {
     if (c.scaling > 0) solve_scale(q);
     else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
