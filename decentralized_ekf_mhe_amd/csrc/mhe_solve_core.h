@@ -114,7 +114,10 @@ struct SolveLayout {
     // the Ruiz passes' temporaries (pc | En | Dn) sit behind the staged P blocks inside Sinv | Wk, which are not live yet
     DEKF_HD bool r3_fits(int L) const {
         const int ps = K * (6 * L + 27) + ns * (ns + 1) / 2;
-        return ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && DEKF_R3_WAVES * (r3_lds_bytes() + 512) <= 160 * 1024;
+        // LDS is granted in coarse units: measured on gfx950, 53 464 B per workgroup (this layout + 480 B static) run three per
+        // CU, 54 112 B run two although the occupancy query still answers three — consistent with a 1 280 or 1 536 B granule
+        const size_t granule = 1536, need = (r3_lds_bytes() + 512 + granule - 1) / granule * granule;
+        return ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && DEKF_R3_WAVES * need <= 160 * 1024;
     }
     DEKF_HD size_t lds_bytes() const { return (size_t)(factor_in_lds() ? vec + resident : vec) * 8; }
 };
