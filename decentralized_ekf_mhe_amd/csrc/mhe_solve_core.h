@@ -119,7 +119,16 @@ struct SolveLayout {
         const size_t granule = 1536, need = (r3_lds_bytes() + 512 + granule - 1) / granule * granule;
         return ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && DEKF_R3_WAVES * need <= 160 * 1024;
     }
-    DEKF_HD size_t lds_bytes() const { return (size_t)(factor_in_lds() ? vec + resident : vec) * 8; }
+    // Factor in the HBM slab (one workgroup per CU anyway): whatever LDS the iterates leave free takes the per-row constants
+    // that every phase reads (D, E, scaled bounds, R) — they are what made a PogoX iteration fetch 53 KB more from beyond L2.
+    DEKF_HD int gg_consts() const { return n_pad + 2 * m_pad + 3 * K + 9 * K; }
+    DEKF_HD static int wgs_per_cu(size_t bytes) { const size_t g = 1536, need = (bytes + 512 + g - 1) / g * g; return (int)((160 * 1024) / need); }
+    DEKF_HD bool gg_consts_in_lds() const {  // only where it costs no resident workgroup
+        if (factor_in_lds()) return false;
+        const int with = wgs_per_cu((size_t)(vec + gg_consts()) * 8);
+        return with >= 1 && with == (wgs_per_cu((size_t)vec * 8) < 2 ? wgs_per_cu((size_t)vec * 8) : 2);
+    }
+    DEKF_HD size_t lds_bytes() const { return (size_t)(factor_in_lds() ? vec + resident : (gg_consts_in_lds() ? vec + gg_consts() : vec)) * 8; }
 };
 
 // variable / row indices with the leg count known at compile time: every / and % by the
@@ -1389,6 +1398,13 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
             q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc;
             if constexpr (FT) q.Sf = gws + g.Sf;
             q.Sinv = gws + g.Sinv; q.Wk = gws + g.Wk; q.R = gws + g.rho;  // rho slot is unused: R (9K <= m_pad)
+            if (lay.gg_consts_in_lds()) {  // (run-time placement: these five become generic pointers in this instantiation)
+                q.D = p; p += lay.n_pad;
+                q.E = p; p += lay.m_pad;
+                q.lo = p; p += lay.m_pad;
+                q.hi = p; p += 3 * NH;
+                q.R = p; p += 9 * NH;
+            }
         }
         q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
         if constexpr (FT) q.Wf = gws + g.Wf;
