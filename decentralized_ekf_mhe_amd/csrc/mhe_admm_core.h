@@ -1346,12 +1346,13 @@ DEKF_FN void row_tile_finish(Q& q, const RowTile& t, double alpha, double sigma)
 // lane-private: a row block's state (slack x, z, y, t) and its constants (E, rho E D, D, bounds, slack-block inverse) are only
 // ever touched by the lane that owns the block.  Here they live in that lane's REGISTERS for a whole chunk of iterations (all
 // iterations up to the next termination check / rho adaptation), and in the workgroup's HBM slab in between, where the rare
-// phases (residuals, refactorisation, restart) find them.  LDS keeps what crosses lanes: x blocks, xs, xd, w, gb, the factor.
-// 45 KiB per instance: three workgroups per CU (measured with an aliased-layout build before this was written: +33 %).
+// phases (residuals, refactorisation) find the state.  LDS keeps what crosses lanes — x blocks, xs, xd, w, gb, the factor — and
+// the scaling vectors D, E that every rare phase reads: 52.9 KiB per instance, three workgroups per CU (decided by an
+// aliased-layout build before this was written: +33 %; 81 doubles more and the hardware places only two, see r3_fits).
 //
 // WAVE-SPECIALISED LOOPS.  Wavefront 0 runs nothing but the block-tridiagonal solve; wavefronts 1-3 own the row tiles and the
 // x-column tiles.  Each side has its own loop with the same sequence of workgroup barriers (s_barrier counts arrivals, it does
-// not care where a wavefront's program counter is), so the 80 state registers are not live in the solve's code and the solve's
+// not care where a wavefront's program counter is), so the 78 state registers are not live in the solve's code and the solve's
 // operand sets are not live in the row code: both fit the 168 VGPRs that three wavefronts per SIMD leave each.
 //   barrier B1: xs complete   (workers: x columns)      ->  wavefront 0: solve
 //   barrier B2: xd complete   (wavefront 0: solve)      ->  workers: rows from registers, w and gb to LDS
