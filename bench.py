@@ -4,13 +4,19 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B_per_gpu]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: called plainly (no WORLD_SIZE in the environment), `main()` starts the N ranks itself as a
+child `python -m torch.distributed.run` — before this process has imported torch or made any HIP call — and exits with
+the child's code; rank 0 of the child prints the line.
+
 One "step" = one estimator-step for every robot instance of the batch: one EKF timer tick
 (predict + accel-correct, VO rewind when a pose is due) + one full MHE update(T) (term
 construction, VO bounds, marginalisation, Ruiz scaling, factorisation, OSQP-style ADMM to
 eps 1e-6, extraction) — SURVEY.md §8(d).  Workload at N=1: BASELINE.json configs[1]
 "Go1, batch=4096 synthetic IMU+encoder+vision streams, 20-step MHE, 1xMI355X".  Instances are
-independent, so N GPUs run N shards of 4096 (weak scaling) and exchange only the fused
-base-velocity estimates (one RCCL all-gather per step).  Sensor logs are synthetic
+independent (the reference runs one process per robot, go1_launch.py:18-25), so N GPUs run N
+shards and exchange only the fused base-velocity estimates (one RCCL all-gather per step).  The
+shard is 4096 instances at N = 1 (configs[1]) and 8192 at N > 1, so that N = 8 is configs[3]
+"Go1, batch=65 536 sharded across 8xMI355X"; --batch overrides both.  Sensor logs are synthetic
 (decentralized_ekf_mhe_amd/streams.py) and resident in HBM before the timed region.
 
 The rank choreography (`run_bench`) takes everything that touches a device through a `BenchEnv`, so that
@@ -134,6 +140,26 @@ def cpu_baseline(params, total_steps, seed_first, gpu_x_final=None):
                                   "max_err_over_tolerance": norm,
                                   "tolerance": "|x - oracle|_inf <= 1e-4 |oracle|_inf + 1e-6 per p / v / bias block"}
     return out
+
+
+def default_batch(gpus):
+    """instances per GPU when --batch is not given: configs[1] at one GPU; at N > 1 the per-rank share of configs[3]
+    (65 536 over 8 GPUs), so that the driver's plain `bench.py --gpus 8` IS that configuration"""
+    return 4096 if gpus == 1 else 8192
+
+
+def workload_name(B, world, N):
+    """config.workload from what actually runs; names the BASELINE.json configuration when it is exactly one"""
+    base = f"Go1, batch={world * B} synthetic IMU+encoder+vision streams, {N}-step MHE"
+    if world == 1:
+        tag = " (BASELINE.json configs[1])" if (B == 4096 and N == 20) else ""
+        return f"{base}, 1xMI355X{tag}"
+    tag = ""
+    if world * B == 65536 and world == 8 and N == 20:
+        tag = " (BASELINE.json configs[3])"
+    elif B == 8192 and N == 20:
+        tag = " (the per-rank share of BASELINE.json configs[3] on every rank)"
+    return f"{base}, {B} per GPU sharded across {world}xMI355X with RCCL all-gather over xGMI{tag}"
 
 
 class BenchEnv:
@@ -267,8 +293,7 @@ def run_bench(args, env, rank, world):
             "value": value, "unit": "estimator-steps/s", "n_gpus": world, "steps": K, "warmup": W, "window_fill_steps_before_warmup": fill,
             "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "Go1, batch=4096 per GPU synthetic IMU+encoder+vision streams, 20-step MHE "
-                                   "(BASELINE.json configs[1])",
+            "config": {"workload": workload_name(B, world, int(p.N)),
                        "robot": "go1", "legs": 4, "N": int(p.N), "batch_per_gpu": B, "global_batch": world * B,
                        "eps": 1e-6, "parallelism": f"instances sharded x{world}, RCCL all-gather of v_b per step", "allgather": gather_path},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -291,6 +316,8 @@ def run_bench(args, env, rank, world):
                        "solved_frac": solved, "max_abs_v_err_vs_truth": v_err},
             "stream_gen_s": t_gen,
         }
+        if not env.real:
+            line["stand_in"] = True  # tests only: no estimator ran, nothing in this line is a measurement
         if not args.no_cpu_baseline and world == 1 and env.real:  # the CPU leg runs at N = 1 only (rank 0's host cores, same run)
             cb = cpu_baseline(p, total, seed_first=0, gpu_x_final=out["x"])
             err = cb.pop("error_vs_oracle", None)
@@ -302,15 +329,53 @@ def run_bench(args, env, rank, world):
     return line
 
 
-def main():
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def self_launch(args, argv):
+    """`bench.py --gpus N` called plainly for N > 1: one process per GPU is started HERE, as a child
+    `python -m torch.distributed.run`, and this process only waits for it.  Nothing in this process has imported torch
+    or touched HIP at this point (a process that has initialised the GPU must never exec or fork workers), and the
+    children are fresh interpreters.  Rank 0 of the child prints the JSON line on the inherited stdout."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env)
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 4096 at --gpus 1, else 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
-    args = ap.parse_args()
+    # test hook (tests/test_bench_orchestration.py): "module:function" returning a BenchEnv for (rank, local_rank, world);
+    # such a line is marked "stand_in": true and is never a measurement
+    ap.add_argument("--bench-env", default=None, help=argparse.SUPPRESS)
+    args = ap.parse_args(argv)
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.batch is None:
+        args.batch = default_batch(args.gpus)
+    return args
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args, argv))
 
     import torch
     import torch.distributed as dist
@@ -318,8 +383,26 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher set WORLD_SIZE={world}")
+
+    if args.bench_env:
+        import importlib
+        mod, fn = args.bench_env.split(":")
+        env = getattr(importlib.import_module(mod), fn)(rank, local_rank, world)
+        assert not env.real
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(env.backend)
+        line = run_bench(args, env, rank, world)
+        if rank == 0:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product has no CPU path)"
+    assert local_rank < torch.cuda.device_count(), f"rank {rank}: no GPU {local_rank} on this node"
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -344,7 +427,7 @@ def main():
                    new_unique_id=new_unique_id, preflight=preflight, device_sync=torch.cuda.synchronize)
     line = run_bench(args, env, rank, world)
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -3,12 +3,14 @@
 The 8-GPU runs are the driver's to launch, so the code path `bench.py --gpus N` takes for N > 1 — unique-id
 broadcast, the MIN-reduced pre-flight that decides which all-gather runs, the per-step exchange, the barrier-bracketed
 timed region, the MAX-reduce of the elapsed time and the rank-0 JSON line — is executed here first, with a stand-in
-estimator that lives in THIS file (the product has no such thing: bench.py's main() always builds the HIP estimator
+estimator that lives in tests/bench_stand_in.py (the product has no such thing: bench.py's main() always builds the HIP estimator
 and refuses to start without a GPU)."""
 import argparse
 import json
 import os
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import torch
@@ -16,65 +18,9 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import bench
+from bench_stand_in import make_env
 
-
-class StandInEstimator:
-    """records what run_bench asks of an estimator; v_b of step k is a known function of (rank, instance, k)"""
-
-    def __init__(self, p, B, rank, world, comm_fails=False):
-        self.B, self.rank, self.world, self.k = B, rank, world, -1
-        self.comm_fails, self.comm, self.timing = comm_fails, None, False
-        self.timed_steps, self.gathers = 0, 0
-
-    def vb(self):
-        inst = np.arange(self.B)[:, None] + self.rank * self.B
-        return inst * 1000.0 + self.k + np.arange(3)[None, :] * 0.25
-
-    def push_stream_step(self, sd, k):
-        assert sd["tag"] == "device-streams"
-
-    def step(self, k):
-        assert k == self.k + 1
-        self.k = k
-        self.timed_steps += self.timing
-
-    def sync(self):
-        pass
-
-    def comm_init(self, world, rank, uid):
-        assert (world, rank) == (self.world, self.rank) and uid == b"stand-in-id"
-        if self.comm_fails:
-            raise RuntimeError("stand-in communicator refused")
-        self.comm = "up"
-
-    def allgather_vb(self, out):
-        assert self.comm == "up"
-        dist.all_gather_into_tensor(out.view(self.world * self.B, 3), torch.from_numpy(self.vb()))
-        self.gathers += 1
-
-    def get_into(self, v_b=None):
-        v_b.copy_(torch.from_numpy(self.vb()))
-
-    def timing_enable(self, on):
-        self.timing = bool(on)
-
-    def timing_read(self):
-        return {"ekf": (0.01 * self.timed_steps, self.timed_steps), "assemble": (0.07 * self.timed_steps, self.timed_steps),
-                "solve": (3.5 * self.timed_steps, self.timed_steps)}
-
-    def launch_info(self):
-        return dict(solve_workgroups=512, compute_units=256, clock_hz=2.4e9)
-
-    def get(self):
-        x = np.zeros((self.B, 9))
-        x[:, 3] = 0.5
-        return dict(x=x, v_b=self.vb(), status=np.ones(self.B, np.int32))
-
-    def solver_info(self):
-        return dict(iters=np.full(self.B, 75, np.int32), rho_updates=np.ones(self.B, np.int32))
-
-    def close(self):
-        pass
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _free_port():
@@ -90,14 +36,7 @@ def _worker(rank, world, port, out_dir, preflight_fails_on):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     made = []
-
-    def make(p, B):
-        made.append(StandInEstimator(p, B, rank, world))
-        return made[-1]
-
-    env = bench.BenchEnv(device=torch.device("cpu"), backend="gloo", make_estimator=make,
-                         to_device=lambda s: {"tag": "device-streams"}, new_unique_id=lambda: b"stand-in-id",
-                         preflight=lambda: rank != preflight_fails_on, device_sync=lambda: None, real=False)
+    env = make_env(rank, rank, world, preflight_fails_on=preflight_fails_on, made=made)
     args = argparse.Namespace(gpus=world, steps=7, warmup=5, batch=6, no_cpu_baseline=True, no_allgather=False)
     line = bench.run_bench(args, env, rank, world)
     est = made[0]
@@ -142,3 +81,52 @@ def test_flop_model_is_consistent():
     assert f["per_iteration"] == (3 * 20 - 2) * 162 + 20 * 4 * 102 + 38 * 177 + 38 * 105 + 9 * 20 * 8
     assert 2.0e6 < f["total"] < 4.0e6
     assert bench.algorithmic_flops(4, 20, 150, 2.0, 6.0)["total"] > 1.9 * f["total"] - 1.0e6
+
+
+def _bench_cli(extra, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True, text=True, timeout=timeout)
+    return r
+
+
+def test_plain_gpus_2_self_launches_its_ranks_before_touching_a_device():
+    """the driver calls `python bench.py --gpus N` plainly: main() must start N ranks itself (child torch.distributed.run)
+    and rank 0 of the child must print the one JSON line — here with the gloo stand-in, end to end through main()"""
+    r = _bench_cli(["--gpus", "2", "--steps", "4", "--warmup", "3", "--bench-env", "bench_stand_in:make_env"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 3 and d["stand_in"] is True
+    # default shard at N > 1 is the per-rank share of configs[3]
+    assert d["config"]["batch_per_gpu"] == 8192 and d["config"]["global_batch"] == 16384
+    assert "8192 per GPU sharded across 2xMI355X" in d["config"]["workload"] and "per-rank share" in d["config"]["workload"]
+    assert d["config"]["allgather"].startswith("dekf_allgather_vb")
+
+
+def test_a_failing_rank_fails_the_self_launched_run():
+    r = _bench_cli(["--gpus", "2", "--steps", "2", "--warmup", "1", "--bench-env", "bench_stand_in:no_such_factory"])
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_plain_run_without_a_gpu_refuses_loudly():
+    import torch
+    if torch.cuda.is_available():
+        import pytest
+        pytest.skip("this box has a GPU")
+    r = _bench_cli(["--steps", "2", "--warmup", "1"])
+    assert r.returncode != 0 and "needs a GPU" in r.stderr
+
+
+def test_workload_names_and_default_shards():
+    assert bench.default_batch(1) == 4096 and bench.default_batch(2) == 8192 and bench.default_batch(8) == 8192
+    assert bench.parse_args([]).batch == 4096 and bench.parse_args(["--gpus", "8"]).batch == 8192
+    assert bench.parse_args(["--gpus", "8", "--batch", "512"]).batch == 512
+    w1 = bench.workload_name(4096, 1, 20)
+    assert "batch=4096" in w1 and "configs[1]" in w1 and "1xMI355X" in w1
+    assert "configs" not in bench.workload_name(8192, 1, 20) and "batch=8192" in bench.workload_name(8192, 1, 20)
+    w8 = bench.workload_name(8192, 8, 20)
+    assert "batch=65536" in w8 and "configs[3]" in w8 and "8xMI355X" in w8
+    assert "configs[3]" not in bench.workload_name(4096, 8, 20).replace("per-rank share of BASELINE.json configs[3]", "")
