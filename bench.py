@@ -43,20 +43,37 @@ FP64_VECTOR_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector peak (the path com
 # dependent-issue floor of one 9x9 chain step: nine v_fmac_f64_dpp, each occupying its SIMD for 16 cycles
 # (quarter-rate DPP f64), back to back on one wavefront (tools/probes/dpp_chain_probe.hip)
 CHAIN_STEP_FLOOR_CYCLES = 9 * 16
-TRAFFIC_FILE = os.path.join("profiles", "r02_traffic_k_mhe_solve.json")  # refreshed by tools/final_profiles.sh for the kernel of this round
+TRAFFIC_FILE = os.path.join("profiles", "traffic_k_mhe_solve.json")  # refreshed by tools/final_profiles.sh for the kernel of this round
 
 
-def measured_traffic():
+def measured_traffic(kernel, batch):
     """(HBM bytes per launch of the dominant kernel, where the figure comes from).  The PMC passes cannot run inside
     this process (rocprofv3 wraps the command), so the figure is the committed result of tools/collect_traffic.sh
-    (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes) for exactly this
-    workload; (None, None) if that file is absent."""
+    (FETCH_SIZE / WRITE_SIZE in separate --pmc passes, corrected as MI355X_MICROARCH.md prescribes).  It is only quoted
+    when that file was collected for the very kernel this run launched (`kernel`: dekf_solve_kernel_name) with the same
+    code (the file records a hash of csrc/) at the same batch; otherwise (None, why)."""
     try:
         with open(os.path.join(ROOT, TRAFFIC_FILE)) as fh:
             d = json.load(fh)
-        return d.get("hbm_bytes_per_launch"), f"{TRAFFIC_FILE} ({d.get('collected', 'rocprofv3 --pmc passes')})"
     except Exception:
-        return None, None
+        return None, f"{TRAFFIC_FILE} absent"
+    if d.get("kernel") != kernel or int(d.get("batch", -1)) != int(batch):
+        return None, f"{TRAFFIC_FILE} is for {d.get('kernel')} at batch {d.get('batch')}, this run launched {kernel} at batch {batch}"
+    if d.get("csrc_sha1") != csrc_sha1():
+        return None, f"{TRAFFIC_FILE} was collected for another revision of csrc/ ({d.get('csrc_sha1')})"
+    return d.get("hbm_bytes_per_launch"), f"{TRAFFIC_FILE} ({d.get('collected', 'rocprofv3 --pmc passes')})"
+
+
+def csrc_sha1():
+    """hash over the kernel sources: ties a committed PMC figure to the code it was measured on"""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "decentralized_ekf_mhe_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".h", ".hip")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_flops(L, N, iters, factorizations, checks, scaling_passes=10):
@@ -287,7 +304,8 @@ def run_bench(args, env, rank, world):
         # dependent mat-vec steps of one block-tridiagonal solve: (N - 2) / 2 forward + 1 joint middle + (N - 2) / 2 outward
         # on each side of the two-sided solve, the two sides in lock step
         chain_floor = mean_iters * (int(p.N) - 1) * CHAIN_STEP_FLOOR_CYCLES
-        traffic, traffic_src = measured_traffic() if (B == 4096 and world == 1 and env.real) else (None, None)
+        kernel = est.solve_kernel_name(True)
+        traffic, traffic_src = measured_traffic(kernel, B) if (world == 1 and env.real) else (None, None)
         line = {
             "metric": "estimator-steps/sec (EKF+MHE, 20-step window)",
             "value": value, "unit": "estimator-steps/s", "n_gpus": world, "steps": K, "warmup": W, "window_fill_steps_before_warmup": fill,
@@ -299,7 +317,7 @@ def run_bench(args, env, rank, world):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "k_mhe_solve", "avg_launch_ms": avg_solve_s * 1e3, "launches": solve_n,
+                         "kernel": kernel, "avg_launch_ms": avg_solve_s * 1e3, "launches": solve_n,
                          "alg_bytes_per_step": B_ALG_GO1, "units_per_launch": B,
                          # the contract's roofline is the HBM one; what actually limits this kernel is the chain of
                          # dependent mat-vec steps inside every ADMM iteration, so both honest fractions ride along:

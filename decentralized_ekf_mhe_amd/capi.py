@@ -16,6 +16,7 @@ DEKF_OK, DEKF_ERR_INVALID, DEKF_ERR_NO_DEVICE, DEKF_ERR_HIP, DEKF_ERR_ORDER, DEK
 DEKF_HOST, DEKF_DEVICE = 0, 1
 DEKF_SOLVE_NONE, DEKF_SOLVE_OK, DEKF_SOLVE_MAX_ITER, DEKF_SOLVE_NUMERIC = 0, 1, 2, -1
 DEKF_UNIQUE_ID_BYTES = 128
+DEKF_ABI_VERSION = 2  # include/dekf.h; the ctypes mirror of dekf_params (params.py) is laid out for exactly this version
 
 _dp, _ip, _vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
 
@@ -45,6 +46,7 @@ PROTOTYPES = {
     "dekf_timing_enable": (C.c_int, [_vp, C.c_int]),
     "dekf_timing_read": (C.c_int, [_vp, _dp, _ip]),
     "dekf_launch_info": (C.c_int, [_vp, _ip, _ip, _dp]),
+    "dekf_solve_kernel_name": (C.c_char_p, [_vp, C.c_int]),
     "dekf_comm_unique_id": (C.c_int, [_vp]),
     "dekf_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dekf_allgather_vb": (C.c_int, [_vp, _vp]),
@@ -61,8 +63,16 @@ def load():
             raise RuntimeError(f"{LIB_PATH} is missing: build it with decentralized_ekf_mhe_amd/csrc/build.sh "
                                "(python -c 'import __graft_entry__ as g; g.build()'); there is no fallback path")
         lib = C.CDLL(LIB_PATH)
+        # a stale prebuilt library (the .so is git-ignored) would be handed a parameter block of the wrong layout
+        lib.dekf_abi_version.restype = C.c_int
+        have = lib.dekf_abi_version()
+        if have != DEKF_ABI_VERSION:
+            raise RuntimeError(f"{LIB_PATH} implements ABI version {have}, this package binds version {DEKF_ABI_VERSION}: "
+                               "rebuild it with decentralized_ekf_mhe_amd/csrc/build.sh")
         for name, (res, args) in PROTOTYPES.items():
-            fn = getattr(lib, name)
+            fn = getattr(lib, name, None)
+            if fn is None:
+                raise RuntimeError(f"{LIB_PATH} does not export {name}: rebuild it with decentralized_ekf_mhe_amd/csrc/build.sh")
             fn.restype = res
             fn.argtypes = args
         _lib = lib

@@ -118,6 +118,12 @@ namespace dekf_shim {
 inline void check(dekf_status st) {
     if (st != DEKF_OK) throw std::runtime_error(std::string("dekf: ") + dekf_last_error());
 }
+// the header this shim was compiled against and the library it is linked to must agree on the layout of dekf_params
+inline void check_abi() {
+    if (dekf_abi_version() != DEKF_ABI_VERSION)
+        throw std::runtime_error("dekf: libdekf.so implements ABI version " + std::to_string(dekf_abi_version()) + ", this shim was compiled against " +
+                                 std::to_string(DEKF_ABI_VERSION) + " (rebuild decentralized_ekf_mhe_amd/csrc)");
+}
 inline void copy3(double* dst, const std::vector<double>& src, const char* name) {
     if (src.size() < 3) throw std::invalid_argument(std::string("robot_params.") + name + " needs 3 entries");
     for (int i = 0; i < 3; ++i) dst[i] = src[(size_t)i];
@@ -169,6 +175,7 @@ class DecentralizedEstimation {
         params_ptr_ = params;
         prm_ = dekf_shim::to_dekf_params(*params);
         if (h_) { dekf_destroy(h_); h_ = nullptr; }
+        dekf_shim::check_abi();
         dekf_shim::check(dekf_create(&prm_, 1, device, nullptr, &h_));
         dim_state_ = 9 + 3 * prm_.leg_odom_type * prm_.num_legs;  // DecentralEst.cpp:20
         x_MHE_.resize(dim_state_);
@@ -272,7 +279,10 @@ class DecentralizedEstimation {
 // run one timer step on the GPU, read the quaternion that is published on imu/filter.
 class OrientationEkf {
   public:
-    explicit OrientationEkf(const dekf_params& p, int device = 0) { dekf_shim::check(dekf_create(&p, 1, device, nullptr, &h_)); }
+    explicit OrientationEkf(const dekf_params& p, int device = 0) {
+        dekf_shim::check_abi();
+        dekf_shim::check(dekf_create(&p, 1, device, nullptr, &h_));
+    }
     ~OrientationEkf() { if (h_) dekf_destroy(h_); }
     OrientationEkf(const OrientationEkf&) = delete;
     OrientationEkf& operator=(const OrientationEkf&) = delete;

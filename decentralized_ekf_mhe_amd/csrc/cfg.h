@@ -22,6 +22,7 @@ namespace dekf {
 #define DEKF_SOLVE_THREADS 256  // lanes of the workgroup that solves one instance (4 wavefronts)
 #endif
 
+constexpr int DEKF_PROF_SLOTS = 32;  // section stamps per instance, diagnostic build only (DevState::prof)
 constexpr double OSQP_INFTY = 1e30;
 constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e6, RHO_EQ_OVER_RHO_INEQ = 1e3, RHO_TOL = 1e-4;
 constexpr double MIN_SCALING = 1e-4, MAX_SCALING = 1e4;
@@ -35,6 +36,7 @@ struct DevCfg {
     int wcap;             // N+1 window records
     int rec;              // doubles per window record
     int est_type;
+    int marg_info;        // leg_odom_type 1: fold a step into the arrival cost in information form (dekf_params.arrival_cost_form)
     double dt;
     // estimator constants (DecentralEst.cpp:39-51, 236-253)
     double C_p[3], C_accel[3], C_accel_bias[3], C_gyro[3];
@@ -155,7 +157,7 @@ struct DevState {
     double *x_mhe, *v_b;
     int *status, *iters, *rho_updates;
     double *pri_res, *dua_res;
-    double* prof;  // [B][16] section cycles, written by the diagnostic (-DDEKF_PROFILE) build only
+    double* prof;  // [B][DEKF_PROF_SLOTS] section cycles, written by the diagnostic (-DDEKF_PROFILE) build only
 };
 
 }  // namespace dekf

@@ -77,6 +77,7 @@ struct dekf_handle_s {
     void (*solve_kernel_full)(DevCfg, DevState, int, int, int) = nullptr;
     int solve_grid_full = 0;
     size_t lds_solve_full = 0;
+    const char *solve_name = nullptr, *solve_name_full = nullptr;  // kernel symbols, for dekf_solve_kernel_name
     size_t lds_solve = 0, lds_asm = 0, lds_kf = 0;
     int ekf_count = 0, pushes = 0, next_T = 0;
     bool initialized = false;
@@ -219,25 +220,30 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     // diagnostic build only: DEKF_DEBUG_LDS_PAD=<bytes> inflates the request (e.g. to force one workgroup per CU)
     if (const char* pad = getenv("DEKF_DEBUG_LDS_PAD")) h->lds_solve += (size_t)atol(pad);
 #endif
+    typedef void (*SolveFn)(DevCfg, DevState, int, int, int);
     {
-        typedef void (*SolveFn)(DevCfg, DevState, int, int, int);
-        static const SolveFn table[4][3] = {
-            {k_mhe_solve_ll_1, k_mhe_solve_lg_1, k_mhe_solve_gg_1}, {k_mhe_solve_ll_2, k_mhe_solve_lg_2, k_mhe_solve_gg_2},
-            {k_mhe_solve_ll_3, k_mhe_solve_lg_3, k_mhe_solve_gg_3}, {k_mhe_solve_ll_4, k_mhe_solve_lg_4, k_mhe_solve_gg_4}};
-        h->solve_kernel = table[c.L - 1][lay.pa_in_lds() ? 0 : (lay.factor_in_lds() ? 1 : 2)];
-        if (c.L == 4 && c.N == 20 && lay.pa_in_lds()) h->solve_kernel = k_mhe_solve_ll_4_n20;
-        if (c.L == 2 && c.N == 20 && lay.factor_in_lds() && !lay.pa_in_lds()) h->solve_kernel = k_mhe_solve_lg_2_n20;
+        struct Named { SolveFn fn; const char* name; };
+#define DEKF_K(sym) {sym, #sym}
+        static const Named table[4][3] = {
+            {DEKF_K(k_mhe_solve_ll_1), DEKF_K(k_mhe_solve_lg_1), DEKF_K(k_mhe_solve_gg_1)}, {DEKF_K(k_mhe_solve_ll_2), DEKF_K(k_mhe_solve_lg_2), DEKF_K(k_mhe_solve_gg_2)},
+            {DEKF_K(k_mhe_solve_ll_3), DEKF_K(k_mhe_solve_lg_3), DEKF_K(k_mhe_solve_gg_3)}, {DEKF_K(k_mhe_solve_ll_4), DEKF_K(k_mhe_solve_lg_4), DEKF_K(k_mhe_solve_gg_4)}};
+        Named pick = table[c.L - 1][lay.pa_in_lds() ? 0 : (lay.factor_in_lds() ? 1 : 2)];
+        if (c.L == 4 && c.N == 20 && lay.pa_in_lds()) pick = DEKF_K(k_mhe_solve_ll_4_n20);
+        if (c.L == 2 && c.N == 20 && lay.factor_in_lds() && !lay.pa_in_lds()) pick = DEKF_K(k_mhe_solve_lg_2_n20);
         if (c.ft) {  // foot-position states: their own kernel family (two rows per block in the solve)
-            static const SolveFn foot[4][2] = {{k_mhe_solve_foot_lg_1, k_mhe_solve_foot_gg_1}, {k_mhe_solve_foot_lg_2, k_mhe_solve_foot_gg_2},
-                                               {k_mhe_solve_foot_lg_3, k_mhe_solve_foot_gg_3}, {k_mhe_solve_foot_lg_4, k_mhe_solve_foot_gg_4}};
-            h->solve_kernel = foot[c.L - 1][lay.factor_in_lds() ? 0 : 1];
+            static const Named foot[4][2] = {{DEKF_K(k_mhe_solve_foot_lg_1), DEKF_K(k_mhe_solve_foot_gg_1)}, {DEKF_K(k_mhe_solve_foot_lg_2), DEKF_K(k_mhe_solve_foot_gg_2)},
+                                             {DEKF_K(k_mhe_solve_foot_lg_3), DEKF_K(k_mhe_solve_foot_gg_3)}, {DEKF_K(k_mhe_solve_foot_lg_4), DEKF_K(k_mhe_solve_foot_gg_4)}};
+            pick = foot[c.L - 1][lay.factor_in_lds() ? 0 : 1];
         }
+        h->solve_kernel = pick.fn;
+        h->solve_name = pick.name;
 #ifdef DEKF_PROFILE
         // diagnostic build only: DEKF_DEBUG_PLACEMENT=1|2 forces the _lg / _gg placement (2 also shrinks the LDS request)
         if (const char* pl = getenv("DEKF_DEBUG_PLACEMENT")) {
             int p = atoi(pl);
-            if ((p == 1 || p == 2) && !c.ft) h->solve_kernel = table[c.L - 1][p];
-            if (p == 2) h->lds_solve = (size_t)lay.vec * sizeof(double);
+            if ((p == 1 || p == 2) && !c.ft) { h->solve_kernel = table[c.L - 1][p].fn; h->solve_name = table[c.L - 1][p].name; }
+            // the _gg kernels carve D, E, bounds and R behind the iterates when SolveLayout::gg_consts_in_lds() says so
+            if (p == 2) h->lds_solve = (size_t)(lay.vec + (lay.gg_consts_in_lds() ? lay.gg_consts() : 0)) * sizeof(double);
         }
 #endif
     }
@@ -252,18 +258,33 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     int per_cu = 1;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)h->solve_kernel, DEKF_SOLVE_THREADS, h->lds_solve) != hipSuccess || per_cu < 1)
         per_cu = 1;
+    const int cap = p->solve_workgroups_per_cu;  // 0: no cap
+    if (cap > 0 && per_cu > cap) per_cu = cap;
     long slots = (long)per_cu * prop.multiProcessorCount;
     h->solve_grid = (int)(slots < batch ? slots : batch);
 #ifndef DEKF_NO_R3
-    if (!c.ft && c.N == 20 && (c.L == 4 || c.L == 2) && lay.r3_fits(c.L) && !getenv("DEKF_DISABLE_R3")) {
-        h->solve_kernel_full = c.L == 4 ? k_mhe_solve_r3_4_n20 : k_mhe_solve_r3_2_n20;
-        h->lds_solve_full = lay.r3_lds_bytes();
-        int pcf = 1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pcf, (const void*)h->solve_kernel_full, DEKF_SOLVE_THREADS, h->lds_solve_full) != hipSuccess || pcf < 1)
-            pcf = 1;
-        const long sf = (long)pcf * prop.multiProcessorCount;
-        h->solve_grid_full = (int)(sf < batch ? sf : batch);
-        if (pcf <= per_cu) h->solve_kernel_full = nullptr;  // no residency gained: keep one kernel
+    if (!c.ft && c.N == 20 && (c.L == 4 || c.L == 2) && (cap == 0 || cap > per_cu)) {
+        const SolveFn full = c.L == 4 ? k_mhe_solve_r3_4_n20 : k_mhe_solve_r3_2_n20;
+        // the kernel's static LDS (reduction scratch of wave.h) counts against the same allocation as the dynamic part
+        hipFuncAttributes fa;
+        size_t static_lds = 512;
+        if (hipFuncGetAttributes(&fa, (const void*)full) == hipSuccess) static_lds = fa.sharedSizeBytes;
+        if (lay.r3_fits(c.L, static_lds)) {
+            h->lds_solve_full = lay.r3_lds_bytes();
+            int pcf = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pcf, (const void*)full, DEKF_SOLVE_THREADS, h->lds_solve_full) != hipSuccess || pcf < 1)
+                pcf = 1;
+            if (pcf > DEKF_R3_WAVES) pcf = DEKF_R3_WAVES;  // the query over-reports: r3_fits has decided that DEKF_R3_WAVES fit
+            if (cap > 0 && pcf > cap) pcf = cap;
+            const long sf = (long)pcf * prop.multiProcessorCount;
+            h->solve_grid_full = (int)(sf < batch ? sf : batch);
+            // only where the batch really fills more slots than the two-workgroup kernel offers: below that the row state
+            // would travel through the slab for no residency gained
+            if (pcf > per_cu && h->solve_grid_full > h->solve_grid) {
+                h->solve_kernel_full = full;
+                h->solve_name_full = c.L == 4 ? "k_mhe_solve_r3_4_n20" : "k_mhe_solve_r3_2_n20";
+            }
+        }
     }
 #endif
     const int solve_slots = h->solve_kernel_full && h->solve_grid_full > h->solve_grid ? h->solve_grid_full : h->solve_grid;
@@ -573,11 +594,16 @@ dekf_status dekf_launch_info(dekf_handle h, int* solve_workgroups, int* compute_
     return DEKF_OK;
 }
 
-// not part of include/dekf.h: section cycles [B][16] of the last solve; all zero unless this
+const char* dekf_solve_kernel_name(dekf_handle h, int full_window) {
+    if (!h || h->c.est_type != 0) return nullptr;
+    return (full_window && h->solve_kernel_full) ? h->solve_name_full : h->solve_name;
+}
+
+// not part of include/dekf.h: section cycles [B][DEKF_PROF_SLOTS] of the last solve; all zero unless this
 // library was built with -DDEKF_PROFILE (libdekf_prof.so, tools/profile_sections.py)
 dekf_status dekf_debug_sections(dekf_handle h, double* out_host) {
     if (!h || !out_host) return fail(DEKF_ERR_INVALID, "null argument");
-    HIPCHK(hipMemcpyAsync(out_host, h->s.prof, 16 * (size_t)h->c.B * 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipMemcpyAsync(out_host, h->s.prof, DEKF_PROF_SLOTS * (size_t)h->c.B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return DEKF_OK;
 }

@@ -42,6 +42,7 @@ inline void default_params(dekf_params* p) {
     set3(p->ekf_gravity_meas_std, 4.0, 4.0, 4.0);
     p->ekf_quaternion_init[0] = 1.0;
     p->ekf_rate = 500; p->ekf_history = 64;
+    p->arrival_cost_form = 0; p->solve_workgroups_per_cu = 0;
 }
 
 // returns nullptr when ok, else a message
@@ -55,6 +56,13 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     if (p.rate < 1 || p.ekf_rate < 1) return "rate must be positive";
     if (p.ekf_history < 4) return "ekf_history must be >= 4";
     if (p.polish) return "osqp.polish = true is not implemented";
+    if (p.arrival_cost_form != 0 && p.arrival_cost_form != 1) return "arrival_cost_form must be 0 (reference form) or 1 (information form)";
+    if (p.solve_workgroups_per_cu < 0 || p.solve_workgroups_per_cu > 8) return "solve_workgroups_per_cu out of range [0,8]";
+    if (p.leg_odom_type == 1) {  // these become gains 1 / std^2 (DecentralEst.cpp:47-51): a zero would be an infinite weight
+        for (int i = 0; i < 3; ++i)
+            if (!(p.foot_slide_std[i] > 0) || !(p.foot_init_std[i] > 0) || !(p.foot_swing_std[i] > 0))
+                return "leg_odom_type 1 needs positive foot_slide_std, foot_init_std and foot_swing_std";
+    }
     if (!(p.sigma > 0) || !(p.rho > 0) || !(p.alpha > 0 && p.alpha < 2)) return "rho/sigma/alpha out of range";
     std::memset(&c, 0, sizeof(c));
     c.B = B; c.L = p.num_legs; c.nj = p.joints_per_leg; c.N = p.N; c.nm = 3 * p.num_legs;
@@ -62,6 +70,7 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     c.SV = 2 * c.ns + c.nm + 3; c.SC = c.nm + c.ns + 3;
     c.ring = 4 * p.N + 1; c.wcap = p.N + 1; c.rec = Rec::len(c.L, c.ft);
     c.est_type = p.est_type;
+    c.marg_info = p.leg_odom_type == 1 && p.arrival_cost_form == 1;
     c.dt = 1.0 / (double)p.rate;
     auto sq = [](double v) { return v * v; };
     for (int i = 0; i < 3; ++i) {
@@ -125,7 +134,7 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
     s.x_mhe = D(ns * B); s.v_b = D(3 * B);
     s.status = I(B); s.iters = I(B); s.rho_updates = I(B);
     s.pri_res = D(B); s.dua_res = D(B);
-    s.prof = D(16 * B);
+    s.prof = D(DEKF_PROF_SLOTS * B);
 }
 
 }  // namespace dekf

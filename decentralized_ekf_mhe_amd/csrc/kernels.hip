@@ -49,6 +49,11 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
 #ifndef DEKF_SOLVE_MIN_WAVES
 #define DEKF_SOLVE_MIN_WAVES 2
 #endif
+// -DDEKF_GO1_ONLY (A/B builds of the benchmark shape, tools/ab_variants.sh): every solve kernel but the two Go1 N = 20
+// ones is an empty stub, which cuts the build from minutes to seconds.  Such a library solves nothing but Go1, N = 20.
+#ifdef DEKF_GO1_ONLY
+#define DEKF_SOLVE_KERNEL(NAME, LEGS, FL, PL) __global__ void NAME(DevCfg, DevState, int, int, int) {}
+#else
 #define DEKF_SOLVE_KERNEL(NAME, LEGS, FL, PL)                                                            \
     __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_SOLVE_MIN_WAVES) NAME(DevCfg c, DevState s, int kstart, int K, \
                                                                   int gws_len) {                         \
@@ -57,6 +62,7 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
         for (int b = blockIdx.x; b < c.B; b += gridDim.x)                                                \
             solve_window<LEGS, FL, PL>(c, s, b, kstart, K, lds, gws);                                    \
     }
+#endif
 #define DEKF_SOLVE_KERNELS(LEGS)                            \
     DEKF_SOLVE_KERNEL(k_mhe_solve_ll_##LEGS, LEGS, true, true)   \
     DEKF_SOLVE_KERNEL(k_mhe_solve_lg_##LEGS, LEGS, true, false)  \
@@ -69,12 +75,17 @@ extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) k_mhe_solve_
     for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<4, true, true, 20>(c, s, b, kstart, K, lds, gws);
 }
 // Cassie (2 legs, N = 20; its factor-time temporary does not fit next to the vectors: _lg placement)
+#ifdef DEKF_GO1_ONLY
+extern "C" __global__ void k_mhe_solve_lg_2_n20(DevCfg, DevState, int, int, int) {}
+extern "C" __global__ void k_mhe_solve_r3_2_n20(DevCfg, DevState, int, int, int) {}
+#else
 extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) k_mhe_solve_lg_2_n20(DevCfg c, DevState s, int kstart, int K,
                                                                                    int gws_len) {
     extern __shared__ double lds[];
     double* gws = s.gws + (size_t)blockIdx.x * gws_len;
     for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<2, true, false, 20>(c, s, b, kstart, K, lds, gws);
 }
+#endif
 // Full windows of the two fixed-horizon shapes: THREE workgroups per CU (mhe_admm_core.h, admm_chunk_r3: row state in registers,
 // 45 KiB of LDS per instance, 168 VGPRs).  The window-fill ticks (K < N) keep the two-workgroup kernels above.
 #ifndef DEKF_NO_R3
@@ -84,12 +95,14 @@ extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_R3_WAVES) 
     double* gws = s.gws + (size_t)blockIdx.x * gws_len;
     for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<4, true, true, 20, 0, true>(c, s, b, kstart, K, lds, gws);
 }
+#ifndef DEKF_GO1_ONLY
 extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_R3_WAVES) k_mhe_solve_r3_2_n20(DevCfg c, DevState s, int kstart, int K,
                                                                                    int gws_len) {
     extern __shared__ double lds[];
     double* gws = s.gws + (size_t)blockIdx.x * gws_len;
     for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<2, true, true, 20, 0, true>(c, s, b, kstart, K, lds, gws);
 }
+#endif
 #endif
 DEKF_SOLVE_KERNELS(1)
 DEKF_SOLVE_KERNELS(2)
@@ -98,6 +111,9 @@ DEKF_SOLVE_KERNELS(4)
 // leg_odom_type 1: the foot positions are states (9 + 3 LEGS per window step, 21 for Go1).  Two placements: factor in
 // LDS with the factor-time temporary in HBM (short windows), factor streamed from the workgroup's HBM slab (Go1, N = 20:
 // S^-1 and W alone are 141 KB).
+#ifdef DEKF_GO1_ONLY
+#define DEKF_SOLVE_KERNEL_FOOT(NAME, LEGS, FL) __global__ void NAME(DevCfg, DevState, int, int, int) {}
+#else
 #define DEKF_SOLVE_KERNEL_FOOT(NAME, LEGS, FL)                                                                \
     __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_SOLVE_MIN_WAVES) NAME(DevCfg c, DevState s, int kstart, int K, \
                                                                   int gws_len) {                             \
@@ -106,6 +122,7 @@ DEKF_SOLVE_KERNELS(4)
         for (int b = blockIdx.x; b < c.B; b += gridDim.x)                                                    \
             solve_window<LEGS, FL, false, 0, 1>(c, s, b, kstart, K, lds, gws);                               \
     }
+#endif
 #define DEKF_SOLVE_KERNELS_FOOT(LEGS)                               \
     DEKF_SOLVE_KERNEL_FOOT(k_mhe_solve_foot_lg_##LEGS, LEGS, true)  \
     DEKF_SOLVE_KERNEL_FOOT(k_mhe_solve_foot_gg_##LEGS, LEGS, false)

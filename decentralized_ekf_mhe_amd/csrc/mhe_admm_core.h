@@ -1597,6 +1597,7 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
 #endif
     if (w == 0) {
         DEKF_SYNC();  // B0: w, gb of the (re)start complete
+        DEKF_PROF_MARK(q, 14);
         for (int it = 0; it < iters; ++it) {
             DEKF_R3_T(t0);
             DEKF_SYNC();  // B1
@@ -1645,8 +1646,10 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
         row_regs_store(q, t);
     }
 #undef DEKF_R3_T
+    DEKF_PROF_MARK(q, 9);
     DEKF_SYNC();
     wfor(9 * NF, [&](int e) { const int k = e / 9; q.x[k * SV + e - 9 * k] = q.xb[e]; });
+    DEKF_PROF_MARK(q, 15);
 }
 #endif
 
@@ -1732,6 +1735,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
         int k = e / NS, j = e - NS * k;
         xd[e] = D[k * SV + j] * x[k * SV + j];
     });
+    DEKF_PROF_MARK(q, 20);
     double acc[14];
 #pragma unroll
     for (int r = 0; r < 14; ++r) acc[r] = 0.0;
@@ -1905,6 +1909,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             acc[13] = dmax(acc[13], fabs(Px));
         }
     });
+    DEKF_PROF_MARK(q, 21);
 #pragma unroll
     for (int r = 0; r < 14; ++r) acc[r] = wave_max(acc[r]);
     group_combine<14, false>(acc);

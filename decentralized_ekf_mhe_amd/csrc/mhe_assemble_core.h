@@ -19,7 +19,8 @@ struct AsmScratch {
     DEKF_HD static int len(int L, int ft = 0) {
         const int ns = 9 + (ft ? 3 * L : 0), na = ns + 3, dim = na + 3 * L;
         return ns * ns /*Minv*/ + 2 * na * ns /*Am, AmMi*/ + dim * dim /*S*/ + 2 * dim /*pivot row, column*/ +
-               dim /*u*/ + dim /*Yu*/ + ns /*M^-1 n*/ + 3 * L * ns /*H M^-1*/ + 16;
+               dim /*u*/ + dim /*Yu*/ + ns /*M^-1 n*/ + 3 * L * ns /*H M^-1*/ + 16 +
+               (ft ? dim * dim + dim : 0) /*augmented half of the pivoted inverse (foot-position states)*/;
     }
 };
 
@@ -646,7 +647,7 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
         }
     }
 #endif
-    if (ft) return marginalize_info(c, s, b, r, sm);
+    if (ft && c.marg_info) return marginalize_info(c, s, b, r, sm);
     // generic form (any state dimension): rows [Dyn (ns) | VO (3, when flagged) | Meas (nm)]
     const int na = vo ? ns + 3 : ns;
     const int dim = na + nm;
@@ -662,7 +663,11 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
     const double* R = r + Rec::R;
     const double dt = c.dt;
     wfor(ns * ns + na * ns, [&](int e) {
-        if (e < ns * ns) Minv[e] = Mp[e];
+        // M enters through its LOWER triangle, as in the reference: M^-1 comes from Eigen's SimplicialLLT (default UpLo = Lower,
+        // MheSrb.cpp:524-525), while the QP takes the upper one (OSQP reads triu(P)).  M+ = -B' S^-1 B is symmetric only up to
+        // rounding, and with foot-position states that rounding is amplified at every swing phase (measured: 1e-13 -> 1e-1
+        // over three phases when both triangles feed the inverse)
+        if (e < ns * ns) { const int i = e / ns, j = e - ns * i; Minv[e] = i >= j ? Mp[e] : Mp[ns * j + i]; }
         else {
             int q = e - ns * ns, i = q / ns, j = q - ns * i;
             Am[q] = i < ns ? adyn_entry(R, dt, i, j) : ((i - ns) == j ? 1.0 : 0.0);
@@ -747,8 +752,14 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
         }
         u[i] = v;
     });
-    // S = -([A; H] M^-1 [A; H]' + blkdiag(Q^-1, R^-1)) is negative definite: no pivoting needed
-    ok = winverse_definite(S, dim, wsc) && ok;
+    // S = -([A; H] M^-1 [A; H]' + blkdiag(Q^-1, R^-1)) is negative definite: no pivoting needed — as long as its entries are of
+    // comparable size.  With foot-position states they are not: a swinging foot puts dt^2 1e14 on the diagonal next to
+    // measurement covariances of 1e-4, and elimination in natural order (small, huge, medium) loses the small entries
+    // (measured: an instance turns indefinite after 130 ticks of a 5 Hz gait).  The reference inverts this matrix with
+    // Eigen's inverse() = LU with partial pivoting (MheSrb.cpp:588,640); Gauss-Jordan with the same row-pivot rule visits
+    // the same pivots.
+    if (ft) ok = winverse(S, dim, HMi + nm * ns, true) && ok;
+    else ok = winverse_definite(S, dim, wsc) && ok;
     wfor(dim, [&](int i) {
         double sacc = 0;
         for (int t = 0; t < dim; ++t) sacc += S[i * dim + t] * u[t];

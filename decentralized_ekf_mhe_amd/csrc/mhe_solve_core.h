@@ -112,11 +112,11 @@ struct SolveLayout {
     DEKF_HD int r3_doubles() const { return 9 * K + n_pad + m_pad + ns * K + r3_pa_region() + solve_tmp_len(ns) + 2 * K * ns * ns; }
     DEKF_HD size_t r3_lds_bytes() const { return (size_t)r3_doubles() * 8; }
     // the Ruiz passes' temporaries (pc | En | Dn) sit behind the staged P blocks inside Sinv | Wk, which are not live yet
-    DEKF_HD bool r3_fits(int L) const {
+    DEKF_HD bool r3_fits(int L, size_t static_lds = 512) const {
         const int ps = K * (6 * L + 27) + ns * (ns + 1) / 2;
         // LDS is granted in coarse units: measured on gfx950, 53 464 B per workgroup (this layout + 480 B static) run three per
         // CU, 54 112 B run two although the occupancy query still answers three — consistent with a 1 280 or 1 536 B granule
-        const size_t granule = 1536, need = (r3_lds_bytes() + 512 + granule - 1) / granule * granule;
+        const size_t granule = 1536, need = (r3_lds_bytes() + static_lds + granule - 1) / granule * granule;
         return ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && DEKF_R3_WAVES * need <= 160 * 1024;
     }
     // Factor in the HBM slab (one workgroup per CU anyway): whatever LDS the iterates leave free takes the per-row constants
@@ -608,6 +608,7 @@ DEKF_FN void solve_scale(Q& q) {
 #endif
     wtiles(ntiles, [&](int tile, int lane) { (void)adopt(tile, lane); });  // column norms of P for D = 1
     DEKF_SYNC();
+    DEKF_PROF_MARK(q, 16);
     double gq[NS];  // the linear cost sits in HBM: read it once, not once per pass (a global round trip each)
 #pragma unroll
     for (int j = 0; j < NS; ++j) gq[j] = g[j];
@@ -1221,6 +1222,7 @@ DEKF_FN bool solve_factor(Q& q) {
             if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
         });
     DEKF_SYNC();
+    DEKF_PROF_MARK(q, 22);
     two_waves(
         [&] {
             bool g = factor_block(mid, mid > 0, mid < K - 1, 0, q.tmp);
@@ -1435,12 +1437,12 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     const auto& ix = q.ix;
     SolveInfo info{0, DEKF_SOLVE_MAX_ITER, 0, 0.0, 0.0, c.rho0};
 
-    q.prof = s.prof + 16 * (size_t)b;
+    q.prof = s.prof + DEKF_PROF_SLOTS * (size_t)b;
 #if defined(DEKF_PROFILE) && DEKF_DEVICE_BUILD
     q.prof_last = clock64();
     const long long prof_t0 = q.prof_last;
     if (DEKF_LANE() == 0)
-        for (int i = 0; i < 16; ++i) q.prof[i] = 0.0;
+        for (int i = 0; i < DEKF_PROF_SLOTS; ++i) q.prof[i] = 0.0;
 #endif
     wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });
     if constexpr (R3) {
@@ -1475,6 +1477,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         y[r] = 0.0;
         at[r] = 0.0;  // u = rho z - y of the cold start
     });
+    DEKF_PROF_MARK(q, 19);
     bool ok = solve_factor(q);
     // scaled linear cost on x_0 (LDS copy for the per-lane look-ups)
     wfor(NS, [&](int j) { q.tmp[TM::QSL + j] = q.cc * q.D[ix.x(0, j)] * q.np[j]; });

@@ -162,6 +162,11 @@ class BatchedEstimator:
         capi.check(self.lib.dekf_launch_info(self.h, C.byref(wg), C.byref(cu), C.byref(hz)))
         return dict(solve_workgroups=wg.value, compute_units=cu.value, clock_hz=hz.value)
 
+    def solve_kernel_name(self, full_window=True):
+        """symbol of the solve kernel this handle launches (full windows / window-fill ticks); None for a KF handle"""
+        n = self.lib.dekf_solve_kernel_name(self.h, int(bool(full_window)))
+        return n.decode() if n else None
+
     # ---- multi-GPU --------------------------------------------------------------------
     def comm_init(self, world, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, capi.DEKF_UNIQUE_ID_BYTES)

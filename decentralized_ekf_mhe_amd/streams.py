@@ -79,8 +79,9 @@ def leg_kinematics(q, leg, nj):
 
 
 def make_streams(params, batch, nsteps, first_instance=0, vo=True, vo_rate=30.0, vo_latency=0.03,
-                 seed0=SEED0):
-    """Return a dict of [nsteps][batch][...] arrays (+ ground truth under 'gt_*')."""
+                 seed0=SEED0, gait_hz=2.0):
+    """Return a dict of [nsteps][batch][...] arrays (+ ground truth under 'gt_*').  gait_hz: contact cycles per second
+    (2 Hz trot, 60 % duty); the long-run parity cases raise it to pack more swing phases into a log."""
     L, nj = params.num_legs, params.joints_per_leg
     dt = 1.0 / params.rate
     B, K = batch, nsteps
@@ -139,9 +140,9 @@ def make_streams(params, batch, nsteps, first_instance=0, vo=True, vo_rate=30.0,
     nominal = np.array([0.0] + [0.8, -1.6] * nj)[:nj]
     n_qd = np.stack([r.normal(0, 1.0, (K, L, nj)) for r in rngs], axis=1)
     for leg in range(L):
-        cyc = (2.0 * t + gait_phase[leg] + ph[:, 5] / (2 * np.pi)) % 1.0
+        cyc = (gait_hz * t + gait_phase[leg] + ph[:, 5] / (2 * np.pi)) % 1.0
         contact[:, :, leg] = (cyc < 0.6).astype(np.float64)
-        q = nominal + 0.3 * np.sin(2 * np.pi * 2.0 * t[..., None] + ph[:, 6, None] + leg + np.arange(nj))
+        q = nominal + 0.3 * np.sin(2 * np.pi * gait_hz * t[..., None] + ph[:, 6, None] + leg + np.arange(nj))
         q_joint[:, :, leg] = q
         p, Jl = leg_kinematics(q, leg, nj)
         p_foot[:, :, leg] = p

@@ -10,7 +10,8 @@
  * vo_nonlinear_correct driven by orien_ekf::timerCallback
  *         (src/orien_est/include/orien_ekf.hpp:79-81, src/orien_est/src/orien_ekf.cpp:77-106).
  * Every entry point below names the reference interface it replaces.  The batch
- * dimension B (independent robot instances, one wavefront each on the GPU) is new.
+ * dimension B (independent robot instances; on the GPU the solve gives each one a workgroup of four
+ * wavefronts, the EKF one lane, term construction one wavefront) is new.
  *
  * Conventions
  *  - plain pointers + sizes, no C++/torch types; all arrays are instance-major
@@ -31,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DEKF_ABI_VERSION 1
+#define DEKF_ABI_VERSION 2 /* 2: dekf_params.solve_workgroups_per_cu, dekf_solve_kernel_name, dekf_launch_info; dim_state-sized rows */
 #define DEKF_MAX_LEGS 4
 #define DEKF_MAX_JOINTS 8 /* joints per leg */
 
@@ -71,7 +72,11 @@ typedef struct dekf_params {
     int num_legs;       /* leg_odom.num_leg */
     int joints_per_leg; /* 3 on Go1 (hard-coded block<3,3> in the reference) */
     int leg_odom_type;  /* 0: foot-velocity measurements, dim_state 9.  1: foot positions are states,
-                         * dim_state = 9 + 3 num_legs (21 on Go1), DecentralEst.cpp:20 */
+                         * dim_state = 9 + 3 num_legs (21 on Go1), DecentralEst.cpp:20.
+                         * Deviation for type 1: the arrival cost is updated in INFORMATION form (same cost in exact
+                         * arithmetic), not through the covariance-form saddle inverse of MheSrb.cpp:527-651, which
+                         * loses the measurement information of a swinging foot (covariance dt^2 * 1e14) to rounding;
+                         * agreement with the reference form is tested over long runs. */
     double joint_position_std[DEKF_MAX_JOINTS];
     double joint_velocity_std[DEKF_MAX_JOINTS];
     double foot_slide_std[3];
@@ -100,7 +105,15 @@ typedef struct dekf_params {
     double ekf_vo_meas_std[4];
     double ekf_quaternion_init[4];  /* w x y z */
     int ekf_rate;                   /* 500 */
-    int ekf_history;                /* depth of the rewind ring (reference: unbounded) */
+    int ekf_history;                /* depth of the rewind ring (reference: unbounded); size it as
+                                     * ceil(worst VO pose latency * ekf_rate) + 2, INTEGRATION.md section 5 */
+    int arrival_cost_form;          /* leg_odom_type 1 only.  0: the reference's covariance-form saddle inverse
+                                     * (MheSrb.cpp:527-651).  1: information form (same arrival cost in exact arithmetic,
+                                     * computed from gains only). leg_odom_type 0 always uses the reference form. */
+    /* launch tuning (new) */
+    int solve_workgroups_per_cu;    /* 0: as many as the CU holds (3 for full Go1 / Cassie windows); 1 or 2: cap —
+                                     * 2 keeps the two-workgroup solve kernels for full windows too (bit-identical
+                                     * results: the A/B and the identity test use it) */
 } dekf_params;
 
 typedef struct dekf_handle_s* dekf_handle;
@@ -203,6 +216,10 @@ dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches);
  * ceil(B / solve_workgroups) instances back to back per launch), the compute units and the engine clock in Hz —
  * what a caller needs to turn a launch time into cycles per solve. Any pointer may be NULL. */
 dekf_status dekf_launch_info(dekf_handle h, int* solve_workgroups, int* compute_units, double* clock_hz);
+/* Name of the solve kernel this handle launches for full windows (full_window != 0) or for the window-fill ticks,
+ * e.g. "k_mhe_solve_r3_4_n20": lets a caller match profiler output (rocprofv3 kernel names) to the run. NULL for a
+ * KF handle. The string lives as long as the library. */
+const char* dekf_solve_kernel_name(dekf_handle h, int full_window);
 
 /* ---- multi-GPU (new: the reference is single-robot) ------------------------------ */
 /* All-gather of the fused base velocity over RCCL: every rank contributes its

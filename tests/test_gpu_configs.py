@@ -306,18 +306,22 @@ def test_rccl_allgather_two_ranks_equals_single_rank_results(tmp_path):
 
 
 @pytest.mark.parametrize("maker", [go1_params, cassie_params], ids=["go1", "cassie"])
-def test_three_workgroup_kernel_is_bit_identical_to_the_two_workgroup_kernel(maker, monkeypatch):
+def test_three_workgroup_kernel_is_bit_identical_to_the_two_workgroup_kernel(maker):
     """Full windows of the fixed-horizon shapes run k_mhe_solve_r3_* (three workgroups per CU, row state in registers);
-    DEKF_DISABLE_R3 keeps the two-workgroup kernel for every tick.  Same operations in the same order: the states, the
+    dekf_params.solve_workgroups_per_cu = 2 keeps the two-workgroup kernel for every tick.  Same operations in the same order: the states, the
     residuals and the iteration counts must agree to the last bit, at a batch that uses all 768 slots unevenly."""
     p = maker()
     p.ekf_rate = p.rate
     B, K = 1000, p.N + 12
     sd = streams_to_device(make_streams(p, B, K))
 
-    def run():
-        est = BatchedEstimator(p, B)
+    def run(cap):
+        q = p.copy()
+        q.solve_workgroups_per_cu = cap
+        est = BatchedEstimator(q, B)
         wg = est.launch_info()["solve_workgroups"]
+        assert ("_r3_" in est.solve_kernel_name(True)) == (cap == 0), est.solve_kernel_name(True)
+        assert "_r3_" not in est.solve_kernel_name(False)
         for k in range(K):
             est.push_stream_step(sd, k)
             est.step(k)
@@ -325,10 +329,8 @@ def test_three_workgroup_kernel_is_bit_identical_to_the_two_workgroup_kernel(mak
         est.close()
         return wg, o, info
 
-    monkeypatch.delenv("DEKF_DISABLE_R3", raising=False)
-    wg3, o3, i3 = run()
-    monkeypatch.setenv("DEKF_DISABLE_R3", "1")
-    wg2, o2, i2 = run()
+    wg3, o3, i3 = run(0)
+    wg2, o2, i2 = run(2)
     assert wg3 > wg2, (wg3, wg2)  # the three-workgroup kernel really was selected (more resident workgroups)
     assert (o3["status"] == 1).all() and (o2["status"] == 1).all()
     for key in ("x", "v_b", "quat"):

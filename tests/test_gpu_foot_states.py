@@ -43,6 +43,54 @@ def test_go1_foot_states_every_step_matches_oracle():
     assert (it[1:] == it_ref[1:]).mean() > 0.98
 
 
+def _base_and_foot_err(x, ref):
+    """worst error over tolerance of the base blocks (p, v, accel bias: what the node logs and publishes) and of the
+    foot-position blocks, per tick"""
+    base = np.array([block_err(x[k][..., :9], ref[k][..., :9]) for k in range(len(x))])
+    foot = np.array([block_err(x[k][..., 9:], ref[k][..., 9:]) for k in range(len(x))])
+    return base, foot
+
+
+@pytest.mark.parametrize("form", [0, 1], ids=["reference-form", "information-form"])
+def test_arrival_cost_over_many_swing_phases(form):
+    """leg_odom_type 1 over a log that takes every foot through 8 swing phases (5 Hz gait, 320 ticks, 300 marginalisations),
+    every tick against the oracle, which follows the reference's covariance-form saddle inverse (MheSrb.cpp:527-651).
+    Base states (p, v, accel bias): inside the stated tolerance at every tick, with either form of the arrival cost.
+    Foot-position states: the reference formula evaluates the information a foot regains at touch-down through a
+    1e20 - 1e20 = 1e6 cancellation (1e-2 relative noise in that block of M), so two correct implementations of it — the
+    oracle and the device's default form — already differ by a few 1e-4 relative there, and so does the information form:
+    they are held to 10 x the tolerance, and must not creep.  (tools/stress_parity.py type1-long: 32 x 2000 ticks.)"""
+    p = _params(arrival_cost_form=form)
+    B, K = 8, 320
+    s = make_streams(p, B, K, gait_hz=5.0)
+    c = s["contact"]
+    assert ((c[:-1] == 1.0) & (c[1:] == 0.0)).sum(axis=0).min() >= 7
+    x_ref, vb_ref, q_ref, _ = O.run_streams(p, s, nthreads=16)
+    x, it, st, vb, q = _run(p, s, B, K)
+    assert (st[1:] == 1).all()
+    base, foot = _base_and_foot_err(x[1:], x_ref[1:])
+    assert base.max() <= 1.0, (int(base.argmax()) + 1, base.max())
+    assert foot.max() <= 10.0, (int(foot.argmax()) + 1, foot.max())
+    assert np.abs(vb[1:] - vb_ref[1:]).max() <= 1e-4 * np.abs(vb_ref).max() + 1e-6
+    # no creep: the last quarter of the log is no worse than the first three
+    assert base[3 * K // 4:].max() <= max(2.0 * base[:3 * K // 4].max(), 0.05)
+    assert foot[3 * K // 4:].max() <= max(2.0 * foot[:3 * K // 4].max(), 0.5)
+
+
+def test_reference_form_reproduces_the_oracle_at_the_benchmark_gait():
+    """2 Hz trot, 12 instances x 130 ticks, several swing phases marginalised: with the default form the GPU
+    follows the oracle far inside the tolerance on every block — the reference's drift against the exact optimum included"""
+    p = _params()
+    assert p.arrival_cost_form == 0
+    B, K = 12, 130
+    s = make_streams(p, B, K)
+    x_ref, vb_ref, q_ref, _ = O.run_streams(p, s, nthreads=16)
+    x, it, st, vb, q = _run(p, s, B, K)
+    assert (st[1:] == 1).all()
+    base, foot = _base_and_foot_err(x[1:], x_ref[1:])
+    assert base.max() <= 0.2 and foot.max() <= 1.0, (base.max(), foot.max())
+
+
 def test_go1_foot_states_kf_mode():
     p = _params(est_type=1)
     B, K = 8, 40

@@ -1,7 +1,7 @@
 """The device cores under AddressSanitizer + UBSan (CPU build only: GPU ASan is not available on
 this pool).  A stand-alone driver links tests/hostsim/hostsim.cpp with -fsanitize=address,undefined
-and steps Go1, a 2-leg/5-joint robot and a long-horizon 1-leg robot through window fill,
-marginalisation and VO updates; any out-of-bounds index in the kernels' LDS/HBM carving aborts it."""
+and steps Go1, a 2-leg/5-joint robot, a long-horizon 1-leg robot and two leg_odom_type = 1 shapes (foot positions as states)
+through window fill, marginalisation and VO updates; any out-of-bounds index in the kernels' LDS/HBM carving aborts it."""
 import os
 import subprocess
 import sys
@@ -11,8 +11,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DRIVER = r'''
 #include "hostsim.cpp"
 #include <cstdio>
-static int run(int L, int nj, int N, int steps) {
-    dekf_params p; default_params(&p); p.ekf_rate = 200; p.num_legs = L; p.joints_per_leg = nj; p.N = N;
+static int run(int L, int nj, int N, int steps, int ft = 0) {
+    dekf_params p; default_params(&p); p.ekf_rate = 200; p.num_legs = L; p.joints_per_leg = nj; p.N = N; p.leg_odom_type = ft;
+    const int ns = 9 + 3 * L * ft;
     int B = 2;
     void* h = hs_create(&p, B);
     if (!h) return 1;
@@ -35,13 +36,15 @@ static int run(int L, int nj, int N, int steps) {
         hs_ekf_step(h);
         if (T == 0) hs_initialize(h); else hs_update(h, T);
     }
-    std::vector<double> x(9 * B); std::vector<int> st(B), it(B);
+    std::vector<double> x(ns * B); std::vector<int> st(B), it(B);
     hs_get(h, x.data(), nullptr, nullptr, nullptr, st.data(), it.data(), nullptr);
-    std::printf("L=%d nj=%d N=%d: status %d iters %d v=%g\n", L, nj, N, st[0], it[0], x[3]);
+    std::printf("L=%d nj=%d N=%d leg_odom_type=%d: status %d iters %d v=%g\n", L, nj, N, ft, st[0], it[0], x[3]);
     hs_destroy(h);
     return st[0] == 1 ? 0 : 2;
 }
-int main() { return run(4, 3, 20, 60) | run(2, 5, 8, 30) | run(1, 3, 40, 70); }
+// leg_odom_type 1 (foot positions as states, 21-dim blocks on Go1: its own solve family, factor in the slab, information-form
+// marginalisation) through window fill, marginalisation with swinging feet and VO updates; and a 2-leg shape of it
+int main() { return run(4, 3, 20, 60) | run(2, 5, 8, 30) | run(1, 3, 40, 70) | run(4, 3, 20, 34, 1) | run(2, 5, 6, 24, 1); }
 '''
 
 

@@ -15,6 +15,8 @@ done
 python3 - "$OUT" "$R" <<'PY'
 import csv, glob, json, sys
 out, root = sys.argv[1], sys.argv[2]
+sys.path.insert(0, root)
+import bench
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True)[0]
@@ -22,7 +24,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     last = rows[-6:]                      # the timed, steady-state launches
     vals[c] = sum(float(r["Counter_Value"]) for r in last) / len(last)
 fetch_b, write_b = vals["FETCH_SIZE"] * 1024 * 2, vals["WRITE_SIZE"] * 1024
-res = {"kernel": last[-1]["Kernel_Name"], "batch": 4096, "collected": "tools/collect_traffic.sh, rocprofv3 --pmc, separate passes", "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"],
+res = {"kernel": last[-1]["Kernel_Name"].split("(")[0].replace(".kd", ""), "batch": 4096, "csrc_sha1": bench.csrc_sha1(), "collected": "tools/collect_traffic.sh, rocprofv3 --pmc, separate passes", "FETCH_SIZE_KB_raw": vals["FETCH_SIZE"], "WRITE_SIZE_KB_raw": vals["WRITE_SIZE"],
        "fetch_bytes_corrected_x2": fetch_b, "write_bytes": write_b, "hbm_bytes_per_launch": fetch_b + write_b,
        "note": "separate --pmc passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950); 8-B accesses are uncalibrated"}
 json.dump(res, open(f"{root}/gpurun_out/traffic_k_mhe_solve.json", "w"), indent=1)

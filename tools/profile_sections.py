@@ -24,7 +24,10 @@ from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
 
 NAMES = ["0 copy R + Ruiz scaling", "1 bounds + first factorisation + restart", "2 X: reduced rhs on x columns",
          "3 S1: forward legs (two-wavefront form only)", "4 S2: meeting block | g_k (two-wavefront form only)", "5 S: block-tridiagonal solve on one wavefront (or S3: outward legs)", "6 factor 3a: slack blocks (both factorisations)", "7 factor 3b-3c: PA, T_kk, C_k", "8 factor 3d: block LDL'",
-         "9 R: fused row blocks", "10 residuals + termination", "11 rho update + refactor", "12 epilogue", "13 total"]
+         "9 R: fused row blocks", "10 residuals + termination", "11 rho update + refactor", "12 epilogue", "13 total",
+         "14 R3: chunk prologue (x blocks in, row blocks into registers = restart)", "15 R3: chunk epilogue (row state and x blocks back to the slab)",
+         "16 R copy, P staging, first column norms", "17 -", "18 -", "19 scaled bounds + cold start", "20 residuals: D x", "21 residuals: tile phase (state + window records)",
+         "22 block LDL': the two legs", "23 -"]
 
 
 def main():
@@ -43,7 +46,7 @@ def main():
         est.step(k)
     est.sync()
     lib = capi.load()
-    out = np.zeros((B, 16))
+    out = np.zeros((B, 32))
     lib.dekf_debug_sections.argtypes = [C.c_void_p, C.c_void_p]
     capi.check(lib.dekf_debug_sections(est.h, C.c_void_p(out.ctypes.data)))
     info = est.solver_info()
@@ -64,7 +67,9 @@ def main():
     tot = mean[13]
     res = {"batch": B, "T": K - 1, "mean_iters": float(info["iters"].mean()), "mean_rho_updates": float(info["rho_updates"].mean()),
            "total_cycles_mean": tot, "sections": {}}
-    for i, nme in enumerate(NAMES[:13]):
+    for i, nme in enumerate(NAMES):
+        if i == 13 or nme.endswith(" -") or (i > 13 and mean[i] == 0.0):
+            continue
         res["sections"][nme] = {"cycles": mean[i], "share": mean[i] / tot if tot else 0.0}
         print(f"{nme:38s} {mean[i]:12.0f} cyc  {100 * mean[i] / max(tot, 1):5.1f} %")
     print(f"{'total':38s} {tot:12.0f} cyc   iters {res['mean_iters']:.1f}  rho updates {res['mean_rho_updates']:.2f}")
