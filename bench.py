@@ -224,6 +224,8 @@ def run_bench(args, env, rank, world):
 
     p = go1_params()
     p.ekf_rate = p.rate  # one EKF tick per estimator-step, so its dt is the step
+    if getattr(args, "pipeline", False):
+        p.solve_pipeline = 1
     B, W, K = args.batch, args.warmup, args.steps
     # The metric is quoted at steady state: full window AND visual-odometry intervals active (from about tick 40 on the
     # solves need 75 ADMM iterations instead of 50).  The default warm-up of 50 steps covers that; if the caller asks for
@@ -378,6 +380,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 4096 at --gpus 1, else 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--pipeline", action="store_true", help="dekf_params.solve_pipeline = 1: consecutive steps overlap (A/B; the launch "
+                    "durations the roofline is priced on then overlap too, so the default keeps the steps in order)")
     # test hook (tests/test_bench_orchestration.py): "module:function" returning a BenchEnv for (rank, local_rank, world);
     # such a line is marked "stand_in": true and is never a measurement
     ap.add_argument("--bench-env", default=None, help=argparse.SUPPRESS)

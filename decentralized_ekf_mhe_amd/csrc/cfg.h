@@ -35,6 +35,7 @@ struct DevCfg {
     int ring;             // 4N+1 stack entries
     int wcap;             // N+1 window records
     int rec;              // doubles per window record
+    int snap_len;         // doubles per instance of the solve's input snapshot: M_p (ns^2) | n_p (ns) | VO flag + bound of every ring slot (4 wcap)
     int est_type;
     int marg_info;        // leg_odom_type 1: fold a step into the arrival cost in information form (dekf_params.arrival_cost_form)
     double dt;
@@ -146,6 +147,10 @@ struct DevState {
     double *st_time, *st_R;
     int* st_dtime;
     double *rec, *Mp, *np_;
+    // What a solve reads of the state the NEXT step's assemble overwrites (arrival cost, VO flags / bounds of the window), copied
+    // by k_mhe_assemble at its end: [B][snap_len].  Two copies exist (by parity of T, as for the outputs and the solver scratch),
+    // so that step T + 1's EKF tick and assemble can run under the tail of step T's solve (dekf_capi.hip: dekf_update).
+    double* snap;
     double *wp, *wpt;
     int* wp_count;
     double* p_vo;

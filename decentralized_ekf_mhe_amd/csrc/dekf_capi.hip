@@ -85,6 +85,16 @@ struct dekf_handle_s {
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DEKF_TIMING_CLASSES];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
+    // Step pipelining (dekf_params.solve_pipeline): the solve of step T runs on solve_stream[T & 1] out of set T & 1 of the
+    // per-solve data (input snapshot, outputs, scratch slabs), so the pushes, the EKF tick and the assemble of step T + 1 — and
+    // then its solve — start while the last round of step T's persistent workgroups is still running (a launch of B instances
+    // on S slots runs ceil(B / S) rounds, the last one partly empty: 4096 on 768 is 5.33).
+    bool pipelined = false;
+    DevState sp[2];               // sp[0] == s; sp[1]: the second set
+    hipStream_t solve_stream[2] = {nullptr, nullptr};
+    hipEvent_t ev_asm[2] = {nullptr, nullptr}, ev_solve[2] = {nullptr, nullptr};
+    bool solve_pending[2] = {false, false};
+    int last_par = 0;             // set the newest results are in
     // RCCL: the all-gather runs on its own stream out of a snapshot of v_b, so that it overlaps the next step
     void* comm = nullptr;
     int world = 1, rank = 0;
@@ -155,11 +165,18 @@ dekf_status put_many(dekf_handle h, int n, double* const* dst, const double* con
     return DEKF_OK;
 }
 
+// the handle's stream waits (no host block) for the solve that produces the newest results; getters then read in stream order
+dekf_status await_results(dekf_handle h) {
+    if (h->pipelined && h->solve_pending[h->last_par]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_solve[h->last_par], 0));
+    return DEKF_OK;
+}
+
 struct Timed {  // brackets one launch with events when timing is on
     dekf_handle h;
     int cls;
     hipEvent_t a = nullptr, b = nullptr;
-    Timed(dekf_handle h_, int cls_) : h(h_), cls(cls_) {
+    hipStream_t st;
+    Timed(dekf_handle h_, int cls_, hipStream_t st_ = nullptr) : h(h_), cls(cls_), st(st_ ? st_ : h_->stream) {
         if (!h->timing) return;
         if (!h->ev_pool.empty()) { a = h->ev_pool.back().first; b = h->ev_pool.back().second; h->ev_pool.pop_back(); }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
@@ -167,11 +184,11 @@ struct Timed {  // brackets one launch with events when timing is on
             a = b = nullptr;
             return;
         }
-        (void)hipEventRecord(a, h->stream);
+        (void)hipEventRecord(a, st);
     }
     ~Timed() {
         if (!a) return;
-        (void)hipEventRecord(b, h->stream);
+        (void)hipEventRecord(b, st);
         h->ev[cls].push_back({a, b});
     }
 };
@@ -280,6 +297,14 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             h->solve_grid_full = (int)(sf < batch ? sf : batch);
             // only where the batch really fills more slots than the two-workgroup kernel offers: below that the row state
             // would travel through the slab for no residency gained
+#ifdef DEKF_X_ALWAYS_R3  // experiment builds only: the three-workgroup kernel at a forced residency (DEKF_X_R3_CAP workgroups per CU)
+            if (const char* e = getenv("DEKF_X_R3_CAP")) {
+                const long g = (long)atoi(e) * prop.multiProcessorCount;
+                h->solve_grid_full = (int)(g < batch ? g : batch);
+                h->solve_kernel_full = full;
+                h->solve_name_full = "k_mhe_solve_r3_4_n20";
+            } else
+#endif
             if (pcf > per_cu && h->solve_grid_full > h->solve_grid) {
                 h->solve_kernel_full = full;
                 h->solve_name_full = c.L == 4 ? "k_mhe_solve_r3_4_n20" : "k_mhe_solve_r3_2_n20";
@@ -291,6 +316,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     Gws g;
     g.init(c.N, c.L, c.ft);
     h->gws_len = g.total;
+    h->pipelined = c.est_type == 0 && p->solve_pipeline == 1;
     bool ok = true;
     alloc_state(h->c, h->s, solve_slots, [&](size_t bytes) -> void* {
         void* q = nullptr;
@@ -299,10 +325,23 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
         if (hipMemsetAsync(q, 0, bytes ? bytes : 8, h->stream) != hipSuccess) ok = false;
         h->blocks.push_back(q);
         return q;
-    });
+    }, h->pipelined ? 2 : 1);
     if (!ok) {
         dekf_destroy(h);
         return fail(DEKF_ERR_HIP, "hipMalloc failed while allocating the estimator state");
+    }
+    h->sp[0] = h->s;
+    h->sp[1] = h->pipelined ? second_set(h->c, h->s, solve_slots) : h->s;
+    if (h->pipelined) {
+        for (int i = 0; i < 2 && ok; ++i) {
+            ok = hipStreamCreateWithFlags(&h->solve_stream[i], hipStreamNonBlocking) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->ev_asm[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&h->ev_solve[i], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok) {
+            dekf_destroy(h);
+            return fail(DEKF_ERR_HIP, "could not create the solve streams");
+        }
     }
     // the handle is published only once it is usable: a caller that checks the status alone leaks nothing
     const dekf_status st = dekf_reset(h);
@@ -320,6 +359,11 @@ dekf_status dekf_destroy(dekf_handle h) {
     if (!h) return DEKF_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; ++i) {
+        if (h->solve_stream[i]) { (void)hipStreamSynchronize(h->solve_stream[i]); (void)hipStreamDestroy(h->solve_stream[i]); }
+        if (h->ev_asm[i]) (void)hipEventDestroy(h->ev_asm[i]);
+        if (h->ev_solve[i]) (void)hipEventDestroy(h->ev_solve[i]);
+    }
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) rccl_destroy(h->comm);
     if (h->ev_vb_ready) (void)hipEventDestroy(h->ev_vb_ready);
@@ -338,8 +382,13 @@ dekf_status dekf_destroy(dekf_handle h) {
 dekf_status dekf_reset(dekf_handle h) {
     if (!h) return fail(DEKF_ERR_INVALID, "null handle");
     HIPCHK(hipSetDevice(h->device));
-    k_reset_state<<<(h->c.B + 255) / 256, 256, 0, h->stream>>>(h->c, h->s);
-    HIPCHK(hipGetLastError());
+    for (int i = 0; i < 2; ++i)   // a solve still in flight writes the outputs this clears
+        if (h->solve_pending[i]) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_solve[i], 0)); h->solve_pending[i] = false; }
+    for (int i = 0; i < (h->pipelined ? 2 : 1); ++i) {
+        k_reset_state<<<(h->c.B + 255) / 256, 256, 0, h->stream>>>(h->c, h->sp[i]);
+        HIPCHK(hipGetLastError());
+    }
+    h->last_par = 0;
     h->ekf_count = 0;
     h->pushes = 0;
     h->next_T = 0;
@@ -350,6 +399,8 @@ dekf_status dekf_reset(dekf_handle h) {
 dekf_status dekf_sync(dekf_handle h) {
     if (!h) return fail(DEKF_ERR_INVALID, "null handle");
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 2; ++i)
+        if (h->solve_stream[i]) HIPCHK(hipStreamSynchronize(h->solve_stream[i]));
     if (h->comm_stream) HIPCHK(hipStreamSynchronize(h->comm_stream));
     return DEKF_OK;
 }
@@ -455,6 +506,7 @@ dekf_status dekf_initialize(dekf_handle h) {
         h->pushes = 2;
     }
     HIPCHK(hipGetLastError());
+    h->last_par = 0;
     h->initialized = true;
     h->next_T = 1;
     return DEKF_OK;
@@ -465,20 +517,36 @@ dekf_status dekf_update(dekf_handle h, int T) {
     if (!h->initialized) return fail(DEKF_ERR_ORDER, "dekf_update before dekf_initialize");
     if (T != h->next_T) return fail(DEKF_ERR_ORDER, "update(T) must be called with T = 1, 2, 3, ... (EstSub.cpp:58-75)");
     if (h->c.est_type == 0) {
+        const int par = h->pipelined ? (T & 1) : 0;
+        const DevState& sp = h->sp[par];
+        hipStream_t ss = h->pipelined ? h->solve_stream[par] : h->stream;
+        // the solve of step T - 2 read this set's snapshot and wrote its outputs and slabs: the assemble that refills it waits
+        if (h->pipelined && h->solve_pending[par]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_solve[par], 0));
         {
             Timed t(h, 1);
-            k_mhe_assemble<<<h->c.B, 64, h->lds_asm, h->stream>>>(h->c, h->s, T, h->pushes);
+            k_mhe_assemble<<<h->c.B, 64, h->lds_asm, h->stream>>>(h->c, sp, T, h->pushes);
         }
         HIPCHK(hipGetLastError());
+        if (h->pipelined) {
+            HIPCHK(hipEventRecord(h->ev_asm[par], h->stream));
+            HIPCHK(hipStreamWaitEvent(ss, h->ev_asm[par], 0));
+            // an all-gather in flight still reads this set's v_b until its snapshot copy is through (dekf_allgather_vb)
+            if (h->ag_pending) HIPCHK(hipStreamWaitEvent(ss, h->ev_vb_ready, 0));
+        }
         int kstart = T - h->c.N + 1 > 0 ? T - h->c.N + 1 : 0;
         {
-            Timed t(h, 2);
+            Timed t(h, 2, ss);
             const int K = T - kstart + 1;
             if (h->solve_kernel_full && K == h->c.N)
-                h->solve_kernel_full<<<h->solve_grid_full, DEKF_SOLVE_THREADS, h->lds_solve_full, h->stream>>>(h->c, h->s, kstart, K, h->gws_len);
+                h->solve_kernel_full<<<h->solve_grid_full, DEKF_SOLVE_THREADS, h->lds_solve_full, ss>>>(h->c, sp, kstart, K, h->gws_len);
             else
-                h->solve_kernel<<<h->solve_grid, DEKF_SOLVE_THREADS, h->lds_solve, h->stream>>>(h->c, h->s, kstart, K, h->gws_len);
+                h->solve_kernel<<<h->solve_grid, DEKF_SOLVE_THREADS, h->lds_solve, ss>>>(h->c, sp, kstart, K, h->gws_len);
         }
+        if (h->pipelined) {
+            HIPCHK(hipEventRecord(h->ev_solve[par], ss));
+            h->solve_pending[par] = true;
+        }
+        h->last_par = par;
     } else {
         Timed t(h, 1);
         k_kf_update<<<h->c.B, 64, h->lds_kf, h->stream>>>(h->c, h->s, h->pushes);
@@ -499,11 +567,13 @@ dekf_status dekf_get(dekf_handle h, double* x_mhe, double* v_b, double* quat, do
     if (!h) return fail(DEKF_ERR_INVALID, "null handle");
     size_t B = h->c.B;
     dekf_status st;
-    if ((st = fetch(h, x_mhe, h->s.x_mhe, (size_t)h->c.ns * B * 8, where))) return st;
-    if ((st = fetch(h, v_b, h->s.v_b, 3 * B * 8, where))) return st;
-    if ((st = fetch(h, quat, h->s.quat, 4 * B * 8, where))) return st;
-    if ((st = fetch(h, p_vo, h->s.p_vo, 3 * B * 8, where))) return st;
-    if ((st = fetch(h, status, h->s.status, B * 4, where))) return st;
+    if ((st = await_results(h))) return st;
+    const DevState& s = h->sp[h->last_par];
+    if ((st = fetch(h, x_mhe, s.x_mhe, (size_t)h->c.ns * B * 8, where))) return st;
+    if ((st = fetch(h, v_b, s.v_b, 3 * B * 8, where))) return st;
+    if ((st = fetch(h, quat, s.quat, 4 * B * 8, where))) return st;
+    if ((st = fetch(h, p_vo, s.p_vo, 3 * B * 8, where))) return st;
+    if ((st = fetch(h, status, s.status, B * 4, where))) return st;
     if (where == DEKF_HOST) HIPCHK(hipStreamSynchronize(h->stream));
     return DEKF_OK;
 }
@@ -532,10 +602,12 @@ dekf_status dekf_get_solver_info(dekf_handle h, int* iters, int* rho_updates, do
     if (!h) return fail(DEKF_ERR_INVALID, "null handle");
     size_t B = h->c.B;
     dekf_status st;
-    if ((st = fetch(h, iters, h->s.iters, B * 4, where))) return st;
-    if ((st = fetch(h, rho_updates, h->s.rho_updates, B * 4, where))) return st;
-    if ((st = fetch(h, pri_res, h->s.pri_res, B * 8, where))) return st;
-    if ((st = fetch(h, dua_res, h->s.dua_res, B * 8, where))) return st;
+    if ((st = await_results(h))) return st;
+    const DevState& s = h->sp[h->last_par];
+    if ((st = fetch(h, iters, s.iters, B * 4, where))) return st;
+    if ((st = fetch(h, rho_updates, s.rho_updates, B * 4, where))) return st;
+    if ((st = fetch(h, pri_res, s.pri_res, B * 8, where))) return st;
+    if ((st = fetch(h, dua_res, s.dua_res, B * 8, where))) return st;
     if (where == DEKF_HOST) HIPCHK(hipStreamSynchronize(h->stream));
     return DEKF_OK;
 }
@@ -569,6 +641,8 @@ dekf_status dekf_timing_enable(dekf_handle h, int on) {
 dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches) {
     if (!h || !ms_sum || !launches) return fail(DEKF_ERR_INVALID, "null argument");
     HIPCHK(hipStreamSynchronize(h->stream));
+    for (int i = 0; i < 2; ++i)
+        if (h->solve_stream[i]) HIPCHK(hipStreamSynchronize(h->solve_stream[i]));
     for (int c = 0; c < DEKF_TIMING_CLASSES; ++c) {
         double sum = 0.0;
         for (auto& pr : h->ev[c]) {
@@ -603,7 +677,8 @@ const char* dekf_solve_kernel_name(dekf_handle h, int full_window) {
 // library was built with -DDEKF_PROFILE (libdekf_prof.so, tools/profile_sections.py)
 dekf_status dekf_debug_sections(dekf_handle h, double* out_host) {
     if (!h || !out_host) return fail(DEKF_ERR_INVALID, "null argument");
-    HIPCHK(hipMemcpyAsync(out_host, h->s.prof, DEKF_PROF_SLOTS * (size_t)h->c.B * 8, hipMemcpyDeviceToHost, h->stream));
+    { dekf_status st = await_results(h); if (st) return st; }
+    HIPCHK(hipMemcpyAsync(out_host, h->sp[h->last_par].prof, DEKF_PROF_SLOTS * (size_t)h->c.B * 8, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return DEKF_OK;
 }
@@ -661,11 +736,24 @@ dekf_status dekf_allgather_vb(dekf_handle h, double* v_b_all_dev) {
     if (!h->comm) return fail(DEKF_ERR_ORDER, "dekf_comm_init has not been called");
     HIPCHK(hipSetDevice(h->device));
     const size_t n = 3 * (size_t)h->c.B;
+    if (h->pipelined) {
+        // Everything on the communication stream, which is in order (the previous all-gather has read the snapshot): wait for the
+        // solve that produced v_b, copy it, exchange.  The handle's stream is not involved, so the next step's pushes, EKF tick and
+        // assemble are not held back; the solve that will overwrite this set's v_b waits for ev_vb_ready (dekf_update).
+        if (h->solve_pending[h->last_par]) HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_solve[h->last_par], 0));
+        else {  // (T = 0: no solve yet; v_b is what the reset / initialise kernels on the handle's stream left)
+            HIPCHK(hipEventRecord(h->ev_vb_ready, h->stream));
+            HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_vb_ready, 0));
+        }
+        HIPCHK(hipMemcpyAsync(h->vb_snapshot, h->sp[h->last_par].v_b, n * sizeof(double), hipMemcpyDeviceToDevice, h->comm_stream));
+        HIPCHK(hipEventRecord(h->ev_vb_ready, h->comm_stream));
+    } else {
     // the previous all-gather must have read the snapshot before it is overwritten (it finished a step ago)
     if (h->ag_pending) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ag_done, 0));
     HIPCHK(hipMemcpyAsync(h->vb_snapshot, h->s.v_b, n * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     HIPCHK(hipEventRecord(h->ev_vb_ready, h->stream));
     HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_vb_ready, 0));
+    }
     const char* e = rccl_allgather_f64(h->comm, h->vb_snapshot, v_b_all_dev, n, h->comm_stream);
     if (e) return fail(DEKF_ERR_COMM, e);
     HIPCHK(hipEventRecord(h->ev_ag_done, h->comm_stream));

@@ -42,7 +42,7 @@ inline void default_params(dekf_params* p) {
     set3(p->ekf_gravity_meas_std, 4.0, 4.0, 4.0);
     p->ekf_quaternion_init[0] = 1.0;
     p->ekf_rate = 500; p->ekf_history = 64;
-    p->arrival_cost_form = 0; p->solve_workgroups_per_cu = 0;
+    p->arrival_cost_form = 0; p->solve_pipeline = 0; p->solve_workgroups_per_cu = 0;
 }
 
 // returns nullptr when ok, else a message
@@ -57,6 +57,7 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     if (p.ekf_history < 4) return "ekf_history must be >= 4";
     if (p.polish) return "osqp.polish = true is not implemented";
     if (p.arrival_cost_form != 0 && p.arrival_cost_form != 1) return "arrival_cost_form must be 0 (reference form) or 1 (information form)";
+    if (p.solve_pipeline != 0 && p.solve_pipeline != 1) return "solve_pipeline must be 0 (in order) or 1 (consecutive steps overlap)";
     if (p.solve_workgroups_per_cu < 0 || p.solve_workgroups_per_cu > 8) return "solve_workgroups_per_cu out of range [0,8]";
     if (p.leg_odom_type == 1) {  // these become gains 1 / std^2 (DecentralEst.cpp:47-51): a zero would be an infinite weight
         for (int i = 0; i < 3; ++i)
@@ -69,6 +70,7 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     c.ft = p.leg_odom_type; c.ns = 9 + 3 * c.ft * c.L;
     c.SV = 2 * c.ns + c.nm + 3; c.SC = c.nm + c.ns + 3;
     c.ring = 4 * p.N + 1; c.wcap = p.N + 1; c.rec = Rec::len(c.L, c.ft);
+    c.snap_len = c.ns * c.ns + c.ns + 4 * c.wcap;
     c.est_type = p.est_type;
     c.marg_info = p.leg_odom_type == 1 && p.arrival_cost_form == 1;
     c.dt = 1.0 / (double)p.rate;
@@ -111,8 +113,10 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
 }
 
 // every persistent array: alloc(bytes) must return zero-filled memory
+// `copies` (1 or 2): sets of the per-solve data (input snapshot, outputs, solver scratch, section stamps); set 1 follows set 0
+// in each allocation (second_set() moves a DevState's pointers over)
 template <class Alloc>
-inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc alloc) {
+inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc alloc, int copies = 1) {
     const size_t B = (size_t)c.B, L = (size_t)c.L, nj = (size_t)c.nj;
     auto D = [&](size_t n) { return (double*)alloc(n * sizeof(double)); };
     auto I = [&](size_t n) { return (int*)alloc(n * sizeof(int)); };
@@ -125,16 +129,31 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
     s.st_time = D((size_t)c.ring * B); s.st_R = D((size_t)c.ring * 9 * B); s.st_dtime = I((size_t)c.ring * B);
     const size_t ns = (size_t)c.ns;
     s.rec = D((size_t)c.wcap * c.rec * B); s.Mp = D(ns * ns * B); s.np_ = D(ns * B);
+    s.snap = D((size_t)copies * c.snap_len * B);
     s.wp = D(12 * B); s.wpt = D(4 * B); s.wp_count = I(B);
     s.p_vo = D(3 * B); s.vo_ins_idx = I(B); s.vo_ins_dtime = I(B);
     Gws g;
     g.init(c.N, c.L, c.ft);
-    s.gws = D((size_t)solve_slots * g.total);
+    const size_t cp = (size_t)copies;
+    s.gws = D(cp * solve_slots * g.total);
     s.kf_x = D(ns * B); s.kf_C = D(ns * ns * B);
-    s.x_mhe = D(ns * B); s.v_b = D(3 * B);
-    s.status = I(B); s.iters = I(B); s.rho_updates = I(B);
-    s.pri_res = D(B); s.dua_res = D(B);
-    s.prof = D(DEKF_PROF_SLOTS * B);
+    s.x_mhe = D(cp * ns * B); s.v_b = D(cp * 3 * B);
+    s.status = I(cp * B); s.iters = I(cp * B); s.rho_updates = I(cp * B);
+    s.pri_res = D(cp * B); s.dua_res = D(cp * B);
+    s.prof = D(cp * DEKF_PROF_SLOTS * B);
+}
+inline DevState second_set(const DevCfg& c, const DevState& s, int solve_slots) {
+    const size_t B = (size_t)c.B, ns = (size_t)c.ns;
+    Gws g;
+    g.init(c.N, c.L, c.ft);
+    DevState t = s;
+    t.snap += (size_t)c.snap_len * B;
+    t.gws += (size_t)solve_slots * g.total;
+    t.x_mhe += ns * B; t.v_b += 3 * B;
+    t.status += B; t.iters += B; t.rho_updates += B;
+    t.pri_res += B; t.dua_res += B;
+    t.prof += DEKF_PROF_SLOTS * B;
+    return t;
 }
 
 }  // namespace dekf

@@ -823,6 +823,21 @@ DEKF_FN void assemble_update(const DevCfg& c, const DevState& s, int b, int T, i
     get_measurement(c, s, b, T, pushes, sm);
     write_measurement_record(c, s, b, T);
     if (T >= c.N) marginalize_step(c, s, b, T - c.N, sm);
+    // the solve's input snapshot (cfg.h: DevState::snap): the arrival cost as this step leaves it and the VO flag / bound of every
+    // ring slot — the two things update(T + 1) rewrites in place while the solve of step T may still be reading them
+    DEKF_SYNC();
+    {
+        const int ns2 = c.ns * c.ns, ns = c.ns;
+        const double* Mp = s.Mp + (size_t)ns2 * b;
+        const double* np = s.np_ + (size_t)ns * b;
+        const double* recb = s.rec + (size_t)b * c.wcap * c.rec;
+        double* sn = s.snap + (size_t)c.snap_len * b;
+        wfor(c.snap_len, [&](int e) {
+            if (e < ns2) sn[e] = Mp[e];
+            else if (e < ns2 + ns) sn[e] = np[e - ns2];
+            else { const int q = e - ns2 - ns; sn[e] = recb[(size_t)(q >> 2) * c.rec + Rec::VOF + (q & 3)]; }
+        });
+    }
 }
 
 // InitializeMHE (DecentralEst.cpp:200-351): first sample, prior as arrival cost.  With foot-position states the

@@ -176,6 +176,7 @@ struct SolveCtx {
     double *Wm, *Wd, *Wc, *PA;
     double* Wf;  // FOOT: effective row weights of the foot-position Dyn rows
     const double *Mp, *np;
+    const double* vo;  // [wcap][4] VO flag + bound per ring slot, from the solve's input snapshot
     double cc;   // cost scaling c
     double rho;  // current scalar rho
     double* Pst;  // unscaled P blocks staged by solve_scale (aliases Sinv | Wk until the first factorisation)
@@ -200,8 +201,11 @@ struct SolveCtx {
         const double* r = rec(k);
         if (kind == 0) lb = ub = r[Rec::BM + o];
         else if (kind == 1) lb = ub = (o < 3 ? -0.5 * c.dt * c.dt * r[Rec::AS + o] : (o < 6 ? -c.dt * r[Rec::AS + o - 3] : 0.0));
-        else if (r[Rec::VOF] != 0.0) lb = ub = r[Rec::VOB + o];
-        else { lb = -OSQP_INFTY; ub = OSQP_INFTY; }
+        else {  // VO flag and bound come from the step's snapshot, not from the record (update(T + 1) may be rewriting them)
+            const double* v = vo + 4 * ((kstart + k) % c.wcap);
+            if (v[0] != 0.0) lb = ub = v[1 + o];
+            else { lb = -OSQP_INFTY; ub = OSQP_INFTY; }
+        }
     }
     DEKF_FN void dec_row(int r, int& k, int& kind, int& o) const {
         if (r < ix.rdb) { kind = 0; k = r / ix.nm; o = r - k * ix.nm; }
@@ -622,11 +626,28 @@ DEKF_FN void solve_scale(Q& q) {
         for (int it = 0; it < q.c.scaling; ++it) {
             const double cc = q.cc;
             double psum = 0.0;
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)  // per-wavefront: tile phase | wait at its barrier | x_0 norms + sum (slots 24.., 28.., 20..)
+            const long long tr0 = clock64();
+#endif
             wtiles(ntiles, [&](int tile, int lane) { psum += fused(tile, lane, cc, Dr, Er, Dw, Ew); });
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
+            __builtin_amdgcn_s_waitcnt(0);
+            const long long tr1 = clock64();
+#endif
             DEKF_SYNC();
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
+            const long long tr2 = clock64();
+#endif
             wtiles(ntiles, [&](int tile, int lane) { psum += fused_x0(tile, lane, Dw); });
             psum = wave_sum(psum);
             group_combine<1, true>(&psum);
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
+            {
+                const long long tr3 = clock64();
+                const int w_ = DEKF_LANE() >> 6;
+                if ((DEKF_LANE() & 63) == 0) { q.prof[24 + w_] += (double)(tr1 - tr0); q.prof[28 + w_] += (double)(tr2 - tr1); q.prof[17 + (w_ & 1)] += 0.5 * (double)(tr3 - tr2); }
+            }
+#endif
             psum *= cc;
             double qn = 0.0;
 #pragma unroll
@@ -1210,6 +1231,9 @@ DEKF_FN bool solve_factor(Q& q) {
     double* fail = q.tmp + 172;  // [162, 171) is the scaled q
     if (DEKF_LANE() == 0) *fail = 0.0;
     DEKF_SYNC();
+#ifdef DEKF_X_LDL_PRIO
+    __builtin_amdgcn_s_setprio(DEKF_X_LDL_PRIO);
+#endif
     two_waves(
         [&] {
             bool g = true;
@@ -1266,6 +1290,9 @@ DEKF_FN bool solve_factor(Q& q) {
             }
         },
         [&] {});
+#ifdef DEKF_X_LDL_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
     DEKF_SYNC();
     ok = *fail == 0.0;
     DEKF_SYNC();
@@ -1428,8 +1455,9 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     }
     q.n = (K - 1) * IdxT<L, FT>::SV + NS + IdxT<L, FT>::nm;
     q.m = (K - 1) * IdxT<L, FT>::SC + IdxT<L, FT>::nm;
-    q.Mp = s.Mp + (size_t)NS2 * b;
-    q.np = s.np_ + (size_t)NS * b;
+    q.Mp = s.snap + (size_t)c.snap_len * b;
+    q.np = q.Mp + NS2;
+    q.vo = q.np + NS;
     q.cc = 1.0;
     q.Pst = q.Sinv;  // Sinv | Wk are adjacent in both placements and dead until a factorisation writes them
     q.staged = false;
@@ -1443,6 +1471,9 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     const long long prof_t0 = q.prof_last;
     if (DEKF_LANE() == 0)
         for (int i = 0; i < DEKF_PROF_SLOTS; ++i) q.prof[i] = 0.0;
+#endif
+#if defined(DEKF_X_SETUP_PRIO) && DEKF_DEVICE_BUILD
+    __builtin_amdgcn_s_setprio(DEKF_X_SETUP_PRIO);
 #endif
     wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });
     if constexpr (R3) {
@@ -1489,6 +1520,9 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     if (ok) phase_rows<true>(q, alpha, sigma);  // cold start: cf, t = 0, w = 0 (the factorisation scratch aliased xt | zt | at)
     }
     DEKF_PROF_MARK(q, 1);
+#if defined(DEKF_X_SETUP_PRIO) && DEKF_DEVICE_BUILD
+    __builtin_amdgcn_s_setprio(0);
+#endif
     while (ok && !done && iter < c.max_iter) {
 #if DEKF_DEVICE_BUILD
         if constexpr (R3) {

@@ -111,6 +111,13 @@ typedef struct dekf_params {
                                      * (MheSrb.cpp:527-651).  1: information form (same arrival cost in exact arithmetic,
                                      * computed from gains only). leg_odom_type 0 always uses the reference form. */
     /* launch tuning (new) */
+    int solve_pipeline;             /* 0 (default): every kernel of a step in order on the handle's stream.  1: the MHE solve of
+                                     * step T runs on a second stream out of double-buffered inputs and outputs, so the pushes, the
+                                     * EKF tick and the term construction of step T + 1 (and then its solve) start while the last
+                                     * workgroups of step T's solve are still running; getters wait for the newest solve in stream
+                                     * order, so results are bit-identical.  Measured on MI355X, Go1: +7 % at B = 768, +1 % at 4096,
+                                     * +2 % at 8192: it hides the 0.1 ms of EKF + assemble + launch gaps, the
+                                     * partial last round of a launch costs nothing to begin with. */
     int solve_workgroups_per_cu;    /* 0: as many as the CU holds (3 for full Go1 / Cassie windows); 1 or 2: cap —
                                      * 2 keeps the two-workgroup solve kernels for full windows too (bit-identical
                                      * results: the A/B and the identity test use it) */

@@ -337,3 +337,91 @@ def test_three_workgroup_kernel_is_bit_identical_to_the_two_workgroup_kernel(mak
         assert np.array_equal(o3[key], o2[key]), key
     assert np.array_equal(i3["iters"], i2["iters"])
     assert np.array_equal(i3["pri_res"], i2["pri_res"]) and np.array_equal(i3["dua_res"], i2["dua_res"])
+
+
+def test_pipelined_steps_are_bit_identical_to_in_order_steps():
+    """dekf_params.solve_pipeline = 1: the solve of step T runs on a second stream out of a snapshot of what step T + 1
+    overwrites (arrival cost, VO flags / bounds of the window) and into its own set of outputs and scratch slabs, so step
+    T + 1's pushes, EKF tick and assemble are issued — and run — before step T's solve has finished.  Window fill, VO
+    intervals landing inside the window, marginalisation: every state, residual and iteration count must equal the in-order
+    run to the last bit, whether the caller reads every step (the handle's stream then waits for each solve) or only the
+    last one (two solves in flight all the way), and after a reset."""
+    import torch
+    p = go1_params()
+    p.ekf_rate = p.rate
+    B, K = 1500, p.N + 25          # more instances than resident slots: launches of two rounds overlap their neighbours
+    s = make_streams(p, B, K)
+    sd = streams_to_device(s)
+
+    def run(pipeline, read_every, device_reads=False):
+        q = p.copy()
+        q.solve_pipeline = pipeline
+        est = BatchedEstimator(q, B)
+        xs = []
+        xd = torch.zeros((K, B, 9), dtype=torch.float64, device="cuda") if device_reads else None
+        for rep in range(2):
+            for k in range(K):
+                est.push_stream_step(sd, k)
+                est.step(k)
+                if read_every and rep == 0:
+                    if device_reads:
+                        est.get_into(x=xd[k])          # asynchronous: ordered behind the solve by the handle's stream
+                    else:
+                        xs.append(est.get()["x"])
+            if rep == 0:
+                first = (est.get(), est.solver_info())
+                est.reset()
+        second = (est.get(), est.solver_info())
+        est.close()
+        if device_reads:
+            torch.cuda.synchronize()
+            xs = list(xd.cpu().numpy())
+        return first, second, xs
+
+    ref, ref2, ref_xs = run(0, True)
+    for key in ("x", "v_b", "quat", "p_vo", "status"):
+        assert np.array_equal(ref[0][key], ref2[0][key]), key         # reset reproduces the run (in order)
+    assert (ref[0]["status"] == 1).all()
+    for read_every, dev in ((False, False), (True, False), (True, True)):
+        got, got2, xs = run(1, read_every, dev)
+        for a, b in ((got, ref), (got2, ref)):
+            for key in ("x", "v_b", "quat", "p_vo", "status"):
+                assert np.array_equal(a[0][key], b[0][key]), (read_every, dev, key)
+            for key in ("iters", "rho_updates", "pri_res", "dua_res"):
+                assert np.array_equal(a[1][key], b[1][key]), (read_every, dev, key)
+        for k, x in enumerate(xs):
+            assert np.array_equal(x, ref_xs[k]), (read_every, dev, k)
+
+
+def test_pipelined_allgather_returns_each_steps_own_v_b():
+    """the all-gather of step T with pipelined steps: issued right after dekf_step(T) without any host synchronisation, it
+    must wait for THAT step's solve on the communication stream, and the solve of step T + 2 (which reuses the output set)
+    must wait for its snapshot copy"""
+    import torch
+    p = go1_params()
+    p.ekf_rate = p.rate
+    p.solve_pipeline = 1
+    B, K = 1200, p.N + 12
+    s = make_streams(p, 64, K)
+    big = _tile(s, 1200 // 64 + 1)
+    big = {k: (np.ascontiguousarray(v[:, :B]) if isinstance(v, np.ndarray) else v) for k, v in big.items()}
+    sd = streams_to_device(big)
+    est = BatchedEstimator(p, B)
+    est.comm_init(1, 0, new_unique_id())
+    vb_all = torch.full((K, 1, B, 3), float("nan"), dtype=torch.float64, device="cuda")
+    for k in range(K):
+        est.push_stream_step(sd, k)
+        est.step(k)
+        est.allgather_vb(vb_all[k])
+    est.allgather_wait()
+    est.sync()
+    est.close()
+    got = vb_all.cpu().numpy()[:, 0]
+    q = p.copy()
+    q.solve_pipeline = 0
+    ref = BatchedEstimator(q, B)
+    for k in range(K):
+        ref.push_stream_step(sd, k)
+        ref.step(k)
+        assert np.array_equal(got[k], ref.get()["v_b"]), k
+    ref.close()

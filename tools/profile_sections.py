@@ -27,7 +27,11 @@ NAMES = ["0 copy R + Ruiz scaling", "1 bounds + first factorisation + restart", 
          "9 R: fused row blocks", "10 residuals + termination", "11 rho update + refactor", "12 epilogue", "13 total",
          "14 R3: chunk prologue (x blocks in, row blocks into registers = restart)", "15 R3: chunk epilogue (row state and x blocks back to the slab)",
          "16 R copy, P staging, first column norms", "17 -", "18 -", "19 scaled bounds + cold start", "20 residuals: D x", "21 residuals: tile phase (state + window records)",
-         "22 block LDL': the two legs", "23 -"]
+         "22 block LDL': the two legs", "23 -",
+         "24 Ruiz (-DDEKF_PROFILE_RUIZ): tile phase, wavefront 0", "25 Ruiz tile phase, wavefront 1", "26 Ruiz tile phase, wavefront 2", "27 Ruiz tile phase, wavefront 3",
+         "28 Ruiz: wait at the barrier behind the tiles, wavefront 0", "29 Ruiz barrier wait, wavefront 1", "30 Ruiz barrier wait, wavefront 2", "31 Ruiz barrier wait, wavefront 3"]
+NAMES[17] = "17 Ruiz (-DDEKF_PROFILE_RUIZ): x_0 norms + sum, mean of wavefronts 0, 2"
+NAMES[18] = "18 Ruiz (-DDEKF_PROFILE_RUIZ): x_0 norms + sum, mean of wavefronts 1, 3"
 
 
 def main():
