@@ -1045,9 +1045,9 @@ struct SymMat {  // symmetric N x N, packed upper triangle, held in registers
 // path, so that both kinds share a tile: the diagonal goes into the packed slots 0, 3, 5, the rest is zero
 struct VoOrBiasMat {
     double p[6];
-    DEKF_FN VoOrBiasMat(const double* sc6, const double* diag3, bool vo) {
+    DEKF_FN VoOrBiasMat(const double* sc6, const double* diag3, bool vo, int st = 1) {  // st: element stride of both arrays
         const double* sp = vo ? sc6 : diag3;
-        const double s0 = sp[0], s1 = sp[1], s2 = sp[2], s3 = sp[3], s4 = sp[4], s5 = sp[5];  // in bounds for both
+        const double s0 = sp[0], s1 = sp[st], s2 = sp[2 * st], s3 = sp[3 * st], s4 = sp[4 * st], s5 = sp[5 * st];  // in bounds for both
         p[0] = s0; p[1] = vo ? s1 : 0.0; p[2] = vo ? s2 : 0.0;
         p[3] = vo ? s3 : s1; p[4] = vo ? s4 : 0.0; p[5] = vo ? s5 : s2;
     }
@@ -1067,15 +1067,15 @@ struct VoOrBiasMat {
 struct DynPairMat {
     double a[6];  // own rows x own columns (symmetric, packed)
     double b[9];  // own rows x partner columns
-    DEKF_FN DynPairMat(const double* s, bool vel) {
+    DEKF_FN DynPairMat(const double* s, bool vel, int st = 1) {  // st: element stride of s
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = i; j < 3; ++j) a[symidx(i, j, 3)] = s[vel ? symidx(3 + i, 3 + j, 6) : symidx(i, j, 6)];
+            for (int j = i; j < 3; ++j) a[symidx(i, j, 3)] = s[(vel ? symidx(3 + i, 3 + j, 6) : symidx(i, j, 6)) * st];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) b[3 * i + j] = s[vel ? symidx(j, 3 + i, 6) : symidx(i, 3 + j, 6)];
+            for (int j = 0; j < 3; ++j) b[3 * i + j] = s[(vel ? symidx(j, 3 + i, 6) : symidx(i, 3 + j, 6)) * st];
     }
     DEKF_FN void apply(const double* in, double* out) const {
         double pin[3];
@@ -1397,12 +1397,12 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     t.kind = -1; t.k = 0; t.r0 = 0; t.sv0 = 0; t.vel = false; t.meas = false; t.xo = 0;
     bool vo = false;
-    const double* sp = q.Sv;
+    const double* sp = q.Sv;  // (the slack-block inverses are stored entry-major in the slab: solve_factor 3a)
     if (w == 1) {
         if (lane >= nmeas) return;
         const int k = lane / L, leg = lane - k * L;
         t.kind = 0; t.k = k; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg; t.xo = 3;
-        sp = q.Sv + lane * 6;
+        sp = q.Sv + lane;
     } else if (w == 2) {
         const int k = lane >> 1;
         if (k >= K1) return;
@@ -1417,23 +1417,26 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
             if (e >= nmeas) return;
             const int k = e / L, leg = e - k * L;
             t.kind = 2; t.meas = true; t.k = k; t.xo = 3; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg;
-            sp = q.Sv + e * 6;
+            sp = q.Sv + e;
         }
     }
     if (t.kind == 1) {
-        const DynPairMat S(q.Sw + t.k * SWS, t.vel);
+        const DynPairMat S(q.Sw + t.k, t.vel, K);
 #pragma unroll
         for (int i = 0; i < 6; ++i) t.a[i] = S.a[i];
 #pragma unroll
         for (int i = 0; i < 9; ++i) t.b[i] = S.b[i];
     } else if (t.kind == 2 && !t.meas) {
-        const VoOrBiasMat S(q.Sc + t.k * 6, q.Sw + t.k * SWS + 21, vo);
+        const VoOrBiasMat S(q.Sc + t.k, q.Sw + t.k + 21 * K, vo, K);
 #pragma unroll
         for (int i = 0; i < 6; ++i) t.a[i] = S.p[i];
     } else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) t.a[i] = sp[i];
+        for (int i = 0; i < 6; ++i) t.a[i] = sp[i * nmeas];
     }
+    // State: zero before the first chunk (the cold start); afterwards the slack x and y from where the previous chunk left them
+    // in LDS; z of an equality row IS its bound after one iteration (the projection returns it), only the VO rows keep theirs.
+    const bool cold = q.cold;
     double dd[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -1443,9 +1446,10 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
         t.c2[j] = d * t.e[j];
         t.lo[j] = q.lo[r];
         if (t.kind == 2) t.b[j] = vo ? q.hi[r - q.ix.rvb] : t.lo[j];  // an equality block on the generic path: hi = lo
-        t.xs[j] = q.x[sv];
-        t.z[j] = q.z[r];
-        t.y[j] = q.y[r];
+        const double sxv = q.sx[r], syv = q.sy[r], szv = q.sz[vo ? r - q.ix.rvb : 0];
+        t.xs[j] = cold ? 0.0 : sxv;
+        t.y[j] = cold ? 0.0 : syv;
+        t.z[j] = cold ? 0.0 : (vo ? szv : t.lo[j]);
         dd[j] = d;
     }
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
@@ -1482,12 +1486,13 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
 template <class Q>
 DEKF_FN void row_regs_store(Q& q, const RowRegs& t) {
     if (t.kind < 0) return;
+    const bool vo = t.kind == 2 && !t.meas && t.xo == 0;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int r = t.r0 + j, sv = t.sv0 + j;
-        q.x[sv] = t.xs[j];
-        q.z[r] = t.z[j];
-        q.y[r] = t.y[j];
+        const int r = t.r0 + j;
+        q.sx[r] = t.xs[j];   // (aliases the w vector, which nobody reads after the last iteration of a chunk)
+        q.sy[r] = t.y[j];
+        if (vo) q.sz[r - q.ix.rvb] = t.z[j];
     }
 }
 // one iteration of a row block: the arithmetic of row_block_compute, operand for operand, with the state in registers
@@ -1585,8 +1590,7 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
     static_assert(3 * NF <= 64 && 2 * (NF - 1) <= 64, "one tile per kind");
     static_assert(NF * L <= 64 || (NF * L - 64) + 2 * (NF - 1) <= 64, "the Meas blocks beyond 64 fit the VO / bias wavefront");
     const int w = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), lane = DEKF_LANE() & 63;
-    // x blocks of the slab copy -> LDS (the restart / cold start / previous chunk left them there)
-    wfor(9 * NF, [&](int e) { const int k = e / 9; q.xb[e] = q.x[k * SV + e - 9 * k]; });
+    // (the x blocks stay in LDS, q.xb, for the whole solve)
     // -DDEKF_PROFILE -DDEKF_PROFILE_TL: per-wavefront intervals, summed over the iterations (tools/profile_sections.py, DEKF_TIMELINE=1)
     //   prof[w]: w0 the solve, workers the x-column tile | prof[4 + w]: w0 its wait from B2 to B1, workers the row tile |
     //   prof[8 + w]: workers' wait for the solve (B1 to B2)
@@ -1648,7 +1652,7 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
 #undef DEKF_R3_T
     DEKF_PROF_MARK(q, 9);
     DEKF_SYNC();
-    wfor(9 * NF, [&](int e) { const int k = e / 9; q.x[k * SV + e - 9 * k] = q.xb[e]; });
+    q.cold = false;
     DEKF_PROF_MARK(q, 15);
 }
 #endif
@@ -1731,29 +1735,40 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt, cc = q.cc;
     double *x = q.x, *z = q.z, *y = q.y, *xd = q.xd;
     const double *D = q.D, *E = q.E;
+    // Where the iterates are.  Three-workgroup kernels (R3): x blocks compact in LDS (xb); the slack x and y by ROW in sx / sy, z of
+    // the VO rows in sz (what the last chunk of iterations left, admm_chunk_r3); z of an equality row is its scaled bound (the
+    // projection returns it from the first iteration on).  Everywhere else: the full vectors x, z, y.
+    auto XB = [&](int k, int j) -> double { if constexpr (Q::R3) return q.xb[NS * k + j]; else return x[k * SV + j]; };
+    auto XS = [&](int sv, int r) -> double { if constexpr (Q::R3) { (void)sv; return q.sx[r]; } else { (void)r; return x[sv]; } };
+    auto YR = [&](int r) -> double { if constexpr (Q::R3) return q.sy[r]; else return y[r]; };
+    auto ZR = [&](int r, bool vo) -> double {
+        if constexpr (Q::R3) return vo ? q.sz[r - q.ix.rvb] : q.lo[r];
+        else { (void)vo; return z[r]; }
+    };
     wfor(K * NS, [&](int e) {
         int k = e / NS, j = e - NS * k;
-        xd[e] = D[k * SV + j] * x[k * SV + j];
+        xd[e] = D[k * SV + j] * XB(k, j);
     });
     DEKF_PROF_MARK(q, 20);
     double acc[14];
 #pragma unroll
     for (int r = 0; r < 14; ++r) acc[r] = 0.0;
-    // rows r0.. and slack variables sv0.. of one 3-block: ar = E .* (A_x D x), ps = unscaled P_s (D_s x_s)
-    auto block = [&](int r0, int sv0, const double* ar, const double* ps) {
+    // rows r0.. and slack variables sv0.. of one 3-block: ar = E .* (A_x D x), ps = unscaled P_s (D_s x_s); vo: a VO block
+    auto block = [&](int r0, int sv0, const double* ar, const double* ps, bool vo = false) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int r = r0 + j, sv = sv0 + j;
             const double e = E[r], d = D[sv];
-            const double Ax = ar[j] - e * d * x[sv];
-            const double pr = Ax - z[r], ei = rcp_fast(e);
+            const double Ax = ar[j] - e * d * XS(sv, r);
+            const double zr = ZR(r, vo);
+            const double pr = Ax - zr, ei = rcp_fast(e);
             acc[0] = dmax(acc[0], fabs(pr) * ei);
-            acc[1] = dmax(acc[1], fabs(z[r]) * ei);
+            acc[1] = dmax(acc[1], fabs(zr) * ei);
             acc[2] = dmax(acc[2], fabs(Ax) * ei);
             acc[3] = dmax(acc[3], fabs(pr));
-            acc[4] = dmax(acc[4], fabs(z[r]));
+            acc[4] = dmax(acc[4], fabs(zr));
             acc[5] = dmax(acc[5], fabs(Ax));
-            const double Px = cc * d * ps[j], Aty = -e * d * y[r];
+            const double Px = cc * d * ps[j], Aty = -e * d * YR(r);
             const double dr = Px + Aty, di = rcp_fast(d);
             acc[6] = dmax(acc[6], fabs(dr) * di);
             acc[8] = dmax(acc[8], fabs(Aty) * di);
@@ -1764,21 +1779,21 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
         }
     };
     // a 3-block whose P block is a packed symmetric 3x3 in the window record
-    auto block_sym3 = [&](int r0, int sv0, const double* ar, const double* q6) {
+    auto block_sym3 = [&](int r0, int sv0, const double* ar, const double* q6, bool vo = false) {
         double p6[6], dx[3], ps[3];
 #pragma unroll
         for (int t = 0; t < 6; ++t) p6[t] = q6[t];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) dx[a] = D[sv0 + a] * x[sv0 + a];
+        for (int a = 0; a < 3; ++a) dx[a] = D[sv0 + a] * XS(sv0 + a, r0 + a);
 #pragma unroll
         for (int a = 0; a < 3; ++a)
             ps[a] = p6[symidx(0, a, 3)] * dx[0] + p6[1 < a ? symidx(1, a, 3) : symidx(a, 1, 3)] * dx[1] + p6[symidx(a, 2, 3)] * dx[2];
-        block(r0, sv0, ar, ps);
+        block(r0, sv0, ar, ps, vo);
     };
     const int ntm = (nmeas + 63) >> 6, ntp = (2 * K1 + 63) >> 6, ntd = (K1 + 63) >> 6, ntx = (3 * K + 63) >> 6;
     const int ntf = FT ? (K1 * L + 63) >> 6 : 0, ntxf = FT ? (NM * K + 63) >> 6 : 0;
     const double* qsl = q.tmp + TmpMap<NS>::QSL;
-    auto wy = [&](int r) { return E[r] * y[r]; };
+    auto wy = [&](int r) { return E[r] * YR(r); };
     wtiles(ntm + ntp + 2 * ntd + 3 * ntx + ntf + ntxf, [&](int tile, int lane) {
         if (tile < ntm) {  // Meas leg blocks
             const int e = tile * 64 + lane;
@@ -1804,7 +1819,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
 #pragma unroll
             for (int t = 0; t < 21; ++t) p21[t] = q21[t];
 #pragma unroll
-            for (int t = 0; t < 6; ++t) dx[t] = D[w0 + t] * x[w0 + t];
+            for (int t = 0; t < 6; ++t) dx[t] = D[w0 + t] * XS(w0 + t, q.ix.rd(k, t));
             const double* xk = xd + NS * k;
             const double* R = q.R + 9 * k;
             const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
@@ -1835,14 +1850,14 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
                     ar[a] = E[r0 + a] * (xk[6 + a] - xk[NS + 6 + a]);
-                    ps[a] = q.c.Q_bias_dt2[a] * D[sv0 + a] * x[sv0 + a];
+                    ps[a] = q.c.Q_bias_dt2[a] * D[sv0 + a] * XS(sv0 + a, r0 + a);
                 }
                 block(r0, sv0, ar, ps);
             } else {
                 const int r0 = q.ix.rv(k, 0), sv0 = q.ix.c(k, 0);
 #pragma unroll
                 for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[a] - xk[NS + a]);
-                block_sym3(r0, sv0, ar, q.rec(k) + Rec::QC);
+                block_sym3(r0, sv0, ar, q.rec(k) + Rec::QC, true);
             }
             return;
         }

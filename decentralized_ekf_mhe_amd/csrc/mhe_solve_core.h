@@ -100,15 +100,18 @@ struct SolveLayout {
     DEKF_HD bool pa_in_lds() const { return factor_in_lds() && (n_pad + 2 * m_pad >= (K - 1) * ns * ns); }
     // Three-workgroup placement (R3, fixed-horizon kernels with the full window only): the row phase keeps its state and its
     // constants in REGISTERS for a whole chunk of iterations, so LDS holds only what crosses lanes:
-    //   R | D E (the scaling vectors: every phase reads them) | xb (x blocks, compact) | [at xs xd gb + pad] = factor-time PA |
+    //   R | D E (the scaling vectors: every phase reads them) | xb (x blocks, compact) | [xd at xs gb sy sz + pad] = factor-time PA |
     //   tmp | Sinv | Wk
+    // Between chunks of iterations the row state (slack x, y, z of the VO rows) rests in LDS too: sx aliases `at` entry for entry
+    // (a lane overwrites only what it has just read), sy | sz sit in the part of the PA region the iterations leave unused.
 #ifndef DEKF_R3_WAVES
 #define DEKF_R3_WAVES 3     // resident workgroups per CU the R3 kernels are compiled for (launch bound: wavefronts per SIMD)
 #endif
 #ifndef DEKF_R3_PA_LDS
 #define DEKF_R3_PA_LDS 1    // 0: the factor-time product P A in the HBM slab (40 KiB of LDS per instance: a fourth workgroup fits)
 #endif
-    DEKF_HD int r3_pa_region() const { int a = m_pad + 2 * ns * K + 3 * K, b = DEKF_R3_PA_LDS ? (K - 1) * ns * ns : 0; return a > b ? a : b; }
+    // xd | at (= the stash of the slack x between chunks) | xs | gb | stash of y | stash of z (VO rows): the factor-time PA aliases all of it
+    DEKF_HD int r3_pa_region() const { int a = 2 * m_pad + 2 * ns * K + 3 * K + 3 * K, b = DEKF_R3_PA_LDS ? (K - 1) * ns * ns : 0; return a > b ? a : b; }
     DEKF_HD int r3_doubles() const { return 9 * K + n_pad + m_pad + ns * K + r3_pa_region() + solve_tmp_len(ns) + 2 * K * ns * ns; }
     DEKF_HD size_t r3_lds_bytes() const { return (size_t)r3_doubles() * 8; }
     // the Ruiz passes' temporaries (pc | En | Dn) sit behind the staged P blocks inside Sinv | Wk, which are not live yet
@@ -152,6 +155,16 @@ struct IdxT {
     DEKF_FN int rv(int k, int a) const { return rvb + 3 * k + a; }
 };
 
+// a * b rounded on its own: the compiler must not contract it into a following addition (the kernels that keep scaled bounds in an
+// array and the ones that rebuild them from the window record have to see the same bits)
+DEKF_FN double mul_rounded(double a, double b) {
+    double p = a * b;
+#if DEKF_DEVICE_BUILD
+    asm volatile("" : "+v"(p));
+#endif
+    return p;
+}
+
 template <int L, int NF = 0, bool FLDS = true, int FT = 0, bool R3_ = false>
 struct SolveCtx {
     static constexpr bool R3 = R3_;  // three workgroups per CU: row state in registers, x blocks compact in LDS (xb)
@@ -167,6 +180,8 @@ struct SolveCtx {
     // LDS always
     double *x, *z, *y, *xt, *zt, *at, *xs, *xd, *tmp;
     double* xb;       // R3: the x blocks of x, [K][NS], the only part of x an iteration shares between lanes
+    double *sx, *sy, *sz;  // R3: where the row state rests between chunks, by row: slack x (= at), y, z of the VO rows (from the first VO row)
+    bool cold;        // R3: no chunk has run yet (x = z = y = 0)
     double* cf;  // per row rho E D (aliases xt, which only the factorisation uses otherwise)
     double* gb;  // per step R' (dt^2/2 w_p + dt w_v): the Dyn rows' contribution to the bias columns (tail of xt)
     // LDS or HBM scratch
@@ -197,12 +212,14 @@ struct SolveCtx {
     // (hi is indexed from the first VO row; the full-length vector was 3.3 KiB of LDS for nothing)
     DEKF_FN double rho_at(int r) const { return r < ix.rvb ? RHO_EQ_OVER_RHO_INEQ * rho : rho_of(lo[r], hi[r - ix.rvb]); }
     // unscaled bound of row (k, kind, o): kind 0 Meas, 1 Dyn, 2 VO
-    DEKF_FN void bounds(int k, int kind, int o, double& lb, double& ub) const {
-        const double* r = rec(k);
+    DEKF_FN void bounds(int k, int kind, int o, double& lb, double& ub) const { bounds_at((kstart + k) % c.wcap, kind, o, lb, ub); }
+    // the same for a ring slot computed once (the modulo by a run-time ring size is a ~40-instruction software division)
+    DEKF_FN void bounds_at(int slot, int kind, int o, double& lb, double& ub) const {
+        const double* r = s.rec + ((size_t)b * c.wcap + slot) * c.rec;
         if (kind == 0) lb = ub = r[Rec::BM + o];
         else if (kind == 1) lb = ub = (o < 3 ? -0.5 * c.dt * c.dt * r[Rec::AS + o] : (o < 6 ? -c.dt * r[Rec::AS + o - 3] : 0.0));
         else {  // VO flag and bound come from the step's snapshot, not from the record (update(T + 1) may be rewriting them)
-            const double* v = vo + 4 * ((kstart + k) % c.wcap);
+            const double* v = vo + 4 * slot;
             if (v[0] != 0.0) lb = ub = v[1 + o];
             else { lb = -OSQP_INFTY; ub = OSQP_INFTY; }
         }
@@ -832,7 +849,12 @@ DEKF_FN bool solve_factor(Q& q) {
     if (!q.staged) stage_p(q);
     q.staged = false;  // 3c overwrites the staging area
     // a 3x3 slack block with a packed symmetric P block q6: rows r0.., slack variables sv0.. -> inverse Si, row weights Wt
-    auto block3 = [&](const double* q6, int r0, int sv0, double* Si_out, double* W_out) {
+    // Three-workgroup kernels keep the slack-block inverses in the HBM slab: there they are stored ENTRY-major ([entry][block]) so
+    // that the lanes of a wavefront, which own consecutive blocks, write and read consecutive doubles (block-major, a wave's store
+    // of one entry touched up to 64 different 32-byte sectors: 288 such stores per solve were most of the kernel's write traffic)
+    constexpr bool ST = Q::R3;
+    const int stv = ST ? K * L : 1, stw = ST ? K : 1;
+    auto block3 = [&](const double* q6, int r0, int sv0, double* Si_out, double* W_out, int sst) {
         double gv[3], rr[3], S6[6], Si[6];
         for (int a = 0; a < 3; ++a) {
             rr[a] = q.rho_at(r0 + a);
@@ -843,7 +865,7 @@ DEKF_FN bool solve_factor(Q& q) {
                 S6[symidx(a, d, 3)] = cc * q.D[sv0 + a] * q6[symidx(a, d, 3)] * q.D[sv0 + d];
         for (int a = 0; a < 3; ++a) S6[symidx(a, a, 3)] += sigma + gv[a] * q.E[r0 + a] * q.D[sv0 + a];
         inv3_sym(S6, Si);
-        for (int t = 0; t < 6; ++t) Si_out[t] = Si[t];
+        for (int t = 0; t < 6; ++t) Si_out[t * sst] = Si[t];
         for (int a = 0; a < 3; ++a)
             for (int d = a; d < 3; ++d)
                 W_out[symidx(a, d, 3)] = (a == d ? rr[a] : 0.0) - gv[a] * Si[symidx(a, d, 3)] * gv[d];
@@ -852,7 +874,7 @@ DEKF_FN bool solve_factor(Q& q) {
         int k = e / NB, blk = e - k * NB;
         const double* pk = q.Pst + k * PS;  // [Qm 6L | Qd 21 | Qc 6 | Qf 6L]
         if (blk < L) {
-            block3(pk + 6 * blk, ix.rm(k, 3 * blk), ix.v(k, 3 * blk), q.Sv + (k * L + blk) * 6, q.Wm + (k * L + blk) * 6);
+            block3(pk + 6 * blk, ix.rm(k, 3 * blk), ix.v(k, 3 * blk), q.Sv + (k * L + blk) * (ST ? 1 : 6), q.Wm + (k * L + blk) * 6, stv);
         } else if (k < K - 1 && blk == L) {
             const double* q21 = pk + 6 * L;
             double S[36], gv[9], rr[9];
@@ -869,28 +891,28 @@ DEKF_FN bool solve_factor(Q& q) {
                     S[6 * a + d] = cc * q.D[ix.w(k, a)] * symget(q21, a, d, 6) * q.D[ix.w(k, d)] +
                                    (a == d ? sigma + gv[a] * q.E[ix.rd(k, a)] * q.D[ix.w(k, a)] : 0.0);
             inv_spd_unrolled<6>(S);
-            double* sw = q.Sw + k * SWS;
+            double* sw = q.Sw + k * (ST ? 1 : SWS);
             double* wd = q.Wd + k * 24;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
                 for (int d = a; d < 6; ++d) {
                     double si = 0.5 * (S[6 * a + d] + S[6 * d + a]);
-                    sw[symidx(a, d, 6)] = si;
+                    sw[symidx(a, d, 6) * stw] = si;
                     wd[symidx(a, d, 6)] = (a == d ? rr[a] : 0.0) - gv[a] * si * gv[d];
                 }
 #pragma unroll
             for (int a = 6; a < 9; ++a) {
                 double dw = q.D[ix.w(k, a)];
                 double sdiag = cc * dw * c.Q_bias_dt2[a - 6] * dw + sigma + gv[a] * q.E[ix.rd(k, a)] * dw;
-                sw[21 + a - 6] = 1.0 / sdiag;
+                sw[(21 + a - 6) * stw] = 1.0 / sdiag;
                 wd[21 + a - 6] = rr[a] - gv[a] * gv[a] / sdiag;
             }
         } else if (k < K - 1 && blk == L + 1) {
-            block3(pk + 6 * L + 21, ix.rv(k, 0), ix.c(k, 0), q.Sc + k * 6, q.Wc + k * 6);
+            block3(pk + 6 * L + 21, ix.rv(k, 0), ix.c(k, 0), q.Sc + k * (ST ? 1 : 6), q.Wc + k * 6, stw);
         } else if (FT && k < K - 1 && blk >= L + 2) {
             const int leg = blk - L - 2;
-            block3(pk + 6 * L + 27 + 6 * leg, ix.rd(k, 9 + 3 * leg), ix.w(k, 9 + 3 * leg), q.Sf + (k * L + leg) * 6, q.Wf + (k * L + leg) * 6);
+            block3(pk + 6 * L + 27 + 6 * leg, ix.rd(k, 9 + 3 * leg), ix.w(k, 9 + 3 * leg), q.Sf + (k * L + leg) * 6, q.Wf + (k * L + leg) * 6, 1);
         }
     });
     DEKF_PROF_MARK(q, 6);
@@ -1379,20 +1401,27 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
             q.D = p; p += lay.n_pad;
             q.E = p; p += lay.m_pad;
             q.xb = p; p += NS * NH;
-            q.PA = DEKF_R3_PA_LDS ? p : gws + g.PA;  // at | xs | xd | gb are dead while a factorisation runs
-            q.at = p;
-            q.xs = p + lay.m_pad;
-            q.xd = q.xs + NS * NH;
-            q.gb = q.xd + NS * NH;
+            q.PA = DEKF_R3_PA_LDS ? p : gws + g.PA;  // everything in this region is dead while a factorisation runs
+            q.xd = p;
+            q.at = q.xd + NS * NH;
+            q.xs = q.at + lay.m_pad;
+            q.gb = q.xs + NS * NH;
+            q.sx = q.at;
+            q.sy = q.gb + 3 * NH;
+            q.sz = q.sy + lay.m_pad;
             p += lay.r3_pa_region();
             q.tmp = p; p += TM::LEN;
             q.Sinv = p; p += NH * NS2;
             q.Wk = p; p += NH * NS2;
             q.Sf = nullptr; q.Wf = nullptr;
-            // everything a lane keeps to itself between iterations lives in the workgroup's HBM slab while it is not in registers
-            q.x = gws + g.x; q.z = gws + g.z; q.y = gws + g.y; q.zt = gws + g.zt; q.cf = gws + g.cf;
+            // The row state is in registers during a chunk of iterations and in LDS (sx, sy, sz) between chunks; the slab holds it
+            // only across a refactorisation (whose temporaries need the LDS region): q.x <- sx, q.y <- sy, q.z <- sz.  What stays in
+            // the slab for the whole solve are constants: the scaled bounds (written once, at the cold start) and the slack-block
+            // inverses (once per factorisation) — 13 KB per workgroup.
+            q.x = gws + g.x; q.z = gws + g.z; q.y = gws + g.y; q.zt = nullptr; q.cf = nullptr;
             q.xt = nullptr;
             q.lo = gws + g.lo; q.hi = gws + g.hi;
+            q.cold = true;
             q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc;
             q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
         }
@@ -1480,7 +1509,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         // D and E stay in LDS for the whole solve; the Ruiz passes' temporaries pc, En, Dn sit behind the staged P blocks inside
         // S^-1 | W, which are not live before the first factorisation.
         constexpr int PSL = NFIX * (6 * L + 27) + NS * (NS + 1) / 2;
-        double *xg = q.x, *ztg = q.zt;
+        double *xg = q.x, *ztg = nullptr;
         q.x = q.Sinv + PSL;              // pc
         q.zt = q.x + lay.n_pad;          // En
         q.xt = q.zt + lay.m_pad;         // Dn
@@ -1496,7 +1525,8 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     q.rho = dmin(dmax(c.rho0, RHO_MIN), RHO_MAX);
     // scaled bounds, cold start
     double *x = q.x, *z = q.z, *y = q.y, *at = q.at;
-    wfor(n + m, [&](int e) {
+    wfor(R3 ? m : n + m, [&](int e0) {
+        const int e = R3 ? e0 + n : e0;  // (R3: only the scaled bounds; the first chunk's row-block load is the cold start x = z = y = 0)
         if (e < n) { x[e] = 0.0; return; }
         int r = e - n, k, kind, o;
         q.dec_row(r, k, kind, o);
@@ -1504,9 +1534,11 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         q.bounds(k, kind, o, lb, ub);
         q.lo[r] = lb * q.E[r];
         if (kind == 2) q.hi[r - q.ix.rvb] = ub * q.E[r];
-        z[r] = 0.0;
-        y[r] = 0.0;
-        at[r] = 0.0;  // u = rho z - y of the cold start
+        if constexpr (!R3) {
+            z[r] = 0.0;
+            y[r] = 0.0;
+            at[r] = 0.0;  // u = rho z - y of the cold start
+        }
     });
     DEKF_PROF_MARK(q, 19);
     bool ok = solve_factor(q);
@@ -1548,6 +1580,12 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         if (can_check || adapt_now || iter == c.max_iter) {
             double ra[6], va[8];
             residual_norms(q, ra, va);
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RESID)  // debugging aid: the 14 norms of the FIRST check into the stamp slots 16..29
+            if (DEKF_LANE() == 0 && iter <= c.check_termination) {
+                for (int i_ = 0; i_ < 6; ++i_) q.prof[16 + i_] = ra[i_];
+                for (int i_ = 0; i_ < 8; ++i_) q.prof[22 + i_] = va[i_];
+            }
+#endif
             info.pri_res = ra[0];
             info.dua_res = cinv * va[0];
             if (can_check || iter == c.max_iter) {
@@ -1564,7 +1602,23 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
                     q.rho = rho_new;
                     info.rho_updates++;
                     DEKF_SYNC();
+                    if constexpr (R3) {  // the factorisation's temporaries take the LDS the row state rests in: over to the slab and back
+                        const int mp = lay.m_pad, nz = 3 * NH;
+                        wfor(2 * mp + nz, [&](int e) {
+                            if (e < mp) q.x[e] = q.sx[e];
+                            else if (e < 2 * mp) q.y[e - mp] = q.sy[e - mp];
+                            else q.z[e - 2 * mp] = q.sz[e - 2 * mp];
+                        });
+                    }
                     ok = solve_factor(q);
+                    if constexpr (R3) {
+                        const int mp = lay.m_pad, nz = 3 * NH;
+                        wfor(2 * mp + nz, [&](int e) {
+                            if (e < mp) q.sx[e] = q.x[e];
+                            else if (e < 2 * mp) q.sy[e - mp] = q.y[e - mp];
+                            else q.sz[e - 2 * mp] = q.z[e - 2 * mp];
+                        });
+                    }
                     if constexpr (!R3) {
                     if (ok) phase_rows<true>(q, alpha, sigma);  // cf, t, w for the new rho (the scratch aliased xt | zt | at)
                     }
@@ -1580,7 +1634,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     double xT[NS];
     bool finite = ok;
     for (int j = 0; j < NS; ++j) {
-        xT[j] = q.D[ix.x(K - 1, j)] * x[ix.x(K - 1, j)];
+        xT[j] = q.D[ix.x(K - 1, j)] * (R3 ? q.xb[NS * (K - 1) + j] : x[ix.x(K - 1, j)]);
         if (!(fabs(xT[j]) <= 1e300)) finite = false;
     }
     if (!finite) info.status = DEKF_SOLVE_NUMERIC;

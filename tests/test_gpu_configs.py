@@ -339,6 +339,33 @@ def test_three_workgroup_kernel_is_bit_identical_to_the_two_workgroup_kernel(mak
     assert np.array_equal(i3["pri_res"], i2["pri_res"]) and np.array_equal(i3["dua_res"], i2["dua_res"])
 
 
+def test_three_workgroup_kernel_with_vo_rows_and_two_rho_updates():
+    """Past tick 40 the VO rows of the window are equalities with weights of 4.4e9 and many solves refactorise twice (100
+    iterations).  There the two kernels are no longer bit-identical (tools/r3_identity_check.py: the first difference is at the
+    first such tick, 8e-11 in the states — rounding differences, amplified by the VO weights into 40 % of the tiny final dual
+    residual); what must hold is what the oracle tests ask of either of them: same iteration counts, states equal far inside
+    the tolerance."""
+    p = go1_params()
+    p.ekf_rate = p.rate
+    B, K = 1000, p.N + 30
+    sd = streams_to_device(make_streams(p, B, K))
+    outs = []
+    for cap in (0, 2):
+        q = p.copy()
+        q.solve_workgroups_per_cu = cap
+        est = BatchedEstimator(q, B)
+        for k in range(K):
+            est.push_stream_step(sd, k)
+            est.step(k)
+        outs.append((est.get(), est.solver_info()))
+        est.close()
+    (o3, i3), (o2, i2) = outs
+    assert (o3["status"] == 1).all() and (o2["status"] == 1).all()
+    assert i3["rho_updates"].max() >= 2 and i3["iters"].max() >= 100
+    assert np.array_equal(i3["iters"], i2["iters"]) and np.array_equal(i3["rho_updates"], i2["rho_updates"])
+    assert np.abs(o3["x"] - o2["x"]).max() <= 1e-9 and np.abs(o3["v_b"] - o2["v_b"]).max() <= 1e-9
+
+
 def test_pipelined_steps_are_bit_identical_to_in_order_steps():
     """dekf_params.solve_pipeline = 1: the solve of step T runs on a second stream out of a snapshot of what step T + 1
     overwrites (arrival cost, VO flags / bounds of the window) and into its own set of outputs and scratch slabs, so step
