@@ -77,7 +77,8 @@ struct Rec {
 // packed symmetric index, i <= j, n x n
 DEKF_FN int symidx(int i, int j, int n) { return i * n - (i * (i - 1)) / 2 + (j - i); }
 // branch-free for either order of (i, j): lo * (2n - 1 - lo) / 2 + hi
-DEKF_FN double symget(const double* s, int i, int j, int n) {
+template <class P>  // P: const double* or the checked pointer of the -DDEKF_BOUNDS build
+DEKF_FN double symget(P s, int i, int j, int n) {
     int lo = i < j ? i : j, hi = i < j ? j : i;
     return s[(lo * (2 * n - 1 - lo)) / 2 + hi];
 }

@@ -683,6 +683,33 @@ dekf_status dekf_debug_sections(dekf_handle h, double* out_host) {
     return DEKF_OK;
 }
 
+#ifdef DEKF_BOUNDS
+extern "C" __global__ void k_bounds_selftest(double* a);
+dekf_status dekf_debug_bounds_selftest(void) {
+    double* a = nullptr;
+    HIPCHK(hipMalloc(&a, 32 * sizeof(double)));
+    k_bounds_selftest<<<1, 1>>>(a);
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipFree(a));
+    return DEKF_OK;
+}
+// not part of include/dekf.h: the bounds-checked diagnostic build (libdekf_bounds.so, wave.h: BPtr).  out[0] = out-of-range
+// dereferences since the library was loaded, out[1] = offset of the first one in elements from the start of its array,
+// out[2] = that array's extent, out[3] = unused.  Synchronises the device.
+dekf_status dekf_debug_bounds_reset(void) {
+    const unsigned long long z[4] = {0ull, 0ull, 0ull, 0ull};
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(dekf::dekf_bounds_hits), z, sizeof(z)));
+    return DEKF_OK;
+}
+dekf_status dekf_debug_bounds(unsigned long long* out4) {
+    if (!out4) return fail(DEKF_ERR_INVALID, "null argument");
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpyFromSymbol(out4, HIP_SYMBOL(dekf::dekf_bounds_hits), 4 * sizeof(unsigned long long)));
+    return DEKF_OK;
+}
+#endif
+
 // ---------------------------------------------------------------- RCCL all-gather
 dekf_status dekf_comm_unique_id(void* id_out) {
     if (!id_out) return fail(DEKF_ERR_INVALID, "null argument");

@@ -20,6 +20,18 @@
 
 using namespace dekf;
 
+#ifdef DEKF_BOUNDS
+namespace dekf {
+__device__ unsigned long long dekf_bounds_hits[4] = {0ull, 0ull, 0ull, 0ull};  // wave.h: BPtr
+}
+// proves that the checker fires: one read and one write just past a 16-element array (both are counted and redirected)
+extern "C" __global__ void k_bounds_selftest(double* a) {
+    dekf::dptr p = DEKF_SPAN(a, 16);
+    const double v = p[16];
+    (p + 3)[13] = v + 1.0;
+}
+#endif
+
 extern "C" {
 
 __global__ void __launch_bounds__(64) k_ekf_tick(DevCfg c, DevState s, int count) {
@@ -49,87 +61,106 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
 #ifndef DEKF_SOLVE_MIN_WAVES
 #define DEKF_SOLVE_MIN_WAVES 2
 #endif
-// -DDEKF_GO1_ONLY (A/B builds of the benchmark shape, tools/ab_variants.sh): every solve kernel but the two Go1 N = 20
-// ones is an empty stub, which cuts the build from minutes to seconds.  Such a library solves nothing but Go1, N = 20.
+// Which solve kernels a build carries: -DDEKF_KSET=<mask> (default: all).  Kernels outside the mask are empty stubs, so a library
+// built with a mask solves only the shapes of its kernels.  1: Go1 N = 20 (k_mhe_solve_ll_4_n20, k_mhe_solve_r3_4_n20) — what
+// -DDEKF_GO1_ONLY selects, the A/B builds of the benchmark shape (tools/ab_variants.sh; builds in seconds instead of minutes);
+// 2: Cassie N = 20 (k_mhe_solve_lg_2_n20, k_mhe_solve_r3_2_n20); 4 / 8 / 16 / 32: the generic kernels for 1 / 2 / 3 / 4 legs;
+// 64 / 128 / 256 / 512: the foot-position kernels (leg_odom_type 1) for 1 / 2 / 3 / 4 legs.  The bounds-checked diagnostic build
+// is compiled one mask at a time (tools/build_bounds.sh): with checked pointers one translation unit of everything takes hours.
+#ifndef DEKF_KSET
 #ifdef DEKF_GO1_ONLY
-#define DEKF_SOLVE_KERNEL(NAME, LEGS, FL, PL) __global__ void NAME(DevCfg, DevState, int, int, int) {}
+#define DEKF_KSET 1
 #else
-#define DEKF_SOLVE_KERNEL(NAME, LEGS, FL, PL)                                                            \
-    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_SOLVE_MIN_WAVES) NAME(DevCfg c, DevState s, int kstart, int K, \
-                                                                  int gws_len) {                         \
-        extern __shared__ double lds[];                                                                  \
-        double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                              \
-        for (int b = blockIdx.x; b < c.B; b += gridDim.x)                                                \
-            solve_window<LEGS, FL, PL>(c, s, b, kstart, K, lds, gws);                                    \
+#define DEKF_KSET 0x3FF
+#endif
+#endif
+#define DEKF_STUB_KERNEL(NAME) __global__ void NAME(DevCfg, DevState, int, int, int) {}
+#define DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, ...)                                                                             \
+    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, WAVES) NAME(DevCfg c, DevState s, int kstart, int K, int gws_len) { \
+        extern __shared__ double lds[];                                                                                      \
+        double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                                                  \
+        for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<__VA_ARGS__>(c, s, b, kstart, K, lds, gws);            \
     }
-#endif
-#define DEKF_SOLVE_KERNELS(LEGS)                            \
-    DEKF_SOLVE_KERNEL(k_mhe_solve_ll_##LEGS, LEGS, true, true)   \
-    DEKF_SOLVE_KERNEL(k_mhe_solve_lg_##LEGS, LEGS, true, false)  \
-    DEKF_SOLVE_KERNEL(k_mhe_solve_gg_##LEGS, LEGS, false, false)
-// the benchmark shape (Go1, N = 20) additionally with the horizon as a compile-time constant
-extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) k_mhe_solve_ll_4_n20(DevCfg c, DevState s, int kstart, int K,
-                                                                                   int gws_len) {
-    extern __shared__ double lds[];
-    double* gws = s.gws + (size_t)blockIdx.x * gws_len;
-    for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<4, true, true, 20>(c, s, b, kstart, K, lds, gws);
-}
-// Cassie (2 legs, N = 20; its factor-time temporary does not fit next to the vectors: _lg placement)
-#ifdef DEKF_GO1_ONLY
-extern "C" __global__ void k_mhe_solve_lg_2_n20(DevCfg, DevState, int, int, int) {}
-extern "C" __global__ void k_mhe_solve_r3_2_n20(DevCfg, DevState, int, int, int) {}
+#define DEKF_SOLVE_KERNEL_IF(BIT, NAME, WAVES, ...) DEKF_SOLVE_KERNEL_IF_(BIT, NAME, WAVES, __VA_ARGS__)
+#define DEKF_SOLVE_KERNEL_IF_(BIT, NAME, WAVES, ...) DEKF_SOLVE_KERNEL_SEL_##BIT(NAME, WAVES, __VA_ARGS__)
+// one selector per bit (the preprocessor cannot branch on an expression inside a macro body)
+#if DEKF_KSET & 1
+#define DEKF_SOLVE_KERNEL_SEL_0(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
 #else
-extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, 2) k_mhe_solve_lg_2_n20(DevCfg c, DevState s, int kstart, int K,
-                                                                                   int gws_len) {
-    extern __shared__ double lds[];
-    double* gws = s.gws + (size_t)blockIdx.x * gws_len;
-    for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<2, true, false, 20>(c, s, b, kstart, K, lds, gws);
-}
+#define DEKF_SOLVE_KERNEL_SEL_0(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
 #endif
-// Full windows of the two fixed-horizon shapes: THREE workgroups per CU (mhe_admm_core.h, admm_chunk_r3: row state in registers,
-// 45 KiB of LDS per instance, 168 VGPRs).  The window-fill ticks (K < N) keep the two-workgroup kernels above.
-#ifndef DEKF_NO_R3
-extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_R3_WAVES) k_mhe_solve_r3_4_n20(DevCfg c, DevState s, int kstart, int K,
-                                                                                   int gws_len) {
-    extern __shared__ double lds[];
-    double* gws = s.gws + (size_t)blockIdx.x * gws_len;
-    for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<4, true, true, 20, 0, true>(c, s, b, kstart, K, lds, gws);
-}
-#ifndef DEKF_GO1_ONLY
-extern "C" __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_R3_WAVES) k_mhe_solve_r3_2_n20(DevCfg c, DevState s, int kstart, int K,
-                                                                                   int gws_len) {
-    extern __shared__ double lds[];
-    double* gws = s.gws + (size_t)blockIdx.x * gws_len;
-    for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<2, true, true, 20, 0, true>(c, s, b, kstart, K, lds, gws);
-}
+#if DEKF_KSET & 2
+#define DEKF_SOLVE_KERNEL_SEL_1(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
+#else
+#define DEKF_SOLVE_KERNEL_SEL_1(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
 #endif
+#if DEKF_KSET & 4
+#define DEKF_SOLVE_KERNEL_SEL_2(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
+#else
+#define DEKF_SOLVE_KERNEL_SEL_2(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
 #endif
-DEKF_SOLVE_KERNELS(1)
-DEKF_SOLVE_KERNELS(2)
-DEKF_SOLVE_KERNELS(3)
-DEKF_SOLVE_KERNELS(4)
+#if DEKF_KSET & 8
+#define DEKF_SOLVE_KERNEL_SEL_3(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
+#else
+#define DEKF_SOLVE_KERNEL_SEL_3(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
+#endif
+#if DEKF_KSET & 16
+#define DEKF_SOLVE_KERNEL_SEL_4(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
+#else
+#define DEKF_SOLVE_KERNEL_SEL_4(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
+#endif
+#if DEKF_KSET & 32
+#define DEKF_SOLVE_KERNEL_SEL_5(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
+#else
+#define DEKF_SOLVE_KERNEL_SEL_5(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
+#endif
+#if DEKF_KSET & 64
+#define DEKF_SOLVE_KERNEL_SEL_6(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
+#else
+#define DEKF_SOLVE_KERNEL_SEL_6(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
+#endif
+#if DEKF_KSET & 128
+#define DEKF_SOLVE_KERNEL_SEL_7(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
+#else
+#define DEKF_SOLVE_KERNEL_SEL_7(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
+#endif
+#if DEKF_KSET & 256
+#define DEKF_SOLVE_KERNEL_SEL_8(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
+#else
+#define DEKF_SOLVE_KERNEL_SEL_8(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
+#endif
+#if DEKF_KSET & 512
+#define DEKF_SOLVE_KERNEL_SEL_9(NAME, WAVES, ...) DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, __VA_ARGS__)
+#else
+#define DEKF_SOLVE_KERNEL_SEL_9(NAME, WAVES, ...) DEKF_STUB_KERNEL(NAME)
+#endif
+// three placements of the factor per leg count: _ll all in LDS, _lg factor-time temporary in HBM, _gg factor streamed from HBM
+#define DEKF_SOLVE_KERNELS(BIT, LEGS)                                                                       \
+    DEKF_SOLVE_KERNEL_IF(BIT, k_mhe_solve_ll_##LEGS, DEKF_SOLVE_MIN_WAVES, LEGS, true, true)                \
+    DEKF_SOLVE_KERNEL_IF(BIT, k_mhe_solve_lg_##LEGS, DEKF_SOLVE_MIN_WAVES, LEGS, true, false)               \
+    DEKF_SOLVE_KERNEL_IF(BIT, k_mhe_solve_gg_##LEGS, DEKF_SOLVE_MIN_WAVES, LEGS, false, false)
+// the benchmark shape (Go1, N = 20) additionally with the horizon as a compile-time constant; its full windows run THREE
+// workgroups per CU (mhe_admm_core.h, admm_chunk_r3: row state in registers, 168 VGPRs); the window-fill ticks (K < N) keep the
+// two-workgroup kernel
+DEKF_SOLVE_KERNEL_IF(0, k_mhe_solve_ll_4_n20, 2, 4, true, true, 20)
+DEKF_SOLVE_KERNEL_IF(0, k_mhe_solve_r3_4_n20, DEKF_R3_WAVES, 4, true, true, 20, 0, true)
+// Cassie (2 legs, N = 20; its factor-time temporary does not fit next to the vectors: _lg placement)
+DEKF_SOLVE_KERNEL_IF(1, k_mhe_solve_lg_2_n20, 2, 2, true, false, 20)
+DEKF_SOLVE_KERNEL_IF(1, k_mhe_solve_r3_2_n20, DEKF_R3_WAVES, 2, true, true, 20, 0, true)
+DEKF_SOLVE_KERNELS(2, 1)
+DEKF_SOLVE_KERNELS(3, 2)
+DEKF_SOLVE_KERNELS(4, 3)
+DEKF_SOLVE_KERNELS(5, 4)
 // leg_odom_type 1: the foot positions are states (9 + 3 LEGS per window step, 21 for Go1).  Two placements: factor in
 // LDS with the factor-time temporary in HBM (short windows), factor streamed from the workgroup's HBM slab (Go1, N = 20:
 // S^-1 and W alone are 141 KB).
-#ifdef DEKF_GO1_ONLY
-#define DEKF_SOLVE_KERNEL_FOOT(NAME, LEGS, FL) __global__ void NAME(DevCfg, DevState, int, int, int) {}
-#else
-#define DEKF_SOLVE_KERNEL_FOOT(NAME, LEGS, FL)                                                                \
-    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, DEKF_SOLVE_MIN_WAVES) NAME(DevCfg c, DevState s, int kstart, int K, \
-                                                                  int gws_len) {                             \
-        extern __shared__ double lds[];                                                                      \
-        double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                                  \
-        for (int b = blockIdx.x; b < c.B; b += gridDim.x)                                                    \
-            solve_window<LEGS, FL, false, 0, 1>(c, s, b, kstart, K, lds, gws);                               \
-    }
-#endif
-#define DEKF_SOLVE_KERNELS_FOOT(LEGS)                               \
-    DEKF_SOLVE_KERNEL_FOOT(k_mhe_solve_foot_lg_##LEGS, LEGS, true)  \
-    DEKF_SOLVE_KERNEL_FOOT(k_mhe_solve_foot_gg_##LEGS, LEGS, false)
-DEKF_SOLVE_KERNELS_FOOT(1)
-DEKF_SOLVE_KERNELS_FOOT(2)
-DEKF_SOLVE_KERNELS_FOOT(3)
-DEKF_SOLVE_KERNELS_FOOT(4)
+#define DEKF_SOLVE_KERNELS_FOOT(BIT, LEGS)                                                                         \
+    DEKF_SOLVE_KERNEL_IF(BIT, k_mhe_solve_foot_lg_##LEGS, DEKF_SOLVE_MIN_WAVES, LEGS, true, false, 0, 1)           \
+    DEKF_SOLVE_KERNEL_IF(BIT, k_mhe_solve_foot_gg_##LEGS, DEKF_SOLVE_MIN_WAVES, LEGS, false, false, 0, 1)
+DEKF_SOLVE_KERNELS_FOOT(6, 1)
+DEKF_SOLVE_KERNELS_FOOT(7, 2)
+DEKF_SOLVE_KERNELS_FOOT(8, 3)
+DEKF_SOLVE_KERNELS_FOOT(9, 4)
 
 __global__ void __launch_bounds__(64) k_kf_initialize(DevCfg c, DevState s) {
     extern __shared__ double lds[];

@@ -65,7 +65,7 @@ DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
     const bool hn = k < q.K - 1, hp = k > 0;
     const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-    const double* R = q.R + 9 * kn;
+    cdptr R = q.R + 9 * kn;
     const int rn = q.ix.rd(kn, 0);
     const double p0 = w(q.ix.rd(kp, 6 + a));
     double g = w(rn + 6 + a);
@@ -82,8 +82,8 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
     constexpr int NS = Q::NS, NM = 3 * Q::LEGS, SV = 2 * NS + 3 + NM;
     const int K = q.K, n3 = 3 * K, nt = (n3 + 63) >> 6;
     const int ntf = Q::FOOT ? (NM * K + 63) >> 6 : 0;
-    const double* qsl = q.tmp + TmpMap<NS>::QSL;
-    const double* at = q.at;
+    cdptr qsl = q.tmp + TmpMap<NS>::QSL;
+    cdptr at = q.at;
     auto w = [&](int r) { return at[r]; };
 #if defined(DEKF_PROFILE_TL) && defined(DEKF_PROFILE_TLX)  // -DDEKF_PROFILE_TLX: slots 4.. and 8.. describe phase X instead of the row phase
     const long long tx0 = clock64();
@@ -136,7 +136,7 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
 // Inline assembly gets no hazard handling from the compiler: a VALU write of v followed by a DPP read of
 // it needs two wait states, hence the s_nop inside the first statement (which has v as an input, so the
 // nop cannot be scheduled before the instruction that produces v).
-DEKF_FN double chain_matvec_dpp(double v, const double* w, double rhs) {
+DEKF_FN double chain_matvec_dpp(double v, cdptr w, double rhs) {
     // TWO accumulators in alternation: a dependent DPP FMA two slots (32 issue cycles) after its predecessor does not
     // stall, and only one addition is left behind the last FMA (three accumulators and two dependent additions were
     // 1.4 % of the whole solve slower; three FMAs in a row on one accumulator stall)
@@ -165,7 +165,7 @@ DEKF_FN double chain_matvec_dpp(double v, const double* w, double rhs) {
 template <bool TR, bool BWD, int STEPS = 0, class Q>
 DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
-    double *xs = q.xs, *xd = q.xd, *x = q.x;
+    dptr xs = q.xs, xd = q.xd, x = q.x;
 #if DEKF_DEVICE_BUILD
     const int lane = DEKF_LANE() & 63;
     const int i = lane < 9 ? lane : 8;
@@ -175,7 +175,7 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
     // compiler cannot do this itself: it may not move the loads above the step's own LDS store.)
     struct Ops { double w[9], rhs, dsc, xo; };
     auto load = [&](int kn, Ops& o) {
-        const double* W = q.Wk + (kn + wofs) * 81;
+        cdptr W = q.Wk + (kn + wofs) * 81;
 #pragma unroll
         for (int t = 0; t < 9; ++t) o.w[t] = TR ? W[9 * t + i] : W[9 * i + t];
         o.rhs = BWD ? xd[9 * kn + i] : xs[9 * kn + i];
@@ -242,7 +242,7 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
     for (int i = 0; i < 9; ++i) v[i] = xs[9 * k0 + i];
     for (int s = 1; s <= steps; ++s) {
         const int kn = k0 + s * dk;
-        const double* W = q.Wk + (kn + wofs) * 81;
+        cdptr W = q.Wk + (kn + wofs) * 81;
         for (int i = 0; i < 9; ++i) {
             double w[9];
             for (int t = 0; t < 9; ++t) w[t] = TR ? W[9 * t + i] : W[9 * i + t];
@@ -272,14 +272,14 @@ template <class Q>
 DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
     const int K = q.K, mid = mid_block(K);
-    double *xs = q.xs, *xd = q.xd, *x = q.x;
-    const double* Si = q.Sinv + mid * 81;
+    dptr xs = q.xs, xd = q.xd, x = q.x;
+    cdptr Si = q.Sinv + mid * 81;
 #if DEKF_DEVICE_BUILD
     const int i = lane < 9 ? lane : 8;
     double f = xs[9 * mid + i];
     if (mid < K - 1) {
-        const double* W = q.Wk + mid * 81 + 9 * i;
-        const double* fh = xs + 9 * (mid + 1);
+        cdptr W = q.Wk + mid * 81 + 9 * i;
+        cdptr fh = xs + 9 * (mid + 1);
         double a0 = W[0] * fh[0] + W[3] * fh[3] + W[6] * fh[6];
         double a1 = W[1] * fh[1] + W[4] * fh[4] + W[7] * fh[7];
         double a2 = W[2] * fh[2] + W[5] * fh[5] + W[8] * fh[8];
@@ -301,8 +301,8 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
     for (int i = 0; i < 9; ++i) {
         f[i] = xs[9 * mid + i];
         if (mid < K - 1) {
-            const double* W = q.Wk + mid * 81 + 9 * i;
-            const double* fh = xs + 9 * (mid + 1);
+            cdptr W = q.Wk + mid * 81 + 9 * i;
+            cdptr fh = xs + 9 * (mid + 1);
             double a0 = W[0] * fh[0] + W[3] * fh[3] + W[6] * fh[6];
             double a1 = W[1] * fh[1] + W[4] * fh[4] + W[7] * fh[7];
             double a2 = W[2] * fh[2] + W[5] * fh[5] + W[8] * fh[8];
@@ -378,24 +378,24 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
     const bool act = li < 9, leg = row < 2, top = (row & 1) == 0;
     // the x blocks of x and D: inside the full variable vector (stride SV per step), or compact (R3: [K][9] in LDS)
     constexpr int XST = Q::R3 ? 9 : SV;
-    double *xs = q.xs, *xd = q.xd, *x = Q::R3 ? q.xb : q.x;
-    const double* Dx = q.D;  // (always inside the full scaling vector: stride SV)
+    dptr xs = q.xs, xd = q.xd, x = Q::R3 ? q.xb : q.x;
+    cdptr Dx = q.D;  // (always inside the full scaling vector: stride SV)
     struct Ops { double w[9], rhs; };
     // ---------------- forward: step s = 1..M
-    const double* fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
+    cdptr fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
     const int fstep = top ? 81 : -81;
     q.tmp[260 + lane] = 0.0;  // a zero the rows without a right-hand side can load (tmp[257..338) is free on the device)
     const int rstep = top ? 9 : -9;
-    const double* fr = leg ? xs + (top ? 9 : 9 * (K - 2)) + i : q.tmp + 260 + lane;  // rhs of step 1 (legs) | 0
+    cdptr fr = leg ? xs + (top ? 9 : 9 * (K - 2)) + i : q.tmp + 260 + lane;  // rhs of step 1 (legs) | 0
     const int frstep = leg ? rstep : 0;
     // Stores go through per-lane pointers and strides, lanes with nothing to store aim at a private dummy slot
     // (tmp[176 + lane], free between factorisations): no EXEC juggling and no select inside a step.
-    double* dummy = q.tmp + 176 + lane;
+    dptr dummy = q.tmp + 176 + lane;
     const bool gown = !leg && act;
-    double* gst = gown ? xd + (top ? 0 : 9 * (K - 1)) + i : dummy;  // where rows 2, 3 put -g of step 1
+    dptr gst = gown ? xd + (top ? 0 : 9 * (K - 1)) + i : dummy;  // where rows 2, 3 put -g of step 1
     const int gstep = gown ? rstep : 0;
     auto fload = [&](int s, Ops& o) {
-        const double* W = fm + (s - 1) * fstep;
+        cdptr W = fm + (s - 1) * fstep;
 #pragma unroll
         for (int t = 0; t < 9; ++t) o.w[t] = W[t];
         o.rhs = fr[(s - 1) * frstep];
@@ -421,7 +421,7 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
     //   u_M = row 0 + row 2,  u_{M+1} = row 1 + row 3
     {
         double w[9];
-        const double* W = row == 0 ? q.Sinv + M * 81 + 9 * i : (row == 1 ? q.Sinv + (M + 1) * 81 + 9 * i : q.Wk + M * 81 + (row == 2 ? 9 * i : i));
+        cdptr W = row == 0 ? q.Sinv + M * 81 + 9 * i : (row == 1 ? q.Sinv + (M + 1) * 81 + 9 * i : q.Wk + M * 81 + (row == 2 ? 9 * i : i));
         const int wst = row == 3 ? 9 : 1;  // row 3 reads P12 transposed
 #pragma unroll
         for (int t = 0; t < 9; ++t) w[t] = W[t * wst];
@@ -443,14 +443,14 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
         static_assert(K - 2 - M == M, "both outward legs M steps");
         const bool own = leg && act;
         const int b0 = top ? M : M + 1;
-        double* xdp = own ? xd + 9 * b0 + i : dummy;       // the leg's start block; step s is at +- s blocks
-        double* xp = own ? x + b0 * XST + i : dummy;
-        const double* Dp = own ? Dx + b0 * SV + i : dummy;
+        dptr xdp = own ? xd + 9 * b0 + i : dummy;       // the leg's start block; step s is at +- s blocks
+        dptr xp = own ? x + b0 * XST + i : dummy;
+        cdptr Dp = own ? Dx + b0 * SV + i : dummy;
         const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0, dstep = own ? (top ? -SV : SV) : 0;
-        const double* Wp = q.Wk + M * 81 + i;              // row 0: W_{M-s}', row 1: W^_{M+s}'
+        cdptr Wp = q.Wk + M * 81 + i;              // row 0: W_{M-s}', row 1: W^_{M+s}'
         const int wstep = top ? -81 : 81;
         auto bload = [&](int s, Bops& o) {
-            const double* W = Wp + s * wstep;
+            cdptr W = Wp + s * wstep;
 #pragma unroll
             for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
             o.ng = xdp[s * xdstep];
@@ -484,21 +484,21 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
     const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15;
     const int i = li < 9 ? li : 8;
     const bool act = li < 9, leg = row < 2, top = (row & 1) == 0;
-    double *xs = q.xs, *xd = q.xd, *x = q.x;
+    dptr xs = q.xs, xd = q.xd, x = q.x;
     struct Ops { double w[9], rhs; };
     // ---------------- forward: step s = 1..M
-    const double* fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
+    cdptr fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
     const int fstep = top ? 81 : -81;
     q.tmp[260 + lane] = 0.0;  // a zero the rows without a right-hand side can load
     const int rstep = top ? 9 : -9;
-    const double* fr = leg ? xs + (top ? 9 : 9 * (K - 2)) + i : q.tmp + 260 + lane;
+    cdptr fr = leg ? xs + (top ? 9 : 9 * (K - 2)) + i : q.tmp + 260 + lane;
     const int frstep = leg ? rstep : 0;
-    double* dummy = q.tmp + 176 + lane;
+    dptr dummy = q.tmp + 176 + lane;
     const bool gown = !leg && act;
-    double* gst = gown ? xd + (top ? 0 : 9 * (K - 1)) + i : dummy;  // where rows 2, 3 put -g of step 1
+    dptr gst = gown ? xd + (top ? 0 : 9 * (K - 1)) + i : dummy;  // where rows 2, 3 put -g of step 1
     const int gstep = gown ? rstep : 0;
     auto fload = [&](int s, Ops& o) {
-        const double* W = fm + (s - 1) * fstep;
+        cdptr W = fm + (s - 1) * fstep;
 #pragma unroll
         for (int t = 0; t < 9; ++t) o.w[t] = W[t];
         o.rhs = fr[(s - 1) * frstep];
@@ -528,7 +528,7 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
     // ---------------- meeting block (row 0) and the last g of the bottom half (row 3)
     {
         double w[9];
-        const double* W = row == 0 ? q.Wk + M * 81 + 9 * i : q.Sinv + (M + 1) * 81 + 9 * i;
+        cdptr W = row == 0 ? q.Wk + M * 81 + 9 * i : q.Sinv + (M + 1) * 81 + 9 * i;
         const double z = (row == 0 || row == 3) ? 1.0 : 0.0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) w[t] = z * W[t];
@@ -550,15 +550,15 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
     {
         struct Bops { double w[9], ng, dsc, xo; };
         const bool own = leg && act;
-        double* xdp = own ? xd + 9 * M + i : dummy;
-        double* xp = own ? x + M * SV + i : dummy;
-        const double* Dp = q.D + (own ? M * SV + i : 0);     // (D may sit in HBM: no LDS dummy here, idle lanes re-read D[0])
+        dptr xdp = own ? xd + 9 * M + i : dummy;
+        dptr xp = own ? x + M * SV + i : dummy;
+        cdptr Dp = q.D + (own ? M * SV + i : 0);     // (D may sit in HBM: no LDS dummy here, idle lanes re-read D[0])
         const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -SV : SV) : 0;
-        const double* Wp = q.Wk + (top ? M : M - 1) * 81 + i;  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
+        cdptr Wp = q.Wk + (top ? M : M - 1) * 81 + i;  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
         const int wstep = top ? -81 : 81;
         auto bload = [&](int s, Bops& o) {
             const int sl = s <= M ? s : (top ? M : s);  // row 0 has one step less: its last load repeats block 0
-            const double* W = Wp + sl * wstep;
+            cdptr W = Wp + sl * wstep;
 #pragma unroll
             for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
             o.ng = xdp[sl * xdstep];
@@ -613,7 +613,7 @@ DEKF_FN RowPairVec pair_redistribute(double own) {  // rows [r0 r1 r2 r3] -> va 
     return r;
 }
 template <int NS>
-DEKF_FN double pair_matvec_dpp(double va, double vb, const double* w, double rhs) {
+DEKF_FN double pair_matvec_dpp(double va, double vb, cdptr w, double rhs) {
     static_assert(NS > 9 && NS <= 32, "two rows per block");
     double a0 = rhs, a1 = 0.0;
 #define DEKF_PFMAC(pre, acc, src, T, IDX)                                                                          \
@@ -639,7 +639,7 @@ template <bool BWD, class Q>
 DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
     constexpr int NS = Q::NS, NS2 = Q::NS2, SV = 2 * NS + 3 + 3 * Q::LEGS;
     const int K = q.K, mid = mid_block(K);
-    double *xs = q.xs, *xd = q.xd, *x = q.x;
+    dptr xs = q.xs, xd = q.xd, x = q.x;
     // side 0 (top): blocks k0 + s dk; the matrix of step s is Wk[kn + wofs], transposed on the way out
     const int k0s[2] = {BWD ? mid : 0, BWD ? mid : K - 1};
     const int dks[2] = {BWD ? -1 : 1, BWD ? 1 : -1};
@@ -657,14 +657,16 @@ DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
         const int sc = s <= steps ? s : (steps > 0 ? steps : 1);  // a finished (or empty) side re-reads a valid block
         const int kn = steps > 0 ? k0 + sc * dk : k0;
         const int kw = steps > 0 ? kn + wofs : (k0 + wofs >= 0 && k0 + wofs < K - 1 ? k0 + wofs : 0);
-        const double* W = q.Wk + kw * NS2;
+        cdptr W = q.Wk + kw * NS2;
 #pragma unroll
         for (int t = 0; t < NS; ++t) o.w[t] = BWD ? W[NS * t + i] : W[NS * i + t];
         o.rhs = BWD ? xd[NS * kn + i] : xs[NS * kn + i];
         o.dsc = BWD ? q.D[kn * SV + i] : 0.0;
         o.xo = BWD ? x[kn * SV + i] : 0.0;
     };
-    double va = xs[NS * k0 + li], vb = xs[NS * k0 + (16 + li < NS ? 16 + li : NS - 1)];
+    // (lanes beyond the block's last component mirror it: with NS < 16 a plain xs[NS k0 + li] read past the last block of the array,
+    // found by the -DDEKF_BOUNDS build; the mirrored values are never broadcast)
+    double va = xs[NS * k0 + (li < NS ? li : NS - 1)], vb = xs[NS * k0 + (16 + li < NS ? 16 + li : NS - 1)];
     auto step = [&](int s, const Ops& c) {
         const double own = pair_matvec_dpp<NS>(va, vb, c.w, c.rhs);
         const RowPairVec nv = pair_redistribute(own);
@@ -707,7 +709,7 @@ DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
         for (int i = 0; i < NS; ++i) v[i] = xs[NS * k0 + i];
         for (int s = 1; s <= steps; ++s) {
             const int kn = k0 + s * dk;
-            const double* W = q.Wk + (kn + wofs) * NS2;
+            cdptr W = q.Wk + (kn + wofs) * NS2;
             for (int i = 0; i < NS; ++i) {
                 double a0 = BWD ? xd[NS * kn + i] : xs[NS * kn + i], a1 = 0.0;
                 for (int t = 0; t < NS; ++t) {
@@ -735,15 +737,15 @@ template <class Q>
 DEKF_FN void sweep_mid_block_generic(Q& q, int lane, double alpha) {
     constexpr int NS = Q::NS, NS2 = Q::NS2, SV = 2 * NS + 3 + 3 * Q::LEGS;
     const int K = q.K, mid = mid_block(K);
-    double *xs = q.xs, *xd = q.xd, *x = q.x;
-    const double* Si = q.Sinv + mid * NS2;
-    double* ft = q.tmp + TmpMap<NS>::SIDE0;  // factor-time scratch, free during the iterations
+    dptr xs = q.xs, xd = q.xd, x = q.x;
+    cdptr Si = q.Sinv + mid * NS2;
+    dptr ft = q.tmp + TmpMap<NS>::SIDE0;  // factor-time scratch, free during the iterations
 #if DEKF_DEVICE_BUILD
     const int i = lane < NS ? lane : NS - 1;
     double f = xs[NS * mid + i];
     if (mid < K - 1) {
-        const double* W = q.Wk + mid * NS2 + NS * i;
-        const double* fh = xs + NS * (mid + 1);
+        cdptr W = q.Wk + mid * NS2 + NS * i;
+        cdptr fh = xs + NS * (mid + 1);
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
         for (int t = 0; t + 2 < NS; t += 3) { a0 += W[t] * fh[t]; a1 += W[t + 1] * fh[t + 1]; a2 += W[t + 2] * fh[t + 2]; }
@@ -766,8 +768,8 @@ DEKF_FN void sweep_mid_block_generic(Q& q, int lane, double alpha) {
     for (int i = 0; i < NS; ++i) {
         double f = xs[NS * mid + i];
         if (mid < K - 1) {
-            const double* W = q.Wk + mid * NS2 + NS * i;
-            const double* fh = xs + NS * (mid + 1);
+            cdptr W = q.Wk + mid * NS2 + NS * i;
+            cdptr fh = xs + NS * (mid + 1);
             double a0 = 0.0, a1 = 0.0, a2 = 0.0;
             for (int t = 0; t + 2 < NS; t += 3) { a0 += W[t] * fh[t]; a1 += W[t + 1] * fh[t + 1]; a2 += W[t + 2] * fh[t + 2]; }
             f -= a0 + (a1 + a2);
@@ -810,8 +812,8 @@ DEKF_FN void phase_sweeps_generic(Q& q, double alpha) {
         if (e >= K * NS) return;
         const int k = e / NS, i = e - NS * k;
         if (k == mid) return;
-        const double* Si = q.Sinv + k * NS2 + NS * i;
-        const double* f = q.xs + NS * k;
+        cdptr Si = q.Sinv + k * NS2 + NS * i;
+        cdptr f = q.xs + NS * k;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
         for (int t = 0; t + 2 < NS; t += 3) { a0 += Si[t] * f[t]; a1 += Si[t + 1] * f[t + 1]; a2 += Si[t + 2] * f[t + 2]; }
@@ -886,8 +888,8 @@ DEKF_FN void phase_sweeps(Q& q, double alpha) {
         if (tile == 0) { sweep_mid_block(q, lane, alpha); return; }
         const int blk = lane / 9, i = lane - 9 * blk, k = (tile - 1) * 7 + blk;
         if (blk >= 7 || k >= K || k == mid) return;
-        const double* Si = q.Sinv + k * 81 + 9 * i;
-        const double* f = q.xs + 9 * k;
+        cdptr Si = q.Sinv + k * 81 + 9 * i;
+        cdptr f = q.xs + 9 * k;
         double sv[9], fv[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) { sv[t] = Si[t]; fv[t] = f[t]; }
@@ -945,8 +947,8 @@ DEKF_FN void row_block_load(const Q& q, int r0, int sv0, bool has_hi, RowPre<NR>
     }
 }
 template <int NR, bool EQ, class Q, class SM>
-DEKF_FN void row_block_compute(Q& q, int r0, int sv0, const double* ar, const SM& S, const RowPre<NR>& p, double alpha, double sigma,
-                               bool has_hi = true, double* wout = nullptr) {
+DEKF_FN void row_block_compute(Q& q, int r0, int sv0, cdptr ar, const SM& S, const RowPre<NR>& p, double alpha, double sigma,
+                               bool has_hi = true, dptr wout = nullptr) {
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
     double c2[NR], hi[NR], v[NR], sl[NR], xn[NR], zn[NR], yn[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll
@@ -992,15 +994,15 @@ DEKF_FN void row_block_compute(Q& q, int r0, int sv0, const double* ar, const SM
     }
 }
 template <int NR, bool EQ, class Q, class SM>
-DEKF_FN void row_block_update(Q& q, int r0, int sv0, const double* ar, const SM& S, double alpha, double sigma, bool has_hi = true,
-                              double* wout = nullptr) {
+DEKF_FN void row_block_update(Q& q, int r0, int sv0, cdptr ar, const SM& S, double alpha, double sigma, bool has_hi = true,
+                              dptr wout = nullptr) {
     RowPre<NR> p;
     row_block_load<NR, EQ>(q, r0, sv0, has_hi, p);
     row_block_compute<NR, EQ>(q, r0, sv0, ar, S, p, alpha, sigma, has_hi, wout);
 }
 // the same block from (x, z, y) alone: after a (re)factorisation, and for the cold start
 template <int NR, bool EQ, class Q, class SM>
-DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma, double* wout = nullptr) {
+DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma, dptr wout = nullptr) {
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
     double e[NR], cf[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll
@@ -1027,11 +1029,11 @@ DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma,
 template <int N>
 struct SymMat {  // symmetric N x N, packed upper triangle, held in registers
     double p[N * (N + 1) / 2];
-    DEKF_FN explicit SymMat(const double* s) {
+    DEKF_FN explicit SymMat(cdptr s) {
 #pragma unroll
         for (int i = 0; i < N * (N + 1) / 2; ++i) p[i] = s[i];
     }
-    DEKF_FN void apply(const double* in, double* out) const {
+    DEKF_FN void apply(cdptr in, dptr out) const {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             double a = 0.0;
@@ -1045,13 +1047,15 @@ struct SymMat {  // symmetric N x N, packed upper triangle, held in registers
 // path, so that both kinds share a tile: the diagonal goes into the packed slots 0, 3, 5, the rest is zero
 struct VoOrBiasMat {
     double p[6];
-    DEKF_FN VoOrBiasMat(const double* sc6, const double* diag3, bool vo, int st = 1) {  // st: element stride of both arrays
-        const double* sp = vo ? sc6 : diag3;
-        const double s0 = sp[0], s1 = sp[st], s2 = sp[2 * st], s3 = sp[3 * st], s4 = sp[4 * st], s5 = sp[5 * st];  // in bounds for both
+    DEKF_FN VoOrBiasMat(cdptr sc6, cdptr diag3, bool vo, int st = 1) {  // st: element stride of both arrays
+        cdptr sp = vo ? sc6 : diag3;
+        // (a diagonal has three entries: for it the loads of s3..s5 repeat s0..s2 instead of running past the array)
+        const int o3 = vo ? 3 * st : 0, o4 = vo ? 4 * st : st, o5 = vo ? 5 * st : 2 * st;
+        const double s0 = sp[0], s1 = sp[st], s2 = sp[2 * st], s3 = sp[o3], s4 = sp[o4], s5 = sp[o5];
         p[0] = s0; p[1] = vo ? s1 : 0.0; p[2] = vo ? s2 : 0.0;
         p[3] = vo ? s3 : s1; p[4] = vo ? s4 : 0.0; p[5] = vo ? s5 : s2;
     }
-    DEKF_FN void apply(const double* in, double* out) const {
+    DEKF_FN void apply(cdptr in, dptr out) const {
         out[0] = p[0] * in[0] + p[1] * in[1] + p[2] * in[2];
         out[1] = p[1] * in[0] + p[3] * in[1] + p[4] * in[2];
         out[2] = p[2] * in[0] + p[4] * in[1] + p[5] * in[2];
@@ -1067,7 +1071,7 @@ struct VoOrBiasMat {
 struct DynPairMat {
     double a[6];  // own rows x own columns (symmetric, packed)
     double b[9];  // own rows x partner columns
-    DEKF_FN DynPairMat(const double* s, bool vel, int st = 1) {  // st: element stride of s
+    DEKF_FN DynPairMat(cdptr s, bool vel, int st = 1) {  // st: element stride of s
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -1077,7 +1081,7 @@ struct DynPairMat {
 #pragma unroll
             for (int j = 0; j < 3; ++j) b[3 * i + j] = s[(vel ? symidx(j, 3 + i, 6) : symidx(i, 3 + j, 6)) * st];
     }
-    DEKF_FN void apply(const double* in, double* out) const {
+    DEKF_FN void apply(cdptr in, dptr out) const {
         double pin[3];
 #pragma unroll
         for (int j = 0; j < 3; ++j) pin[j] = pair_swap(in[j]);
@@ -1107,7 +1111,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
     const int ntp = (K1 + 63) >> 6;      // host build: one (sequential) lane per 6-block
 #endif
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-    const double *xd = q.xd, *E = q.E;
+    cdptr xd = q.xd, E = q.E;
     // Tile order [Meas | Dyn | VO + bias | foot-position Dyn].  VO blocks and Dyn bias blocks share tiles and ONE code
     // path (3 rows, a 3x3 symmetric slack-block inverse that is diagonal for the bias rows, the generic projection):
     // as separate kinds they were two tile bodies run one after the other by some wavefront.
@@ -1136,13 +1140,13 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             if (k >= K1) return;
             const int r0 = q.ix.rd(k, vel ? 3 : 0), sv0 = q.ix.w(k, vel ? 3 : 0);
             const DynPairMat S(q.Sw + k * SWS, vel);
-            const double* R = q.R + 9 * k;
+            cdptr R = q.R + 9 * k;
             double Rk[9], wo[3];
 #pragma unroll
             for (int t = 0; t < 9; ++t) Rk[t] = R[t];
             if (RESTART) row_block_restart<3, true>(q, r0, sv0, S, sigma, wo);
             else {
-                const double* xk = xd + NS * k;
+                cdptr xk = xd + NS * k;
                 const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
                 const int o = vel ? 3 : 0;
                 double ar[3];
@@ -1171,10 +1175,10 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
         if (td < ntp) {  // Dyn position + velocity rows: 6x6 slack block on one lane (host build)
             const int k = td * 64 + lane;
             if (k >= K1) return;
-            const double* xk = xd + NS * k;
+            cdptr xk = xd + NS * k;
             const int r0 = q.ix.rd(k, 0), sv0 = q.ix.w(k, 0);
             const SymMat<6> S(q.Sw + k * SWS);
-            const double* R = q.R + 9 * k;
+            cdptr R = q.R + 9 * k;
             double wo[6];
             if (RESTART) row_block_restart<6, true>(q, r0, sv0, S, sigma, wo);
             else {
@@ -1202,7 +1206,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             const int r0 = vo ? q.ix.rv(k, 0) : q.ix.rd(k, 6), sv0 = vo ? q.ix.c(k, 0) : q.ix.w(k, 6);
             const VoOrBiasMat S(q.Sc + k * 6, q.Sw + k * SWS + 21, vo);
             if (RESTART) { row_block_restart<3, false>(q, r0, sv0, S, sigma); return; }
-            const double* xk = xd + NS * k;
+            cdptr xk = xd + NS * k;
             double ar[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[o + a] - xk[NS + o + a]);
@@ -1216,7 +1220,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
             const int r0 = q.ix.rd(k, 9 + 3 * leg), sv0 = q.ix.w(k, 9 + 3 * leg);
             const SymMat<3> S(q.Sf + e * 6);
             if (RESTART) { row_block_restart<3, true>(q, r0, sv0, S, sigma); return; }
-            const double* xk = xd + NS * k + 9 + 3 * leg;
+            cdptr xk = xd + NS * k + 9 + 3 * leg;
             double ar[3];
 #pragma unroll
             for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[a] - xk[NS + a]);
@@ -1238,7 +1242,7 @@ struct RowTile {
     bool vel, vo;  // kind 1: velocity half; kind 2: VO block (else bias)
     RowPre<3> pre;
     double a[6], b[9];  // slack-block inverse: symmetric own part; coupling to the partner lane (kind 1)
-    DEKF_FN void apply(const double* in, double* out) const {
+    DEKF_FN void apply(cdptr in, dptr out) const {
         double pin[3] = {0.0, 0.0, 0.0};
         if (kind == 1) {
 #pragma unroll
@@ -1268,7 +1272,7 @@ DEKF_FN void row_tile_load(const Q& q, int tile, int lane, RowTile& t) {
         if (e >= nmeas) return;
         const int k = e / L, leg = e - k * L;
         t.kind = 0; t.k = k; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg;
-        const double* sp = q.Sv + e * 6;
+        cdptr sp = q.Sv + e * 6;
 #pragma unroll
         for (int i = 0; i < 6; ++i) t.a[i] = sp[i];
         row_block_load<3, true>(q, t.r0, t.sv0, true, t.pre);
@@ -1299,15 +1303,15 @@ template <class Q>
 DEKF_FN void row_tile_finish(Q& q, const RowTile& t, double alpha, double sigma) {
     if (t.kind < 0) return;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-    const double* xk = q.xd + 9 * t.k;
-    const double* E = q.E;
+    cdptr xk = q.xd + 9 * t.k;
+    cdptr E = q.E;
     double ar[3];
     if (t.kind == 0) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) ar[a] = E[t.r0 + a] * xk[3 + a];
         row_block_compute<3, true>(q, t.r0, t.sv0, ar, t, t.pre, alpha, sigma);
     } else if (t.kind == 1) {
-        const double* R = q.R + 9 * t.k;
+        cdptr R = q.R + 9 * t.k;
         double Rk[9], wo[3];
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rk[i] = R[i];
@@ -1365,7 +1369,7 @@ struct RowRegs {
     double e[3], c2[3], cf[3], lo[3];
     double t[3], xs[3], z[3], y[3];
     double a[6], b[9];  // slack-block inverse: own part, coupling to the partner lane (kind 1); kind 2: b[0..2] = upper bounds
-    DEKF_FN void apply(const double* in, double* out) const {
+    DEKF_FN void apply(cdptr in, dptr out) const {
         double pin[3] = {0.0, 0.0, 0.0};
         if (kind == 1) {
 #pragma unroll
@@ -1397,7 +1401,7 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     t.kind = -1; t.k = 0; t.r0 = 0; t.sv0 = 0; t.vel = false; t.meas = false; t.xo = 0;
     bool vo = false;
-    const double* sp = q.Sv;  // (the slack-block inverses are stored entry-major in the slab: solve_factor 3a)
+    cdptr sp = q.Sv;  // (the slack-block inverses are stored entry-major in the slab: solve_factor 3a)
     if (w == 1) {
         if (lane >= nmeas) return;
         const int k = lane / L, leg = lane - k * L;
@@ -1470,7 +1474,7 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
     }
     if (t.kind == 1) {
         const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-        const double* R = q.R + 9 * t.k;
+        cdptr R = q.R + 9 * t.k;
         double u[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -1500,10 +1504,10 @@ template <class Q>
 DEKF_FN void row_regs_iter(Q& q, RowRegs& t, double alpha, double sigma) {
     if (t.kind < 0) return;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-    const double* xk = q.xd + 9 * t.k;
+    cdptr xk = q.xd + 9 * t.k;
     double ar[3], Rk[9];
     if (t.kind == 1) {
-        const double* R = q.R + 9 * t.k;
+        cdptr R = q.R + 9 * t.k;
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rk[i] = R[i];
         const bool vel = t.vel;
@@ -1568,8 +1572,8 @@ template <class Q>
 DEKF_FN void xcols_tile_r3(Q& q, int kind, int lane, double sigma) {
     const int K = q.K;
     if (lane >= 3 * K) return;
-    const double* qsl = q.tmp + TmpMap<9>::QSL;
-    const double* at = q.at;
+    cdptr qsl = q.tmp + TmpMap<9>::QSL;
+    cdptr at = q.at;
     auto w = [&](int r) { return at[r]; };
     const int k = lane / 3, a = lane - 3 * k, j = 3 * kind + a, i = 9 * k + j;
     const double xv = q.xb[i], dv = q.D[k * (21 + 3 * Q::LEGS) + j], qv = qsl[j];
@@ -1729,12 +1733,12 @@ DEKF_FN void phase_sweeps_rows(Q& q, double alpha, double sigma) {
 // arrive while the LDS part is being computed).  Replaces two wfor sweeps over rows / variables with
 // per-item kind decoding (50 k cycles per check on Go1, 3 checks per solve).
 template <class Q>
-DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
+DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
     constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, SV = 2 * NS + 3 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt, cc = q.cc;
-    double *x = q.x, *z = q.z, *y = q.y, *xd = q.xd;
-    const double *D = q.D, *E = q.E;
+    dptr x = q.x, z = q.z, y = q.y, xd = q.xd;
+    cdptr D = q.D, E = q.E;
     // Where the iterates are.  Three-workgroup kernels (R3): x blocks compact in LDS (xb); the slack x and y by ROW in sx / sy, z of
     // the VO rows in sz (what the last chunk of iterations left, admm_chunk_r3); z of an equality row is its scaled bound (the
     // projection returns it from the first iteration on).  Everywhere else: the full vectors x, z, y.
@@ -1754,7 +1758,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
 #pragma unroll
     for (int r = 0; r < 14; ++r) acc[r] = 0.0;
     // rows r0.. and slack variables sv0.. of one 3-block: ar = E .* (A_x D x), ps = unscaled P_s (D_s x_s); vo: a VO block
-    auto block = [&](int r0, int sv0, const double* ar, const double* ps, bool vo = false) {
+    auto block = [&](int r0, int sv0, cdptr ar, cdptr ps, bool vo = false) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int r = r0 + j, sv = sv0 + j;
@@ -1779,7 +1783,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
         }
     };
     // a 3-block whose P block is a packed symmetric 3x3 in the window record
-    auto block_sym3 = [&](int r0, int sv0, const double* ar, const double* q6, bool vo = false) {
+    auto block_sym3 = [&](int r0, int sv0, cdptr ar, cdptr q6, bool vo = false) {
         double p6[6], dx[3], ps[3];
 #pragma unroll
         for (int t = 0; t < 6; ++t) p6[t] = q6[t];
@@ -1792,7 +1796,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
     };
     const int ntm = (nmeas + 63) >> 6, ntp = (2 * K1 + 63) >> 6, ntd = (K1 + 63) >> 6, ntx = (3 * K + 63) >> 6;
     const int ntf = FT ? (K1 * L + 63) >> 6 : 0, ntxf = FT ? (NM * K + 63) >> 6 : 0;
-    const double* qsl = q.tmp + TmpMap<NS>::QSL;
+    cdptr qsl = q.tmp + TmpMap<NS>::QSL;
     auto wy = [&](int r) { return E[r] * YR(r); };
     wtiles(ntm + ntp + 2 * ntd + 3 * ntx + ntf + ntxf, [&](int tile, int lane) {
         if (tile < ntm) {  // Meas leg blocks
@@ -1814,14 +1818,14 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             const bool vel = pl & 1;
             const int o = vel ? 3 : 0;
             const int r0 = q.ix.rd(k, o), sv0 = q.ix.w(k, o), w0 = q.ix.w(k, 0);
-            const double* q21 = q.rec(k) + Rec::QD;
+            cdptr q21 = q.rec(k) + Rec::QD;
             double p21[21], dx[6], ps[3], ar[3];
 #pragma unroll
             for (int t = 0; t < 21; ++t) p21[t] = q21[t];
 #pragma unroll
             for (int t = 0; t < 6; ++t) dx[t] = D[w0 + t] * XS(w0 + t, q.ix.rd(k, t));
-            const double* xk = xd + NS * k;
-            const double* R = q.R + 9 * k;
+            cdptr xk = xd + NS * k;
+            cdptr R = q.R + 9 * k;
             const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -1843,7 +1847,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
             const bool vo = td < ntd;
             const int k = (td - (vo ? 0 : ntd)) * 64 + lane;
             if (k >= K1) return;
-            const double* xk = xd + NS * k;
+            cdptr xk = xd + NS * k;
             double ar[3], ps[3];
             if (!vo) {
                 const int r0 = q.ix.rd(k, 6), sv0 = q.ix.w(k, 6);
@@ -1895,7 +1899,7 @@ DEKF_FN void residual_norms(Q& q, double* ra, double* va) {
                 if (e >= K1 * L) return;
                 const int k = e / L, leg = e - k * L;
                 const int r0 = q.ix.rd(k, 9 + 3 * leg), sv0 = q.ix.w(k, 9 + 3 * leg);
-                const double* xk = xd + NS * k + 9 + 3 * leg;
+                cdptr xk = xd + NS * k + 9 + 3 * leg;
                 double ar[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) ar[a] = E[r0 + a] * (xk[a] - xk[NS + a]);

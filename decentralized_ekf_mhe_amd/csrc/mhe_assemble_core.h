@@ -26,7 +26,8 @@ struct AsmScratch {
 
 // A_dyn,k[r][j] for R (row-major) and dt (DecentralEst.cpp:395-398)
 // (rows / columns >= 9 are the foot-position states of leg_odom_type 1: identity, :395-398)
-DEKF_FN double adyn_entry(const double* R, double dt, int r, int j) {
+template <class P>  // P: const double* or the checked pointer of the -DDEKF_BOUNDS build
+DEKF_FN double adyn_entry(P R, double dt, int r, int j) {
     if (r == j) return 1.0;
     if (r < 3) {
         if (j == r + 3) return dt;

@@ -178,29 +178,29 @@ struct SolveCtx {
     int b, K, kstart, n, m;
     IdxT<L, FT> ix;
     // LDS always
-    double *x, *z, *y, *xt, *zt, *at, *xs, *xd, *tmp;
-    double* xb;       // R3: the x blocks of x, [K][NS], the only part of x an iteration shares between lanes
-    double *sx, *sy, *sz;  // R3: where the row state rests between chunks, by row: slack x (= at), y, z of the VO rows (from the first VO row)
+    dptr x, z, y, xt, zt, at, xs, xd, tmp;
+    dptr xb;       // R3: the x blocks of x, [K][NS], the only part of x an iteration shares between lanes
+    dptr sx, sy, sz;  // R3: where the row state rests between chunks, by row: slack x (= at), y, z of the VO rows (from the first VO row)
     bool cold;        // R3: no chunk has run yet (x = z = y = 0)
-    double* cf;  // per row rho E D (aliases xt, which only the factorisation uses otherwise)
-    double* gb;  // per step R' (dt^2/2 w_p + dt w_v): the Dyn rows' contribution to the bias columns (tail of xt)
+    dptr cf;  // per row rho E D (aliases xt, which only the factorisation uses otherwise)
+    dptr gb;  // per step R' (dt^2/2 w_p + dt w_v): the Dyn rows' contribution to the bias columns (tail of xt)
     // LDS or HBM scratch
-    double *D, *E, *lo, *hi, *Sv, *Sw, *Sc, *Sinv, *Wk, *R;
-    double* Sf;  // FOOT: inverses of the slack blocks of the foot-position Dyn rows, [K][L][6]
+    dptr D, E, lo, hi, Sv, Sw, Sc, Sinv, Wk, R;
+    dptr Sf;  // FOOT: inverses of the slack blocks of the foot-position Dyn rows, [K][L][6]
     // factor-time temporaries
-    double *Wm, *Wd, *Wc, *PA;
-    double* Wf;  // FOOT: effective row weights of the foot-position Dyn rows
-    const double *Mp, *np;
-    const double* vo;  // [wcap][4] VO flag + bound per ring slot, from the solve's input snapshot
+    dptr Wm, Wd, Wc, PA;
+    dptr Wf;  // FOOT: effective row weights of the foot-position Dyn rows
+    cdptr Mp, np;
+    cdptr vo;  // [wcap][4] VO flag + bound per ring slot, from the solve's input snapshot
     double cc;   // cost scaling c
     double rho;  // current scalar rho
-    double* Pst;  // unscaled P blocks staged by solve_scale (aliases Sinv | Wk until the first factorisation)
+    dptr Pst;  // unscaled P blocks staged by solve_scale (aliases Sinv | Wk until the first factorisation)
     bool staged;  // Pst valid
-    double* prof;         // diagnostic build only
+    dptr prof;         // diagnostic build only
     long long prof_last;  // diagnostic build only
 
-    DEKF_FN const double* rec(int k) const {
-        return s.rec + ((size_t)b * c.wcap + ((kstart + k) % c.wcap)) * c.rec;
+    DEKF_FN cdptr rec(int k) const {
+        return DEKF_CSPAN(s.rec + ((size_t)b * c.wcap + ((kstart + k) % c.wcap)) * c.rec, c.rec);
     }
     DEKF_FN double adyn(int k, int r, int j) const { return adyn_entry(R + 9 * k, c.dt, r, j); }
     // per-row rho from the scaled bounds (OSQP set_rho_vec / osqp_update_rho)
@@ -215,11 +215,11 @@ struct SolveCtx {
     DEKF_FN void bounds(int k, int kind, int o, double& lb, double& ub) const { bounds_at((kstart + k) % c.wcap, kind, o, lb, ub); }
     // the same for a ring slot computed once (the modulo by a run-time ring size is a ~40-instruction software division)
     DEKF_FN void bounds_at(int slot, int kind, int o, double& lb, double& ub) const {
-        const double* r = s.rec + ((size_t)b * c.wcap + slot) * c.rec;
+        cdptr r = DEKF_CSPAN(s.rec + ((size_t)b * c.wcap + slot) * c.rec, c.rec);
         if (kind == 0) lb = ub = r[Rec::BM + o];
         else if (kind == 1) lb = ub = (o < 3 ? -0.5 * c.dt * c.dt * r[Rec::AS + o] : (o < 6 ? -c.dt * r[Rec::AS + o - 3] : 0.0));
         else {  // VO flag and bound come from the step's snapshot, not from the record (update(T + 1) may be rewriting them)
-            const double* v = vo + 4 * slot;
+            cdptr v = vo + 4 * slot;
             if (v[0] != 0.0) lb = ub = v[1 + o];
             else { lb = -OSQP_INFTY; ub = OSQP_INFTY; }
         }
@@ -252,11 +252,11 @@ template <class Q>
 DEKF_FN void stage_p(Q& q) {
     constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, PS = 6 * L + 27 + 6 * L * FT, MP = NS * (NS + 1) / 2;
     const int K = q.K;
-    double* Pst = q.Pst;
+    dptr Pst = q.Pst;
     wfor(K * PS + MP, [&](int e) {
         if (e < K * PS) {
             int k = e / PS, o = e - k * PS;
-            const double* r = q.rec(k);
+            cdptr r = q.rec(k);
             // [Qm 6L | Qd 21 | Qc 6 | Qf 6L (foot states)]: the last block is contiguous with Qm in the record
             Pst[e] = o < 6 * L ? r[Rec::qm(NM) + o]
                                : (o < 6 * L + 21 ? r[Rec::QD + o - 6 * L] : (o < 6 * L + 27 ? r[Rec::QC + o - 6 * L - 21] : r[Rec::qf(NM) + o - 6 * L - 27]));
@@ -274,13 +274,13 @@ DEKF_FN void solve_scale(Q& q) {
     constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, SV = 2 * NS + 3 + NM, PS = 6 * L + 27 + 6 * L * FT;
     const int n = q.n, m = q.m, K = q.K, K1 = q.K - 1, nmeas = K * L;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
-    double *D = q.D, *E = q.E, *Pst = q.Pst, *pc = q.x, *Dn = q.xt, *En = q.zt;  // (R3: the caller points all of these at LDS)
-    const double* g = q.np;
+    dptr D = q.D, E = q.E, Pst = q.Pst, pc = q.x, Dn = q.xt, En = q.zt;  // (R3: the caller points all of these at LDS)
+    cdptr g = q.np;
     const auto& ix = q.ix;
     stage_p(q);
     wfor(n + m, [&](int e) { if (e < n) { D[e] = 1.0; Dn[e] = 1.0; } else { E[e - n] = 1.0; En[e - n] = 1.0; } });
     q.cc = 1.0;
-    const double* Mst = Pst + K * PS;
+    cdptr Mst = Pst + K * PS;
     // Lane ownership is the row phase's: a lane owns one 3-row block and its 3 slack variables (Meas leg
     // block, Dyn position or velocity rows as a lane pair, Dyn bias, VO, [foot-position Dyn block]), or one x
     // entry (tiles by column kind).  One Ruiz pass is two tile phases:
@@ -352,8 +352,8 @@ DEKF_FN void solve_scale(Q& q) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) { en[a] = En[r0 + a]; dn[a] = Dn[sv0 + a]; }
         if (kind == 1) {
-            const double* q21 = Pst + k * PS + 6 * L;
-            const double* d = Dn + ix.w(k, 0);
+            cdptr q21 = Pst + k * PS + 6 * L;
+            cdptr d = Dn + ix.w(k, 0);
             double d6[6], p[3][6];
 #pragma unroll
             for (int t = 0; t < 6; ++t) d6[t] = d[t];
@@ -376,7 +376,7 @@ DEKF_FN void solve_scale(Q& q) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) v[a] = dn[a] * q.c.Q_bias_dt2[a] * dn[a];
         } else {
-            const double* q6 = Pst + k * PS + (kind == 0 ? 6 * sub : (kind == 3 ? 6 * L + 21 : 6 * L + 27 + 6 * sub));
+            cdptr q6 = Pst + k * PS + (kind == 0 ? 6 * sub : (kind == 3 ? 6 * L + 21 : 6 * L + 27 + 6 * sub));
             double p6[6];
 #pragma unroll
             for (int t = 0; t < 6; ++t) p6[t] = q6[t];
@@ -414,7 +414,7 @@ DEKF_FN void solve_scale(Q& q) {
                 if (hn) an = dmax(an, dmax(n0, dt * n1));
                 if (hp) an = dmax(an, p0);
             } else if (kind == 6) {
-                const double* R = q.R + 9 * kn;
+                cdptr R = q.R + 9 * kn;
                 double bn = E[ix.rd(kn, 6 + a)];
                 const double p0 = E[ix.rd(kp, 6 + a)];
 #pragma unroll
@@ -435,7 +435,7 @@ DEKF_FN void solve_scale(Q& q) {
         }
         int r0, sv0;
         row_base(kind, k, sub, r0, sv0);
-        const double* d = D + k * SV;
+        cdptr d = D + k * SV;
         double e3[3], d3[3], p3[3], v[3];  // own rows / slacks; v = inf-norm of the row of A D (before E)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { e3[a] = E[r0 + a]; d3[a] = D[sv0 + a]; p3[a] = pc[sv0 + a]; }
@@ -443,7 +443,7 @@ DEKF_FN void solve_scale(Q& q) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) v[a] = FT ? dmax(d3[a], dmax(d[a], d[9 + 3 * sub + a])) : dmax(d3[a], d[3 + a]);
         } else if (kind == 1) {
-            const double* R = q.R + 9 * k;
+            cdptr R = q.R + 9 * k;
             double dk[9], dnx[6], Ra[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) { dk[t] = d[t]; Ra[t] = fabs(R[t]); }
@@ -480,7 +480,7 @@ DEKF_FN void solve_scale(Q& q) {
         for (int a = 0; a < 3; ++a) { En[r0 + a] = eo[a]; Dn[sv0 + a] = dout[a]; }
     };
 #if DEKF_DEVICE_BUILD
-    auto fused = [&](int tile, int lane, double cc, const double* Dr, const double* Er, double* Dw, double* Ew) -> double {
+    auto fused = [&](int tile, int lane, double cc, cdptr Dr, cdptr Er, dptr Dw, dptr Ew) -> double {
         int kind, k, sub;
         if (!decode(tile, lane, kind, k, sub)) return 0.0;
         if ((kind >= 4 && kind <= 6) || kind == 8) {  // x column: inf-norm over the rows that touch it
@@ -506,7 +506,7 @@ DEKF_FN void solve_scale(Q& q) {
                 if (hn) an = dmax(an, dmax(n0, dt * n1));
                 if (hp) an = dmax(an, p0);
             } else if (kind == 6) {
-                const double* R = q.R + 9 * kn;
+                cdptr R = q.R + 9 * kn;
                 double bn = Er[ix.rd(kn, 6 + a)];
                 const double p0 = Er[ix.rd(kp, 6 + a)];
 #pragma unroll
@@ -527,7 +527,7 @@ DEKF_FN void solve_scale(Q& q) {
         }
         int r0, sv0;
         row_base(kind, k, sub, r0, sv0);
-        const double* d = Dr + k * SV;
+        cdptr d = Dr + k * SV;
         double e3[3], d3[3], p3[3], v[3];  // own rows / slacks; v = inf-norm of the row of A D (before E)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { e3[a] = Er[r0 + a]; d3[a] = Dr[sv0 + a]; p3[a] = pc[sv0 + a]; }
@@ -535,7 +535,7 @@ DEKF_FN void solve_scale(Q& q) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) v[a] = FT ? dmax(d3[a], dmax(d[a], d[9 + 3 * sub + a])) : dmax(d3[a], d[3 + a]);
         } else if (kind == 1) {
-            const double* R = q.R + 9 * k;
+            cdptr R = q.R + 9 * k;
             double dk[9], dnx[6], Ra[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) { dk[t] = d[t]; Ra[t] = fabs(R[t]); }
@@ -572,7 +572,7 @@ DEKF_FN void solve_scale(Q& q) {
         //      a Dyn lane pair comes over by DPP); every load above and below is issued before the first store
         double vv3[3];
         if (kind == 1) {
-            const double* q21 = Pst + k * PS + 6 * L;
+            cdptr q21 = Pst + k * PS + 6 * L;
             double d6[6], pq[3][6];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
@@ -599,7 +599,7 @@ DEKF_FN void solve_scale(Q& q) {
 #pragma unroll
             for (int a = 0; a < 3; ++a) vv3[a] = dout[a] * q.c.Q_bias_dt2[a] * dout[a];
         } else {
-            const double* q6 = Pst + k * PS + (kind == 0 ? 6 * sub : (kind == 3 ? 6 * L + 21 : 6 * L + 27 + 6 * sub));
+            cdptr q6 = Pst + k * PS + (kind == 0 ? 6 * sub : (kind == 3 ? 6 * L + 21 : 6 * L + 27 + 6 * sub));
             double p6[6];
 #pragma unroll
             for (int t = 0; t < 6; ++t) p6[t] = q6[t];
@@ -612,7 +612,7 @@ DEKF_FN void solve_scale(Q& q) {
         return vv3[0] + vv3[1] + vv3[2];
     };
     // the arrival-cost block (x_0 columns): needs the new scaling of all of x_0, i.e. the barrier behind `fused`
-    auto fused_x0 = [&](int tile, int lane, const double* Dw) -> double {
+    auto fused_x0 = [&](int tile, int lane, cdptr Dw) -> double {
         int kind, k, sub;
         if (tile < ntm + ntp + 2 * ntd || tile >= ntm + ntp + 2 * ntd + 3 * ntx) return 0.0;
         if (!decode(tile, lane, kind, k, sub) || k != 0) return 0.0;
@@ -639,7 +639,7 @@ DEKF_FN void solve_scale(Q& q) {
         // pairs of scaling vectors instead of a copy), a barrier, the nine x_0 lanes' arrival-cost norms, the sum.  Same
         // arithmetic, same lanes, same order of the sum as the two-phase form below (which the lane-sequential build and the
         // foot-state shapes keep): bit-identical D, E, c.
-        double *Dr = D, *Er = E, *Dw = Dn, *Ew = En;
+        dptr Dr = D, Er = E, Dw = Dn, Ew = En;
         for (int it = 0; it < q.c.scaling; ++it) {
             const double cc = q.cc;
             double psum = 0.0;
@@ -671,12 +671,12 @@ DEKF_FN void solve_scale(Q& q) {
             for (int j = 0; j < NS; ++j) qn = dmax(qn, fabs(cc * Dw[j] * gq[j]));
             double ct = 1.0 / limit_scaling(dmax(psum / (double)n, limit_scaling(qn)));
             q.cc = cc * ct;
-            double* t0 = Dr; Dr = Dw; Dw = t0;
-            double* t1 = Er; Er = Ew; Ew = t1;
+            dptr t0 = Dr; Dr = Dw; Dw = t0;
+            dptr t1 = Er; Er = Ew; Ew = t1;
         }
         if (Dr != D) {  // odd number of passes: the result sits in the other pair
             DEKF_SYNC();
-            const double *Ds = Dr, *Es = Er;
+            cdptr Ds = Dr, Es = Er;
             wfor(n + m, [&](int e) { if (e < n) D[e] = Ds[e]; else E[e - n] = Es[e - n]; });
         }
         DEKF_SYNC();
@@ -711,7 +711,7 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
     constexpr int NS = Q::NS, NS2 = Q::NS2;
     using TM = TmpMap<NS>;
     const int K = q.K, mid = mid_block(K);
-    double* fail = q.tmp + TM::FAIL;
+    dptr fail = q.tmp + TM::FAIL;
     if (DEKF_LANE() == 0) *fail = 0.0;
     DEKF_SYNC();
     // Operand staging in LDS.  The factor lives in the workgroup's HBM slab (S^-1 and W alone are 141 KB for Go1), and a
@@ -721,41 +721,41 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
     // so each side keeps two NS x NS panels there: `wa` = W of the block just finished, `ca` = its C — exactly what the next
     // block of that side subtracts.  Per block the slab is then touched four times, coalesced: T_kk in, C in, S^-1 out, W out.
     // (only when the factor is NOT in LDS already, and only if the dead vectors are long enough: short windows are not)
-    double* stage[2] = {q.xt, q.xt + 2 * NS2 + 8};
+    dptr stage[2] = {q.xt, q.xt + 2 * NS2 + 8};
     const bool staged = !Q::FACTOR_LDS && 2 * (2 * NS2 + 8) <= (int)(q.xs - q.xt);
 #if DEKF_DEVICE_BUILD
     const int lane = DEKF_LANE() & 63, l0 = lane, st = WAVE;
 #else
     const int l0 = 0, st = 1;
 #endif
-    auto copy_panel = [&](double* dst, const double* src) {
+    auto copy_panel = [&](dptr dst, cdptr src) {
         for (int p = l0; p < NS2; p += st) dst[p] = src[p];
     };
     // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]
     // have_prev: wa / ca of this side already hold the predecessor's W and C
-    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, double* ts, int side, bool have_prev) -> bool {
-        double* wa = stage[side];
-        double* ca = stage[side] + NS2;
+    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, dptr ts, int side, bool have_prev) -> bool {
+        dptr wa = stage[side];
+        dptr ca = stage[side] + NS2;
         if (staged && !have_prev) {  // (not taken today: every caller arrives with its predecessor's panels staged)
             if (use_top) { copy_panel(stage[0], q.Wk + (k - 1) * NS2); copy_panel(stage[0] + NS2, q.PA + (k - 1) * NS2); }
             if (use_bot) { copy_panel(stage[1], q.Wk + k * NS2); copy_panel(stage[1] + NS2, q.PA + k * NS2); }
         }
-        const double* Wt = staged ? stage[0] : q.Wk + (use_top ? k - 1 : 0) * NS2;
-        const double* Ct = staged ? stage[0] + NS2 : q.PA + (use_top ? k - 1 : 0) * NS2;
-        const double* Wb = staged ? stage[1] : q.Wk + k * NS2;
-        const double* Cb = staged ? stage[1] + NS2 : q.PA + k * NS2;
+        cdptr Wt = staged ? stage[0] : q.Wk + (use_top ? k - 1 : 0) * NS2;
+        cdptr Ct = staged ? stage[0] + NS2 : q.PA + (use_top ? k - 1 : 0) * NS2;
+        cdptr Wb = staged ? stage[1] : q.Wk + k * NS2;
+        cdptr Cb = staged ? stage[1] + NS2 : q.PA + k * NS2;
         for (int p = l0; p < NS2; p += st) ts[p] = q.Sinv[k * NS2 + p];
         wave_sync();
-        auto schur = [&](const double* W, const double* C, bool top) {
+        auto schur = [&](cdptr W, cdptr C, bool top) {
             for (int p = l0; p < NS2; p += st) {
                 const int i = p / NS, j = p - NS * i;
-                const double* wr = W + NS * i;
+                cdptr wr = W + NS * i;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
                 if (top) {  // W_{k-1} C_{k-1}'
-                    const double* cr = C + NS * j;
+                    cdptr cr = C + NS * j;
                     for (int t = 0; t + 2 < NS; t += 3) { s0 += wr[t] * cr[t]; s1 += wr[t + 1] * cr[t + 1]; s2 += wr[t + 2] * cr[t + 2]; }
                 } else {    // What_k C_k
-                    const double* cc = C + j;
+                    cdptr cc = C + j;
                     for (int t = 0; t + 2 < NS; t += 3) { s0 += wr[t] * cc[NS * t]; s1 += wr[t + 1] * cc[NS * (t + 1)]; s2 += wr[t + 2] * cc[NS * (t + 2)]; }
                 }
                 ts[p] -= s0 + (s1 + s2);
@@ -788,12 +788,12 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
         copy_panel(q.Sinv + k * NS2, ts);
         if (wmode != 0) {
             const int kw = wmode == 1 ? k : k - 1;
-            const double* cs0 = staged ? ca : q.PA + kw * NS2;
+            cdptr cs0 = staged ? ca : q.PA + kw * NS2;
             for (int p = l0; p < NS2; p += st) {
                 const int i = p / NS, jj = p - NS * i;
-                const double* cr = wmode == 1 ? cs0 + NS * i : cs0 + i;  // row i of C, or column i (C')
+                cdptr cr = wmode == 1 ? cs0 + NS * i : cs0 + i;  // row i of C, or column i (C')
                 const int cs = wmode == 1 ? 1 : NS;
-                const double* tc = ts + jj;
+                cdptr tc = ts + jj;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
                 for (int t = 0; t + 2 < NS; t += 3) {
                     s0 += cr[t * cs] * tc[NS * t];
@@ -854,7 +854,7 @@ DEKF_FN bool solve_factor(Q& q) {
     // of one entry touched up to 64 different 32-byte sectors: 288 such stores per solve were most of the kernel's write traffic)
     constexpr bool ST = Q::R3;
     const int stv = ST ? K * L : 1, stw = ST ? K : 1;
-    auto block3 = [&](const double* q6, int r0, int sv0, double* Si_out, double* W_out, int sst) {
+    auto block3 = [&](cdptr q6, int r0, int sv0, dptr Si_out, dptr W_out, int sst) {
         double gv[3], rr[3], S6[6], Si[6];
         for (int a = 0; a < 3; ++a) {
             rr[a] = q.rho_at(r0 + a);
@@ -872,11 +872,11 @@ DEKF_FN bool solve_factor(Q& q) {
     };
     wfor(K * NB, [&](int e) {
         int k = e / NB, blk = e - k * NB;
-        const double* pk = q.Pst + k * PS;  // [Qm 6L | Qd 21 | Qc 6 | Qf 6L]
+        cdptr pk = q.Pst + k * PS;  // [Qm 6L | Qd 21 | Qc 6 | Qf 6L]
         if (blk < L) {
             block3(pk + 6 * blk, ix.rm(k, 3 * blk), ix.v(k, 3 * blk), q.Sv + (k * L + blk) * (ST ? 1 : 6), q.Wm + (k * L + blk) * 6, stv);
         } else if (k < K - 1 && blk == L) {
-            const double* q21 = pk + 6 * L;
+            cdptr q21 = pk + 6 * L;
             double S[36], gv[9], rr[9];
 #pragma unroll
             for (int a = 0; a < 9; ++a) {
@@ -891,8 +891,8 @@ DEKF_FN bool solve_factor(Q& q) {
                     S[6 * a + d] = cc * q.D[ix.w(k, a)] * symget(q21, a, d, 6) * q.D[ix.w(k, d)] +
                                    (a == d ? sigma + gv[a] * q.E[ix.rd(k, a)] * q.D[ix.w(k, a)] : 0.0);
             inv_spd_unrolled<6>(S);
-            double* sw = q.Sw + k * (ST ? 1 : SWS);
-            double* wd = q.Wd + k * 24;
+            dptr sw = q.Sw + k * (ST ? 1 : SWS);
+            dptr wd = q.Wd + k * 24;
 #pragma unroll
             for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -981,8 +981,8 @@ DEKF_FN bool solve_factor(Q& q) {
             // ---- this step's Dyn / VO rows
             {
                 double en[9], ev[3], dn[9], Rk[9], pa[9], at[9];
-                const double* wd = q.Wd + kn * 24;
-                const double* wc = q.Wc + kn * 6;
+                cdptr wd = q.Wd + kn * 24;
+                cdptr wc = q.Wc + kn * 6;
 #pragma unroll
                 for (int t = 0; t < 9; ++t) { en[t] = q.E[ix.rd(kn, t)]; dn[t] = q.D[ix.x(kn + 1 < K ? kn + 1 : kn, t)]; Rk[t] = q.R[9 * kn + t]; }
 #pragma unroll
@@ -1035,8 +1035,8 @@ DEKF_FN bool solve_factor(Q& q) {
             }
             // ---- the previous step's Dyn / VO rows carry -I on x_k
             {
-                const double* wd = q.Wd + kp * 24;
-                const double* wc = q.Wc + kp * 6;
+                cdptr wd = q.Wd + kp * 24;
+                cdptr wc = q.Wc + kp * 6;
                 const double ej = q.E[ix.rd(kp, j)];
 #pragma unroll
                 for (int i = 0; i < 9; ++i) {
@@ -1054,7 +1054,7 @@ DEKF_FN bool solve_factor(Q& q) {
                 if (kind == 0) {
 #pragma unroll
                     for (int leg = 0; leg < L; ++leg) {
-                        const double* wm = q.Wm + (k * L + leg) * 6;
+                        cdptr wm = q.Wm + (k * L + leg) * 6;
                         const double ea = q.E[ix.rm(k, 3 * leg + a)];
 #pragma unroll
                         for (int i = 0; i < 3; ++i) tc[i] += q.E[ix.rm(k, 3 * leg + i)] * dx[i] * symget(wm, i, a, 3) * ea * dj;
@@ -1063,7 +1063,7 @@ DEKF_FN bool solve_factor(Q& q) {
             } else if (kind == 1) {
 #pragma unroll
                 for (int leg = 0; leg < L; ++leg) {
-                    const double* wm = q.Wm + (k * L + leg) * 6;
+                    cdptr wm = q.Wm + (k * L + leg) * 6;
                     const double ea = q.E[ix.rm(k, 3 * leg + a)];
 #pragma unroll
                     for (int i = 3; i < 6; ++i) tc[i] += q.E[ix.rm(k, 3 * leg + i - 3)] * dx[i] * symget(wm, i - 3, a, 3) * ea * dj;
@@ -1098,29 +1098,29 @@ DEKF_FN bool solve_factor(Q& q) {
     bool ok = true;
     const int mid = mid_block(K);
     const int nph = (mid > K - 1 - mid ? mid : K - 1 - mid);
-    double* bufs[2][2] = {{q.tmp, q.tmp + 81}, {q.tmp + 176, q.tmp + 257}};
+    dptr bufs[2][2] = {{q.tmp, q.tmp + 81}, {q.tmp + 176, q.tmp + 257}};
     // S of block k into dst; use_top / use_bot select the Schur terms
-    auto build_s = [&](int k, bool use_top, bool use_bot, int p, double* dst) {
+    auto build_s = [&](int k, bool use_top, bool use_bot, int p, dptr dst) {
         int i = p / 9, j = p - 9 * i;
         int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
         double acc = q.Sinv[k * 81 + 9 * lo_ + hi_];
         if (use_top) {
-            const double* Wp = q.Wk + (k - 1) * 81;
-            const double* Cp = q.PA + (k - 1) * 81;
+            cdptr Wp = q.Wk + (k - 1) * 81;
+            cdptr Cp = q.PA + (k - 1) * 81;
             double s1 = 0.0, s2 = 0.0;
             for (int t = 0; t < 9; ++t) { s1 += Wp[9 * i + t] * Cp[9 * j + t]; s2 += Wp[9 * j + t] * Cp[9 * i + t]; }
             acc -= 0.5 * (s1 + s2);
         }
         if (use_bot) {
-            const double* Wh = q.Wk + k * 81;
-            const double* Ck = q.PA + k * 81;
+            cdptr Wh = q.Wk + k * 81;
+            cdptr Ck = q.PA + k * 81;
             double s1 = 0.0, s2 = 0.0;
             for (int t = 0; t < 9; ++t) { s1 += Wh[9 * i + t] * Ck[9 * t + j]; s2 += Wh[9 * j + t] * Ck[9 * t + i]; }
             acc -= 0.5 * (s1 + s2);
         }
         dst[p] = acc;
     };
-    auto gj_step = [&](const double* src, double* dst, int pv, int p) {
+    auto gj_step = [&](cdptr src, dptr dst, int pv, int p) {
         int i = p / 9, j = p - 9 * i;
         double d = 1.0 / src[pv * 9 + pv];
         double v;
@@ -1129,8 +1129,8 @@ DEKF_FN bool solve_factor(Q& q) {
         else v = src[p] - src[i * 9 + pv] * src[pv * 9 + j] * d;
         dst[p] = v;
     };
-    auto pivot_ok = [&](const double* src, int pv) { double piv = src[pv * 9 + pv]; return (fabs(piv) > 0.0) && (fabs(piv) < 1e300); };
-    auto store_sinv = [&](int k, const double* src, int e) {
+    auto pivot_ok = [&](cdptr src, int pv) { double piv = src[pv * 9 + pv]; return (fabs(piv) > 0.0) && (fabs(piv) < 1e300); };
+    auto store_sinv = [&](int k, cdptr src, int e) {
         int p = e, i = 0;
         while (p >= 9 - i) { p -= 9 - i; ++i; }
         int j = i + p;
@@ -1146,21 +1146,21 @@ DEKF_FN bool solve_factor(Q& q) {
     (void)nph; (void)bufs; (void)gj_step; (void)pivot_ok; (void)store_sinv; (void)build_s;
     // S of block k, element p (device form: three independent accumulators per sum, no symmetrisation —
     // W C' = C S^-1 C' is symmetric up to rounding and the Gauss-Jordan sweep does not need more)
-    auto build_s3 = [&](int k, bool use_top, bool use_bot, int p, double* dst) {
+    auto build_s3 = [&](int k, bool use_top, bool use_bot, int p, dptr dst) {
         const int i = p / 9, j = p - 9 * i;
         const int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
         double acc = q.Sinv[k * 81 + 9 * lo_ + hi_];
         if (use_top) {
-            const double* Wp = q.Wk + (k - 1) * 81 + 9 * i;
-            const double* Cp = q.PA + (k - 1) * 81 + 9 * j;
+            cdptr Wp = q.Wk + (k - 1) * 81 + 9 * i;
+            cdptr Cp = q.PA + (k - 1) * 81 + 9 * j;
             double s0 = Wp[0] * Cp[0] + Wp[3] * Cp[3] + Wp[6] * Cp[6];
             double s1 = Wp[1] * Cp[1] + Wp[4] * Cp[4] + Wp[7] * Cp[7];
             double s2 = Wp[2] * Cp[2] + Wp[5] * Cp[5] + Wp[8] * Cp[8];
             acc -= s0 + (s1 + s2);
         }
         if (use_bot) {
-            const double* Wh = q.Wk + k * 81 + 9 * i;
-            const double* Ck = q.PA + k * 81 + j;
+            cdptr Wh = q.Wk + k * 81 + 9 * i;
+            cdptr Ck = q.PA + k * 81 + j;
             double s0 = Wh[0] * Ck[0] + Wh[3] * Ck[27] + Wh[6] * Ck[54];
             double s1 = Wh[1] * Ck[9] + Wh[4] * Ck[36] + Wh[7] * Ck[63];
             double s2 = Wh[2] * Ck[18] + Wh[5] * Ck[45] + Wh[8] * Ck[72];
@@ -1168,10 +1168,10 @@ DEKF_FN bool solve_factor(Q& q) {
         }
         dst[p] = acc;
     };
-    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, double* tb) -> bool {
+    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, dptr tb) -> bool {
         // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]
         const int lane = DEKF_LANE() & 63;
-        double* ts = tb;        // S, then the full inverse
+        dptr ts = tb;        // S, then the full inverse
         for (int p = lane; p < 81; p += WAVE) build_s3(k, use_top, use_bot, p, ts);
         wave_sync();
         const int j = lane < 9 ? lane : 8;
@@ -1235,12 +1235,12 @@ DEKF_FN bool solve_factor(Q& q) {
         wave_sync();
         if (wmode != 0) {
             const int kw = wmode == 1 ? k : k - 1;
-            const double* Ck = q.PA + kw * 81;
+            cdptr Ck = q.PA + kw * 81;
             for (int p = lane; p < 81; p += WAVE) {
                 const int i = p / 9, jj = p - 9 * i;
-                const double* cr = wmode == 1 ? Ck + 9 * i : Ck + i;  // row i of C, or column i (C')
+                cdptr cr = wmode == 1 ? Ck + 9 * i : Ck + i;  // row i of C, or column i (C')
                 const int cs = wmode == 1 ? 1 : 9;
-                const double* tc = ts + jj;
+                cdptr tc = ts + jj;
                 double s0 = cr[0] * tc[0] + cr[3 * cs] * tc[27] + cr[6 * cs] * tc[54];
                 double s1 = cr[cs] * tc[9] + cr[4 * cs] * tc[36] + cr[7 * cs] * tc[63];
                 double s2 = cr[2 * cs] * tc[18] + cr[5 * cs] * tc[45] + cr[8 * cs] * tc[72];
@@ -1250,7 +1250,7 @@ DEKF_FN bool solve_factor(Q& q) {
         wave_sync();
         return good;
     };
-    double* fail = q.tmp + 172;  // [162, 171) is the scaled q
+    dptr fail = q.tmp + 172;  // [162, 171) is the scaled q
     if (DEKF_LANE() == 0) *fail = 0.0;
     DEKF_SYNC();
 #ifdef DEKF_X_LDL_PRIO
@@ -1283,9 +1283,9 @@ DEKF_FN bool solve_factor(Q& q) {
             if constexpr (Q::NFIXED >= 4 && Q::NFIXED % 2 == 0) {
                 if (K == Q::NFIXED) {
                     const int lane = DEKF_LANE() & 63;
-                    const double* P11 = q.tmp;           // factor_block left S_m^-1 there
-                    double* P12 = q.tmp + 81;
-                    const double* Wh = q.Wk + mid * 81;  // W^_m
+                    cdptr P11 = q.tmp;           // factor_block left S_m^-1 there
+                    dptr P12 = q.tmp + 81;
+                    cdptr Wh = q.Wk + mid * 81;  // W^_m
                     for (int pp = lane; pp < 81; pp += WAVE) {
                         const int i = pp / 9, j = pp - 9 * i;
                         double s0 = P11[9 * i] * Wh[j] + P11[9 * i + 3] * Wh[27 + j] + P11[9 * i + 6] * Wh[54 + j];
@@ -1339,15 +1339,15 @@ DEKF_FN bool solve_factor(Q& q) {
             });
             cur ^= 1;
         }
-        const double* st = bufs[0][cur];
-        const double* sb = bufs[1][cur];
+        cdptr st = bufs[0][cur];
+        cdptr sb = bufs[1][cur];
         wfor(252, [&](int e) {
             int side = e / 126, o = e - 126 * side;
             if (side == 0 && vt) {
                 if (o < 45) store_sinv(kt, st, o);
                 else if (!last) {  // W_kt = C_kt S^-1
                     int p = o - 45, i = p / 9, j = p - 9 * i;
-                    const double* Ck = q.PA + kt * 81;
+                    cdptr Ck = q.PA + kt * 81;
                     double acc = 0.0;
                     for (int u = 0; u < 9; ++u) acc += Ck[9 * i + u] * st[9 * u + j];
                     q.Wk[kt * 81 + p] = acc;
@@ -1356,7 +1356,7 @@ DEKF_FN bool solve_factor(Q& q) {
                 if (o < 45) store_sinv(kb, sb, o);
                 else {  // What_{kb-1} = C_{kb-1}' S^-1
                     int p = o - 45, i = p / 9, j = p - 9 * i;
-                    const double* Ck = q.PA + (kb - 1) * 81;
+                    cdptr Ck = q.PA + (kb - 1) * 81;
                     double acc = 0.0;
                     for (int u = 0; u < 9; ++u) acc += Ck[9 * u + i] * sb[9 * u + j];
                     q.Wk[(kb - 1) * 81 + p] = acc;
@@ -1381,7 +1381,7 @@ struct SolveInfo {
 // FACTOR_LDS / PA_LDS are compile-time so that every pointer has a provable address space
 // (ds_read/ds_write instead of flat_load) — see SolveLayout::factor_in_lds / pa_in_lds.
 template <int L, bool FACTOR_LDS, bool PA_LDS, int NFIX = 0, int FT = 0, bool R3 = false>
-DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, double* lds, double* gws) {
+DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, dptr lds, dptr gws) {
     // NFIX != 0: the horizon is a compile-time constant, so every LDS array sits at a constant offset
     // (folded into the ds_read/ds_write immediates instead of living in scalar registers)
     const int NH = NFIX ? NFIX : c.N;
@@ -1393,81 +1393,89 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     g.init(NH, L, FT);
     SolveCtx<L, NFIX, FACTOR_LDS, FT, R3> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
     q.xb = nullptr;
-    {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time
-        double* p = lds;
+    {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time.  Every array is handed out with its
+        // extent (DEKF_SPAN: a plain pointer in the product builds, a checked one in the -DDEKF_BOUNDS build, wave.h)
+        double* p = raw_of(lds);
+        double* const gw = raw_of(gws);
+        auto take = [&](int len) { dptr r = DEKF_SPAN(p, len); p += len; return r; };
+        auto gs = [&](int off, int len) { return DEKF_SPAN(gw + off, len); };
+        const int b2K = NH * NS2;
         if constexpr (R3) {
             static_assert(!R3 || (FACTOR_LDS && PA_LDS && NFIX != 0 && FT == 0), "R3: fixed horizon, 9 states, factor in LDS");
-            q.R = p; p += 9 * NH;
-            q.D = p; p += lay.n_pad;
-            q.E = p; p += lay.m_pad;
-            q.xb = p; p += NS * NH;
-            q.PA = DEKF_R3_PA_LDS ? p : gws + g.PA;  // everything in this region is dead while a factorisation runs
-            q.xd = p;
-            q.at = q.xd + NS * NH;
-            q.xs = q.at + lay.m_pad;
-            q.gb = q.xs + NS * NH;
+            q.R = take(9 * NH);
+            q.D = take(lay.n_pad);
+            q.E = take(lay.m_pad);
+            q.xb = take(NS * NH);
+            double* const rb = p;  // everything in this region is dead while a factorisation runs
+            q.PA = DEKF_R3_PA_LDS ? DEKF_SPAN(rb, lay.r3_pa_region()) : gs(g.PA, b2K);
+            q.xd = DEKF_SPAN(rb, NS * NH);
+            q.at = DEKF_SPAN(rb + NS * NH, lay.m_pad);
+            q.xs = DEKF_SPAN(rb + NS * NH + lay.m_pad, NS * NH);
+            q.gb = DEKF_SPAN(rb + 2 * NS * NH + lay.m_pad, 3 * NH);
             q.sx = q.at;
-            q.sy = q.gb + 3 * NH;
-            q.sz = q.sy + lay.m_pad;
+            q.sy = DEKF_SPAN(rb + 2 * NS * NH + lay.m_pad + 3 * NH, lay.m_pad);
+            q.sz = DEKF_SPAN(rb + 2 * NS * NH + 2 * lay.m_pad + 3 * NH, 3 * NH);
             p += lay.r3_pa_region();
-            q.tmp = p; p += TM::LEN;
-            q.Sinv = p; p += NH * NS2;
-            q.Wk = p; p += NH * NS2;
+            q.tmp = take(TM::LEN);
+            q.Sinv = take(b2K);
+            q.Wk = take(b2K);
             q.Sf = nullptr; q.Wf = nullptr;
             // The row state is in registers during a chunk of iterations and in LDS (sx, sy, sz) between chunks; the slab holds it
             // only across a refactorisation (whose temporaries need the LDS region): q.x <- sx, q.y <- sy, q.z <- sz.  What stays in
             // the slab for the whole solve are constants: the scaled bounds (written once, at the cold start) and the slack-block
             // inverses (once per factorisation) — 13 KB per workgroup.
-            q.x = gws + g.x; q.z = gws + g.z; q.y = gws + g.y; q.zt = nullptr; q.cf = nullptr;
+            q.x = gs(g.x, lay.n_pad); q.z = gs(g.z, lay.m_pad); q.y = gs(g.y, lay.m_pad); q.zt = nullptr; q.cf = nullptr;
             q.xt = nullptr;
-            q.lo = gws + g.lo; q.hi = gws + g.hi;
+            q.lo = gs(g.lo, lay.m_pad); q.hi = gs(g.hi, lay.m_pad);
             q.cold = true;
-            q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc;
-            q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
+            q.Sv = gs(g.Sv, NH * 6 * L); q.Sw = gs(g.Sw, NH * SWS); q.Sc = gs(g.Sc, NH * 6);
+            q.Wm = gs(g.Wm, NH * 6 * L); q.Wd = gs(g.Wd, NH * 24); q.Wc = gs(g.Wc, NH * 6);
         }
         if constexpr (!R3) {
-        q.x = p; p += lay.n_pad;
-        q.z = p; p += lay.m_pad;
-        q.y = p; p += lay.m_pad;
-        q.xt = p; p += lay.n_pad;
-        q.cf = q.xt;
-        q.gb = q.xt + lay.m_pad;  // 3 (N - 1) <= n_pad - m_pad = NS N
-        q.zt = p; p += lay.m_pad;
-        q.at = p; p += lay.m_pad;
-        q.xs = p; p += NS * NH;
-        q.xd = p; p += NS * NH;
-        q.tmp = p; p += TM::LEN;
+        q.x = take(lay.n_pad);
+        q.z = take(lay.m_pad);
+        q.y = take(lay.m_pad);
+        double* const xtb = p;  // xt | zt | at: the factor-time scratch (PA, the staging panels of factor_blocks_generic) spans all three
+        q.xt = DEKF_SPAN(xtb, lay.n_pad + 2 * lay.m_pad);
+        q.cf = DEKF_SPAN(xtb, lay.m_pad);
+        q.gb = DEKF_SPAN(xtb + lay.m_pad, lay.n_pad - lay.m_pad);  // 3 (N - 1) <= n_pad - m_pad = NS N
+        p += lay.n_pad;
+        q.zt = take(lay.m_pad);
+        q.at = take(lay.m_pad);
+        q.xs = take(NS * NH);
+        q.xd = take(NS * NH);
+        q.tmp = take(TM::LEN);
         q.Sf = nullptr;
         q.Wf = nullptr;
         if constexpr (FACTOR_LDS) {
-            q.D = p; p += lay.n_pad;
-            q.E = p; p += lay.m_pad;
-            q.lo = p; p += lay.m_pad;
-            q.hi = p; p += 3 * NH;
-            q.Sv = p; p += NH * 6 * L;
-            q.Sw = p; p += NH * SWS;
-            q.Sc = p; p += NH * 6;
-            if constexpr (FT) { q.Sf = p; p += NH * 6 * L; }
-            q.Sinv = p; p += NH * NS2;
-            q.Wk = p; p += NH * NS2;
-            q.R = p; p += NH * 9;
+            q.D = take(lay.n_pad);
+            q.E = take(lay.m_pad);
+            q.lo = take(lay.m_pad);
+            q.hi = take(3 * NH);
+            q.Sv = take(NH * 6 * L);
+            q.Sw = take(NH * SWS);
+            q.Sc = take(NH * 6);
+            if constexpr (FT) q.Sf = take(NH * 6 * L);
+            q.Sinv = take(b2K);
+            q.Wk = take(b2K);
+            q.R = take(NH * 9);
         } else {
-            q.D = gws + g.D; q.E = gws + g.E; q.lo = gws + g.lo; q.hi = gws + g.hi;
-            q.Sv = gws + g.Sv; q.Sw = gws + g.Sw; q.Sc = gws + g.Sc;
-            if constexpr (FT) q.Sf = gws + g.Sf;
-            q.Sinv = gws + g.Sinv; q.Wk = gws + g.Wk; q.R = gws + g.rho;  // rho slot is unused: R (9K <= m_pad)
+            q.D = gs(g.D, lay.n_pad); q.E = gs(g.E, lay.m_pad); q.lo = gs(g.lo, lay.m_pad); q.hi = gs(g.hi, lay.m_pad);
+            q.Sv = gs(g.Sv, NH * 6 * L); q.Sw = gs(g.Sw, NH * SWS); q.Sc = gs(g.Sc, NH * 6);
+            if constexpr (FT) q.Sf = gs(g.Sf, NH * 6 * L);
+            q.Sinv = gs(g.Sinv, b2K); q.Wk = gs(g.Wk, b2K); q.R = gs(g.rho, lay.m_pad);  // rho slot is unused: R (9K <= m_pad)
             if (lay.gg_consts_in_lds()) {  // (run-time placement: these five become generic pointers in this instantiation)
-                q.D = p; p += lay.n_pad;
-                q.E = p; p += lay.m_pad;
-                q.lo = p; p += lay.m_pad;
-                q.hi = p; p += 3 * NH;
-                q.R = p; p += 9 * NH;
+                q.D = take(lay.n_pad);
+                q.E = take(lay.m_pad);
+                q.lo = take(lay.m_pad);
+                q.hi = take(3 * NH);
+                q.R = take(9 * NH);
             }
         }
-        q.Wm = gws + g.Wm; q.Wd = gws + g.Wd; q.Wc = gws + g.Wc;
-        if constexpr (FT) q.Wf = gws + g.Wf;
+        q.Wm = gs(g.Wm, NH * 6 * L); q.Wd = gs(g.Wd, NH * 24); q.Wc = gs(g.Wc, NH * 6);
+        if constexpr (FT) q.Wf = gs(g.Wf, NH * 6 * L);
         if constexpr (PA_LDS) q.PA = q.xt;
-        else q.PA = gws + g.PA;
+        else q.PA = gs(g.PA, b2K);
         }
     }
     if constexpr (FACTOR_LDS) {
@@ -1476,25 +1484,32 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         // S^-1.  (They used to make a round trip through the HBM slab per factorisation: most of the kernel's excess traffic.)
         constexpr int PSL = 6 * L + 27 + 6 * L * FT, WLEN = 6 * L + 30 + 6 * L * FT;
         if (NH * PSL + NS * (NS + 1) / 2 <= NH * NS2 && NH * WLEN <= NH * NS2) {
-            q.Wm = q.Wk;
-            q.Wd = q.Wm + NH * 6 * L;
-            q.Wc = q.Wd + NH * 24;
-            if constexpr (FT) q.Wf = q.Wc + NH * 6;
+            double* const wb = raw_of(q.Wk);
+            q.Wm = DEKF_SPAN(wb, NH * 6 * L);
+            q.Wd = DEKF_SPAN(wb + NH * 6 * L, NH * 24);
+            q.Wc = DEKF_SPAN(wb + NH * 6 * L + NH * 24, NH * 6);
+            if constexpr (FT) q.Wf = DEKF_SPAN(wb + NH * 6 * L + NH * 30, NH * 6 * L);
         }
     }
     q.n = (K - 1) * IdxT<L, FT>::SV + NS + IdxT<L, FT>::nm;
     q.m = (K - 1) * IdxT<L, FT>::SC + IdxT<L, FT>::nm;
-    q.Mp = s.snap + (size_t)c.snap_len * b;
-    q.np = q.Mp + NS2;
-    q.vo = q.np + NS;
+    {
+        const double* sn = s.snap + (size_t)c.snap_len * b;
+        q.Mp = DEKF_CSPAN(sn, NS2);
+        q.np = DEKF_CSPAN(sn + NS2, NS);
+        q.vo = DEKF_CSPAN(sn + NS2 + NS, 4 * c.wcap);
+    }
     q.cc = 1.0;
-    q.Pst = q.Sinv;  // Sinv | Wk are adjacent in both placements and dead until a factorisation writes them
+    q.Pst = DEKF_SPAN(raw_of(q.Sinv), 2 * NH * NS2);  // Sinv | Wk are adjacent in both placements and dead until a factorisation writes them
     q.staged = false;
     const int n = q.n, m = q.m;
     const auto& ix = q.ix;
     SolveInfo info{0, DEKF_SOLVE_MAX_ITER, 0, 0.0, 0.0, c.rho0};
+#if defined(DEKF_BOUNDS) && DEKF_DEVICE_BUILD
+    const unsigned long long bounds_hits0 = *(volatile unsigned long long*)&dekf_bounds_hits[0];
+#endif
 
-    q.prof = s.prof + DEKF_PROF_SLOTS * (size_t)b;
+    q.prof = DEKF_SPAN(s.prof + DEKF_PROF_SLOTS * (size_t)b, DEKF_PROF_SLOTS);
 #if defined(DEKF_PROFILE) && DEKF_DEVICE_BUILD
     q.prof_last = clock64();
     const long long prof_t0 = q.prof_last;
@@ -1509,10 +1524,11 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         // D and E stay in LDS for the whole solve; the Ruiz passes' temporaries pc, En, Dn sit behind the staged P blocks inside
         // S^-1 | W, which are not live before the first factorisation.
         constexpr int PSL = NFIX * (6 * L + 27) + NS * (NS + 1) / 2;
-        double *xg = q.x, *ztg = nullptr;
-        q.x = q.Sinv + PSL;              // pc
-        q.zt = q.x + lay.n_pad;          // En
-        q.xt = q.zt + lay.m_pad;         // Dn
+        dptr xg = q.x, ztg = nullptr;
+        double* const sb = raw_of(q.Sinv);
+        q.x = DEKF_SPAN(sb + PSL, lay.n_pad);                            // pc
+        q.zt = DEKF_SPAN(sb + PSL + lay.n_pad, lay.m_pad);               // En
+        q.xt = DEKF_SPAN(sb + PSL + lay.n_pad + lay.m_pad, lay.n_pad);   // Dn
         if (c.scaling > 0) solve_scale(q);
         else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
         q.x = xg; q.zt = ztg; q.xt = nullptr;
@@ -1524,7 +1540,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     DEKF_PROF_MARK(q, 0);
     q.rho = dmin(dmax(c.rho0, RHO_MIN), RHO_MAX);
     // scaled bounds, cold start
-    double *x = q.x, *z = q.z, *y = q.y, *at = q.at;
+    dptr x = q.x, z = q.z, y = q.y, at = q.at;
     wfor(R3 ? m : n + m, [&](int e0) {
         const int e = R3 ? e0 + n : e0;  // (R3: only the scaled bounds; the first chunk's row-block load is the cold start x = z = y = 0)
         if (e < n) { x[e] = 0.0; return; }
@@ -1630,7 +1646,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     info.iters = iter;
     info.rho = q.rho;
     // store_solution + update() tail: x_T = D x ; v_b = R (x_T[3:6] + gyro x p_imu_2_opti)
-    const double* rT = q.rec(K - 1);
+    cdptr rT = q.rec(K - 1);
     double xT[NS];
     bool finite = ok;
     for (int j = 0; j < NS; ++j) {
@@ -1638,12 +1654,19 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         if (!(fabs(xT[j]) <= 1e300)) finite = false;
     }
     if (!finite) info.status = DEKF_SOLVE_NUMERIC;
+#if defined(DEKF_BOUNDS) && DEKF_DEVICE_BUILD
+    // an out-of-range dereference while this instance was being solved (by this or a concurrent workgroup: the counter is global)
+    if (*(volatile unsigned long long*)&dekf_bounds_hits[0] != bounds_hits0) info.status = DEKF_SOLVE_NUMERIC;
+#endif
     if (DEKF_LANE() == 0) {
         const double p_opti[3] = {0.016041, 0.089061, 0.0579875};
         double wxp[3], t[3], vb[3];
-        cross3(rT + Rec::GY, p_opti, wxp);
+        double gy[3], Rl[9];
+        for (int a = 0; a < 3; ++a) gy[a] = rT[Rec::GY + a];
+        for (int a = 0; a < 9; ++a) Rl[a] = rT[Rec::R + a];
+        cross3(gy, p_opti, wxp);
         for (int a = 0; a < 3; ++a) t[a] = xT[3 + a] + wxp[a];
-        mv3(rT + Rec::R, t, vb);
+        mv3(Rl, t, vb);
         for (int j = 0; j < NS; ++j) s.x_mhe[NS * (size_t)b + j] = xT[j];
         for (int a = 0; a < 3; ++a) s.v_b[3 * (size_t)b + a] = vb[a];
         s.status[b] = info.status;

@@ -44,6 +44,63 @@ static __device__ __forceinline__ int dekf_lane_id() {
 
 namespace dekf {
 
+// ---------------------------------------------------------------- pointers of the solve cores
+// The solve cores (mhe_solve_core.h, mhe_admm_core.h) address LDS, the workgroup's slab and the window records through `dptr` /
+// `cdptr`.  In every product build these ARE double* / const double*.  The -DDEKF_BOUNDS build (csrc/libdekf_bounds.so, a
+// diagnostic variant like libdekf_prof.so) makes them fat pointers that carry the extent of the array they were carved from:
+// every dereference outside [lo, hi) is counted in a device-side counter, redirected to the array's first element (so the kernel
+// neither faults nor corrupts a neighbour) and the instance's status becomes DEKF_SOLVE_NUMERIC.  GPU AddressSanitizer is not
+// available on this pool; this is the substitute for the device-only code the lane-sequential host build cannot execute.
+#if defined(DEKF_BOUNDS) && DEKF_DEVICE_BUILD
+extern __device__ unsigned long long dekf_bounds_hits[4];  // [0] count, [1] first offending offset (elements from lo), [2] extent, [3] line
+static __device__ __forceinline__ void dekf_bounds_report(long off, long n, int line) {
+    if (atomicAdd(&dekf_bounds_hits[0], 1ull) == 0ull) {
+        dekf_bounds_hits[1] = (unsigned long long)off;
+        dekf_bounds_hits[2] = (unsigned long long)n;
+        dekf_bounds_hits[3] = (unsigned long long)line;
+    }
+}
+template <class T>
+struct BPtr {
+    T* p;
+    T* lo;
+    T* hi;  // lo == nullptr: unchecked (a pointer to a lane's own local array, or one that came in as a raw pointer)
+    DEKF_FN BPtr() : p(nullptr), lo(nullptr), hi(nullptr) {}
+    DEKF_FN BPtr(T* raw) : p(raw), lo(nullptr), hi(nullptr) {}
+    DEKF_FN BPtr(decltype(nullptr)) : p(nullptr), lo(nullptr), hi(nullptr) {}
+    DEKF_FN BPtr(T* p_, T* lo_, T* hi_) : p(p_), lo(lo_), hi(hi_) {}
+    template <class U, class = decltype(static_cast<T*>((U*)nullptr))>
+    DEKF_FN BPtr(const BPtr<U>& o) : p(o.p), lo(o.lo), hi(o.hi) {}
+    DEKF_FN T& at(long i, int line = 0) const {
+        T* a = p + i;
+        if (lo && (a < lo || a >= hi)) { dekf_bounds_report((long)(a - lo), (long)(hi - lo), line); a = lo; }
+        return *a;
+    }
+    template <class I> DEKF_FN T& operator[](I i) const { return at((long)i); }
+    DEKF_FN T& operator*() const { return at(0); }
+    template <class I> DEKF_FN BPtr operator+(I i) const { return BPtr(p + i, lo, hi); }
+    template <class I> DEKF_FN BPtr operator-(I i) const { return BPtr(p - i, lo, hi); }
+    template <class I> DEKF_FN BPtr& operator+=(I i) { p += i; return *this; }
+    template <class U> DEKF_FN long operator-(const BPtr<U>& o) const { return (long)(p - o.p); }
+    DEKF_FN explicit operator bool() const { return p != nullptr; }
+    template <class U> DEKF_FN bool operator==(const BPtr<U>& o) const { return p == o.p; }
+    template <class U> DEKF_FN bool operator!=(const BPtr<U>& o) const { return p != o.p; }
+    DEKF_FN T* raw() const { return p; }
+};
+using dptr = BPtr<double>;
+using cdptr = BPtr<const double>;
+// the array of n doubles at raw pointer q
+#define DEKF_SPAN(q_, n_) dekf::dptr((q_), (q_), (q_) + (n_))
+#define DEKF_CSPAN(q_, n_) dekf::cdptr((q_), (q_), (q_) + (n_))
+template <class T> DEKF_FN T* raw_of(const BPtr<T>& b) { return b.p; }
+#else
+using dptr = double*;
+using cdptr = const double*;
+#define DEKF_SPAN(q_, n_) (q_)
+#define DEKF_CSPAN(q_, n_) (q_)
+#endif
+template <class T> DEKF_FN T* raw_of(T* p) { return p; }
+
 constexpr int WAVE = 64;
 constexpr int MAX_WAVES = 4;  // per workgroup / instance
 
