@@ -870,8 +870,17 @@ DEKF_FN bool solve_factor(Q& q) {
             for (int d = a; d < 3; ++d)
                 W_out[symidx(a, d, 3)] = (a == d ? rr[a] : 0.0) - gv[a] * Si[symidx(a, d, 3)] * gv[d];
     };
-    wfor(K * NB, [&](int e) {
-        int k = e / NB, blk = e - k * NB;
+    // One kind of block per wavefront-sized tile (Meas leg blocks | Dyn 6x6 + bias | VO | foot Dyn), so that a wavefront runs ONE
+    // of the four bodies: as items of mixed kind spread over all lanes, every wavefront ran all of them one after the other
+    // (Go1: 14 k cycles per factorisation, most of it the 6x6 inverse that only 19 of 256 lanes needed)
+    (void)NB;
+    const int n3m = K * L, n3d = K - 1, ntm3 = (n3m + 63) >> 6, ntd3 = (n3d + 63) >> 6, ntf3 = FT ? ((K - 1) * L + 63) >> 6 : 0;
+    wtiles(ntm3 + 2 * ntd3 + ntf3, [&](int tile, int lane) {
+        int k, blk;
+        if (tile < ntm3) { const int e = tile * 64 + lane; if (e >= n3m) return; k = e / L; blk = e - k * L; }
+        else if (tile < ntm3 + ntd3) { k = (tile - ntm3) * 64 + lane; if (k >= n3d) return; blk = L; }
+        else if (tile < ntm3 + 2 * ntd3) { k = (tile - ntm3 - ntd3) * 64 + lane; if (k >= n3d) return; blk = L + 1; }
+        else { const int e = (tile - ntm3 - 2 * ntd3) * 64 + lane; if (e >= (K - 1) * L) return; k = e / L; blk = L + 2 + (e - k * L); }
         cdptr pk = q.Pst + k * PS;  // [Qm 6L | Qd 21 | Qc 6 | Qf 6L]
         if (blk < L) {
             block3(pk + 6 * blk, ix.rm(k, 3 * blk), ix.v(k, 3 * blk), q.Sv + (k * L + blk) * (ST ? 1 : 6), q.Wm + (k * L + blk) * 6, stv);
@@ -915,6 +924,7 @@ DEKF_FN bool solve_factor(Q& q) {
             block3(pk + 6 * L + 27 + 6 * leg, ix.rd(k, 9 + 3 * leg), ix.w(k, 9 + 3 * leg), q.Sf + (k * L + leg) * 6, q.Wf + (k * L + leg) * 6, 1);
         }
     });
+    DEKF_SYNC();
     DEKF_PROF_MARK(q, 6);
     // 3b+3c. One lane per column j of block k: column j of PA_k = Wd_k (E A_dyn D) stays in registers and
     //     yields column j of T_kk (upper part, packed -> Sinv[k]) and column j of C_k (-> PA[k]; W_k goes
