@@ -95,7 +95,7 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
             const int k = e / NM, la = e - NM * k, j = 9 + la, i = k * SV + j;
             const double xv = q.x[i], dv = q.D[i], qv = qsl[j];
             const double g = gather_fcol(q, k, la, w);
-            q.xs[NS * k + j] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
+            q.xs[NS * k + j] = fma(dv, g, fma(sigma, xv, -(k == 0 ? qv : 0.0)));
             return;
         }
         const int kind = tile < nt ? 0 : (tile < 2 * nt ? 1 : 2);
@@ -112,7 +112,7 @@ DEKF_FN void phase_xcols(Q& q, double sigma) {
             const double n0 = w(q.ix.rd(kn, 6 + a)), n1 = q.gb[3 * kn + a], p0 = w(q.ix.rd(kp, 6 + a));
             g = (hn ? n0 - n1 : 0.0) - (hp ? p0 : 0.0);
         }
-        q.xs[NS * k + j] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
+        q.xs[NS * k + j] = fma(dv, g, fma(sigma, xv, -(k == 0 ? qv : 0.0)));
     });
 #if defined(DEKF_PROFILE_TL) && defined(DEKF_PROFILE_TLX)
     __builtin_amdgcn_s_waitcnt(0);
@@ -190,7 +190,7 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
         if (act) {
             if (BWD) {
                 xd[9 * kn + i] = c.dsc * v;
-                x[kn * SV + i] = alpha * v + (1.0 - alpha) * c.xo;
+                x[kn * SV + i] = relax(alpha, v, c.xo);
             } else {
                 xs[9 * kn + i] = v;
             }
@@ -211,7 +211,7 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
             if (act) {
                 if (BWD) {
                     xd[9 * kn + i] = c.dsc * v;
-                    x[kn * SV + i] = alpha * v + (1.0 - alpha) * c.xo;
+                    x[kn * SV + i] = relax(alpha, v, c.xo);
                 } else {
                     xs[9 * kn + i] = v;
                 }
@@ -256,7 +256,7 @@ DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha
             v[i] = nv[i];
             if (BWD) {
                 xd[9 * kn + i] = q.D[kn * SV + i] * v[i];
-                x[kn * SV + i] = alpha * v[i] + (1.0 - alpha) * x[kn * SV + i];
+                x[kn * SV + i] = relax(alpha, v[i], x[kn * SV + i]);
             } else {
                 xs[9 * kn + i] = v[i];
             }
@@ -293,7 +293,7 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
         const int xi = mid * SV + i;
         xs[9 * mid + i] = u;
         xd[9 * mid + i] = q.D[xi] * u;
-        x[xi] = alpha * u + (1.0 - alpha) * x[xi];
+        x[xi] = relax(alpha, u, x[xi]);
     }
 #else
     if (lane != 0) return;
@@ -317,7 +317,7 @@ DEKF_FN void sweep_mid_block(Q& q, int lane, double alpha) {
         const int xi = mid * SV + i;
         xs[9 * mid + i] = u;
         xd[9 * mid + i] = q.D[xi] * u;
-        x[xi] = alpha * u + (1.0 - alpha) * x[xi];
+        x[xi] = relax(alpha, u, x[xi]);
     }
 #endif
 }
@@ -433,7 +433,7 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
         const double um = part + rows01_from_rows23(part);        // rows 0, 1: u_M, u_{M+1}
         if (leg && act) {
             xd[9 * blk + i] = dm * um;
-            x[blk * XST + i] = alpha * um + (1.0 - alpha) * xm;
+            x[blk * XST + i] = relax(alpha, um, xm);
         }
         v = um;
     }
@@ -466,7 +466,7 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
             const double r = chain_matvec_dpp(v, c.w, -c.ng);
             v = r;
             xdp[s * xdstep] = c.dsc * r;
-            xp[s * xstep] = alpha * r + (1.0 - alpha) * c.xo;
+            xp[s * xstep] = relax(alpha, r, c.xo);
         }
     }
 }
@@ -542,7 +542,7 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
         const double um = -chain_matvec_dpp(res, s9, 0.0);         // row 0: S_M^-1 (f_M - W^_M f^_{M+1})
         if (row == 0 && act) {
             xd[9 * M + i] = dm * um;
-            x[M * SV + i] = alpha * um + (1.0 - alpha) * xm;
+            x[M * SV + i] = relax(alpha, um, xm);
         }
         v = row1_from_row0(um);                                    // rows 0 and 1 start from u_M
     }
@@ -572,10 +572,10 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
             v = res;
             if (s <= M) {
                 xdp[s * xdstep] = c.dsc * res;
-                xp[s * xstep] = alpha * res + (1.0 - alpha) * c.xo;
+                xp[s * xstep] = relax(alpha, res, c.xo);
             } else if (!top && own) {  // the bottom leg is one block longer
                 xdp[s * xdstep] = c.dsc * res;
-                xp[s * xstep] = alpha * res + (1.0 - alpha) * c.xo;
+                xp[s * xstep] = relax(alpha, res, c.xo);
             }
         };
 #pragma unroll
@@ -676,7 +676,7 @@ DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
             const int kn = k0 + s * dk;
             if (BWD) {
                 xd[NS * kn + i] = c.dsc * own;
-                x[kn * SV + i] = alpha * own + (1.0 - alpha) * c.xo;
+                x[kn * SV + i] = relax(alpha, own, c.xo);
             } else {
                 xs[NS * kn + i] = own;
             }
@@ -722,7 +722,7 @@ DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
                 v[i] = nv[i];
                 if (BWD) {
                     xd[NS * kn + i] = q.D[kn * SV + i] * v[i];
-                    x[kn * SV + i] = alpha * v[i] + (1.0 - alpha) * x[kn * SV + i];
+                    x[kn * SV + i] = relax(alpha, v[i], x[kn * SV + i]);
                 } else {
                     xs[NS * kn + i] = v[i];
                 }
@@ -761,7 +761,7 @@ DEKF_FN void sweep_mid_block_generic(Q& q, int lane, double alpha) {
         const int xi = mid * SV + i;
         xs[NS * mid + i] = u;
         xd[NS * mid + i] = q.D[xi] * u;
-        x[xi] = alpha * u + (1.0 - alpha) * x[xi];
+        x[xi] = relax(alpha, u, x[xi]);
     }
 #else
     if (lane != 0) return;
@@ -783,7 +783,7 @@ DEKF_FN void sweep_mid_block_generic(Q& q, int lane, double alpha) {
         const int xi = mid * SV + i;
         xs[NS * mid + i] = u;
         xd[NS * mid + i] = q.D[xi] * u;
-        x[xi] = alpha * u + (1.0 - alpha) * x[xi];
+        x[xi] = relax(alpha, u, x[xi]);
     }
 #endif
 }
@@ -966,8 +966,8 @@ DEKF_FN void row_block_compute(Q& q, int r0, int sv0, cdptr ar, const SM& S, con
     for (int j = 0; j < NR; ++j) {
         const double sj = p.t0[j] + sl[j];       // slack solution
         const double ztn = ar[j] - c2[j] * sj;   // (A xt)(r)
-        xn[j] = alpha * sj + (1.0 - alpha) * p.x0[j];
-        const double zh = alpha * ztn + (1.0 - alpha) * p.z0[j];
+        xn[j] = relax(alpha, sj, p.x0[j]);
+        const double zh = relax(alpha, ztn, p.z0[j]);
         double rv;
         if (EQ) {
             rv = rho_eq;
@@ -978,7 +978,7 @@ DEKF_FN void row_block_compute(Q& q, int r0, int sv0, cdptr ar, const SM& S, con
         }
         yn[j] = p.y0[j] + rv * (zh - zn[j]);
         un[j] = rv * zn[j] - yn[j];
-        rhs[j] = sigma * xn[j] - c2[j] * un[j];
+        rhs[j] = lin2(sigma, xn[j], -c2[j], un[j]);
     }
     S.apply(rhs, t);
 #pragma unroll
@@ -1013,7 +1013,7 @@ DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma,
         e[j] = q.E[r];
         cf[j] = rv * e[j] * d;
         un[j] = rv * q.z[r] - q.y[r];
-        rhs[j] = sigma * q.x[sv] - e[j] * d * un[j];
+        rhs[j] = lin2(sigma, q.x[sv], -(e[j] * d), un[j]);
     }
     S.apply(rhs, t);
 #pragma unroll
@@ -1361,17 +1361,27 @@ DEKF_FN void row_tile_finish(Q& q, const RowTile& t, double alpha, double sigma)
 //   barrier B1: xs complete   (workers: x columns)      ->  wavefront 0: solve
 //   barrier B2: xd complete   (wavefront 0: solve)      ->  workers: rows from registers, w and gb to LDS
 //   barrier B3: w, gb complete (workers)                ->  workers: x columns of the next iteration
-struct RowRegs {
-    int kind;  // 0 Meas leg block (equality), 1 Dyn position / velocity half on a lane pair, 2 VO or bias or Meas block on the generic path; -1 none
+// One row block's state and constants, by KIND of block — a compile-time parameter, because each worker wavefront runs ONE kind
+// in its own loop (admm_chunk_r3) and must not carry the registers of the others: 0 Meas leg block (equality; 27 doubles),
+// 1 Dyn position / velocity half on a lane pair (equality, 6x6 slack block: + 9 coupling entries), 2 VO / Dyn bias / Meas block on
+// the generic projection path (+ upper bounds and z).  An equality block keeps no z: it is the bound itself from the first
+// iteration on (0 before it, on a cold start).
+template <int KIND>
+struct RowRegsT {
+    static constexpr int kind = KIND;
+    bool valid;      // the lane owns a block
     int k, r0, sv0;
     bool vel, meas;  // kind 1: velocity half; kind 2: a Meas block folded into the VO / bias tile
+    bool vo;         // kind 2: a VO block (the only kind whose z is state)
     int xo;          // kind 2: offset of the block's x entries inside a step (0 VO, 6 bias, 3 Meas)
     double e[3], c2[3], cf[3], lo[3];
-    double t[3], xs[3], z[3], y[3];
-    double a[6], b[9];  // slack-block inverse: own part, coupling to the partner lane (kind 1); kind 2: b[0..2] = upper bounds
+    double t[3], xs[3], y[3];
+    double z[KIND == 2 ? 3 : 1];
+    double a[6];                                  // slack-block inverse: own 3x3 (symmetric, packed)
+    double b[KIND == 1 ? 9 : (KIND == 2 ? 3 : 1)];  // kind 1: coupling to the partner lane; kind 2: upper bounds
     DEKF_FN void apply(cdptr in, dptr out) const {
         double pin[3] = {0.0, 0.0, 0.0};
-        if (kind == 1) {
+        if constexpr (KIND == 1) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) pin[j] = pair_swap(in[j]);
         }
@@ -1380,7 +1390,7 @@ struct RowRegs {
             double acc = 0.0;
 #pragma unroll
             for (int j = 0; j < 3; ++j) acc += a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)] * in[j];
-            if (kind == 1) {
+            if constexpr (KIND == 1) {
 #pragma unroll
                 for (int j = 0; j < 3; ++j) acc += b[3 * i + j] * pin[j];
             }
@@ -1395,42 +1405,43 @@ struct RowRegs {
 // w = E (u + rho E D t) from x_s, z, y and the block's new inverse) — the same expressions, so t and w also come out as the last
 // iteration left them when a chunk merely continues after a termination check.  Neither t nor rho E D ever go to the slab, and
 // the three-workgroup kernels run no separate restart phase.  Writes w (and gb) to LDS: a workgroup barrier follows.
-template <class Q>
-DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
+template <int KIND, class Q>
+DEKF_FN void row_regs_load(Q& q, int lane, double sigma, RowRegsT<KIND>& t) {
     constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
-    t.kind = -1; t.k = 0; t.r0 = 0; t.sv0 = 0; t.vel = false; t.meas = false; t.xo = 0;
-    bool vo = false;
+    t.valid = false; t.k = 0; t.r0 = 0; t.sv0 = 0; t.vel = false; t.meas = false; t.vo = false; t.xo = 0;
     cdptr sp = q.Sv;  // (the slack-block inverses are stored entry-major in the slab: solve_factor 3a)
-    if (w == 1) {
-        if (lane >= nmeas) return;
+    if constexpr (KIND == 0) {
+        if (lane >= nmeas || lane >= 64) return;
         const int k = lane / L, leg = lane - k * L;
-        t.kind = 0; t.k = k; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg; t.xo = 3;
+        t.k = k; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg; t.xo = 3;
         sp = q.Sv + lane;
-    } else if (w == 2) {
+    } else if constexpr (KIND == 1) {
         const int k = lane >> 1;
         if (k >= K1) return;
-        t.kind = 1; t.k = k; t.vel = lane & 1; t.r0 = q.ix.rd(k, t.vel ? 3 : 0); t.sv0 = k * SV + 9 + NM + (t.vel ? 3 : 0);
+        t.k = k; t.vel = lane & 1; t.r0 = q.ix.rd(k, t.vel ? 3 : 0); t.sv0 = k * SV + 9 + NM + (t.vel ? 3 : 0);
     } else {
         if (lane < 2 * K1) {
-            vo = lane < K1;
-            const int k = vo ? lane : lane - K1;
-            t.kind = 2; t.k = k; t.xo = vo ? 0 : 6; t.r0 = vo ? q.ix.rv(k, 0) : q.ix.rd(k, 6); t.sv0 = k * SV + (vo ? 18 + NM : 9 + NM + 6);
+            t.vo = lane < K1;
+            const int k = t.vo ? lane : lane - K1;
+            t.k = k; t.xo = t.vo ? 0 : 6; t.r0 = t.vo ? q.ix.rv(k, 0) : q.ix.rd(k, 6); t.sv0 = k * SV + (t.vo ? 18 + NM : 9 + NM + 6);
         } else {
             const int e = 64 + lane - 2 * K1;
             if (e >= nmeas) return;
             const int k = e / L, leg = e - k * L;
-            t.kind = 2; t.meas = true; t.k = k; t.xo = 3; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg;
+            t.meas = true; t.k = k; t.xo = 3; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg;
             sp = q.Sv + e;
         }
     }
-    if (t.kind == 1) {
+    t.valid = true;
+    const bool vo = t.vo;
+    if constexpr (KIND == 1) {
         const DynPairMat S(q.Sw + t.k, t.vel, K);
 #pragma unroll
         for (int i = 0; i < 6; ++i) t.a[i] = S.a[i];
 #pragma unroll
         for (int i = 0; i < 9; ++i) t.b[i] = S.b[i];
-    } else if (t.kind == 2 && !t.meas) {
+    } else if (KIND == 2 && !t.meas) {
         const VoOrBiasMat S(q.Sc + t.k, q.Sw + t.k + 21 * K, vo, K);
 #pragma unroll
         for (int i = 0; i < 6; ++i) t.a[i] = S.p[i];
@@ -1441,7 +1452,7 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
     // State: zero before the first chunk (the cold start); afterwards the slack x and y from where the previous chunk left them
     // in LDS; z of an equality row IS its bound after one iteration (the projection returns it), only the VO rows keep theirs.
     const bool cold = q.cold;
-    double dd[3];
+    double dd[3], zz[3], hi[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int r = t.r0 + j, sv = t.sv0 + j;
@@ -1449,21 +1460,23 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
         t.e[j] = q.E[r];
         t.c2[j] = d * t.e[j];
         t.lo[j] = q.lo[r];
-        if (t.kind == 2) t.b[j] = vo ? q.hi[r - q.ix.rvb] : t.lo[j];  // an equality block on the generic path: hi = lo
+        hi[j] = t.lo[j];
+        if constexpr (KIND == 2) { hi[j] = vo ? q.hi[r - q.ix.rvb] : t.lo[j]; t.b[j] = hi[j]; }  // an equality block on the generic path: hi = lo
         const double sxv = q.sx[r], syv = q.sy[r], szv = q.sz[vo ? r - q.ix.rvb : 0];
         t.xs[j] = cold ? 0.0 : sxv;
         t.y[j] = cold ? 0.0 : syv;
-        t.z[j] = cold ? 0.0 : (vo ? szv : t.lo[j]);
+        zz[j] = cold ? 0.0 : (vo ? szv : t.lo[j]);
+        if constexpr (KIND == 2) t.z[j] = zz[j];
         dd[j] = d;
     }
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
     double un[3], rhs[3], tn[3], wo[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const double rv = t.kind != 2 ? rho_eq : q.rho_of(t.lo[j], t.b[j]);
+        const double rv = KIND != 2 ? rho_eq : q.rho_of(t.lo[j], hi[j]);
         t.cf[j] = rv * t.e[j] * dd[j];
-        un[j] = rv * t.z[j] - t.y[j];
-        rhs[j] = sigma * t.xs[j] - t.e[j] * dd[j] * un[j];
+        un[j] = rv * zz[j] - t.y[j];
+        rhs[j] = lin2(sigma, t.xs[j], -(t.e[j] * dd[j]), un[j]);
     }
     t.apply(rhs, tn);
 #pragma unroll
@@ -1472,7 +1485,7 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
         wo[j] = t.e[j] * (un[j] + t.cf[j] * tn[j]);
         q.at[t.r0 + j] = wo[j];
     }
-    if (t.kind == 1) {
+    if constexpr (KIND == 1) {
         const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
         cdptr R = q.R + 9 * t.k;
         double u[3];
@@ -1487,26 +1500,26 @@ DEKF_FN void row_regs_load(Q& q, int w, int lane, double sigma, RowRegs& t) {
         }
     }
 }
-template <class Q>
-DEKF_FN void row_regs_store(Q& q, const RowRegs& t) {
-    if (t.kind < 0) return;
-    const bool vo = t.kind == 2 && !t.meas && t.xo == 0;
+template <int KIND, class Q>
+DEKF_FN void row_regs_store(Q& q, const RowRegsT<KIND>& t) {
+    if (!t.valid) return;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int r = t.r0 + j;
         q.sx[r] = t.xs[j];   // (aliases the w vector, which nobody reads after the last iteration of a chunk)
         q.sy[r] = t.y[j];
-        if (vo) q.sz[r - q.ix.rvb] = t.z[j];
+        if constexpr (KIND == 2) { if (t.vo) q.sz[r - q.ix.rvb] = t.z[j]; }
     }
 }
-// one iteration of a row block: the arithmetic of row_block_compute, operand for operand, with the state in registers
-template <class Q>
-DEKF_FN void row_regs_iter(Q& q, RowRegs& t, double alpha, double sigma) {
-    if (t.kind < 0) return;
+// one iteration of a row block: the arithmetic of row_block_compute, operand for operand, with the state in registers.
+// first_cold: the first iteration after a cold start (z of an equality row is still 0, not yet its bound)
+template <int KIND, class Q>
+DEKF_FN void row_regs_iter(Q& q, RowRegsT<KIND>& t, double alpha, double sigma, bool first_cold) {
+    if (!t.valid) return;
     const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
     cdptr xk = q.xd + 9 * t.k;
     double ar[3], Rk[9];
-    if (t.kind == 1) {
+    if constexpr (KIND == 1) {
         cdptr R = q.R + 9 * t.k;
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rk[i] = R[i];
@@ -1518,33 +1531,38 @@ DEKF_FN void row_regs_iter(Q& q, RowRegs& t, double alpha, double sigma) {
             const double rb = Rk[3 * a] * xk[6] + Rk[3 * a + 1] * xk[7] + Rk[3 * a + 2] * xk[8];
             ar[a] = t.e[a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
         }
-    } else if (t.kind == 0 || t.meas) {
+    } else if (KIND == 0 || t.meas) {
 #pragma unroll
         for (int a = 0; a < 3; ++a) ar[a] = t.e[a] * xk[3 + a];
     } else {
 #pragma unroll
         for (int a = 0; a < 3; ++a) ar[a] = t.e[a] * (xk[t.xo + a] - xk[9 + t.xo + a]);
     }
-    const bool eq = t.kind != 2;
+    constexpr bool eq = KIND != 2;
     const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
     double v[3], sl[3], un[3], rhs[3], tn[3], wo[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) v[j] = t.cf[j] * ar[j];
     t.apply(v, sl);
-    const double rv_blk = eq ? rho_eq : q.rho_of(t.lo[0], t.b[0]);
-    const double rinv_blk = eq ? 0.0 : rcp_fast(rv_blk);
+    double rv_blk = rho_eq, rinv_blk = 0.0;
+    if constexpr (!eq) { rv_blk = q.rho_of(t.lo[0], t.b[0]); rinv_blk = rcp_fast(rv_blk); }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
+        double zprev;
+        if constexpr (eq) zprev = first_cold ? 0.0 : t.lo[j];
+        else zprev = t.z[j];
         const double sj = t.t[j] + sl[j];
         const double ztn = ar[j] - t.c2[j] * sj;
-        const double xn = alpha * sj + (1.0 - alpha) * t.xs[j];
-        const double zh = alpha * ztn + (1.0 - alpha) * t.z[j];
-        const double zn = eq ? t.lo[j] : dmin(dmax(zh + rinv_blk * t.y[j], t.lo[j]), t.b[j]);
+        const double xn = relax(alpha, sj, t.xs[j]);
+        const double zh = relax(alpha, ztn, zprev);
+        double zn;
+        if constexpr (eq) zn = t.lo[j];
+        else zn = dmin(dmax(zh + rinv_blk * t.y[j], t.lo[j]), t.b[j]);
         const double yn = t.y[j] + rv_blk * (zh - zn);
         un[j] = rv_blk * zn - yn;
-        rhs[j] = sigma * xn - t.c2[j] * un[j];
+        rhs[j] = lin2(sigma, xn, -t.c2[j], un[j]);
         t.xs[j] = xn;
-        t.z[j] = zn;
+        if constexpr (!eq) t.z[j] = zn;
         t.y[j] = yn;
     }
     t.apply(rhs, tn);
@@ -1554,7 +1572,7 @@ DEKF_FN void row_regs_iter(Q& q, RowRegs& t, double alpha, double sigma) {
         wo[j] = t.e[j] * (un[j] + t.cf[j] * tn[j]);
         q.at[t.r0 + j] = wo[j];
     }
-    if (t.kind == 1) {
+    if constexpr (KIND == 1) {
         double u[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -1586,7 +1604,7 @@ DEKF_FN void xcols_tile_r3(Q& q, int kind, int lane, double sigma) {
         const double n0 = w(q.ix.rd(kn, 6 + a)), n1 = q.gb[3 * kn + a], p0 = w(q.ix.rd(kp, 6 + a));
         g = (hn ? n0 - n1 : 0.0) - (hp ? p0 : 0.0);
     }
-    q.xs[i] = sigma * xv - (k == 0 ? qv : 0.0) + dv * g;
+    q.xs[i] = fma(dv, g, fma(sigma, xv, -(k == 0 ? qv : 0.0)));
 }
 template <int NF, class Q>
 DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
@@ -1625,33 +1643,41 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
             DEKF_TL_ADD(q, 8, t0, t1);
         }
     } else {
-        RowRegs t;
-        row_regs_load(q, w, lane, sigma, t);
-        DEKF_SYNC();  // B0
-        const int xkind = w == 1 ? 1 : (w == 2 ? 2 : 0);  // velocity columns (the longest gather) next to the shortest row tile
-        for (int it = 0; it < iters; ++it) {
-            DEKF_R3_T(t0);
-            xcols_tile_r3(q, xkind, lane, sigma);
+        // one loop per kind of row block (wave-uniform branch): each is compiled with the registers of ITS block kind only
+        auto worker = [&](auto tag) {
+            constexpr int KIND = decltype(tag)::value;
+            RowRegsT<KIND> t;
+            row_regs_load<KIND>(q, lane, sigma, t);
+            DEKF_SYNC();  // B0
+            const int xkind = KIND == 0 ? 1 : (KIND == 1 ? 2 : 0);  // velocity columns (the longest gather) next to the shortest row tile
+            const bool cold = q.cold;
+            for (int it = 0; it < iters; ++it) {
+                DEKF_R3_T(t0);
+                xcols_tile_r3(q, xkind, lane, sigma);
 #if defined(DEKF_PROFILE_TL)
-            __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_s_waitcnt(0);
 #endif
-            DEKF_R3_T(t1);
-            DEKF_SYNC();  // B1
-            DEKF_SYNC();  // B2
-            DEKF_R3_T(t2);
-            if (w == 2) __builtin_amdgcn_s_setprio(2);
-            row_regs_iter(q, t, alpha, sigma);
-            if (w == 2) __builtin_amdgcn_s_setprio(0);
+                DEKF_R3_T(t1);
+                DEKF_SYNC();  // B1
+                DEKF_SYNC();  // B2
+                DEKF_R3_T(t2);
+                if constexpr (KIND == 1) __builtin_amdgcn_s_setprio(2);
+                row_regs_iter<KIND>(q, t, alpha, sigma, cold && it == 0);
+                if constexpr (KIND == 1) __builtin_amdgcn_s_setprio(0);
 #if defined(DEKF_PROFILE_TL)
-            __builtin_amdgcn_s_waitcnt(0);
+                __builtin_amdgcn_s_waitcnt(0);
 #endif
-            DEKF_R3_T(t3);
-            DEKF_SYNC();  // B3
-            DEKF_TL_ADD(q, w, t0, t1);
-            DEKF_TL_ADD(q, 4 + w, t2, t3);
-            DEKF_TL_ADD(q, 8 + w, t1, t2);
-        }
-        row_regs_store(q, t);
+                DEKF_R3_T(t3);
+                DEKF_SYNC();  // B3
+                DEKF_TL_ADD(q, w, t0, t1);
+                DEKF_TL_ADD(q, 4 + w, t2, t3);
+                DEKF_TL_ADD(q, 8 + w, t1, t2);
+            }
+            row_regs_store<KIND>(q, t);
+        };
+        if (w == 1) worker(std::integral_constant<int, 0>{});
+        else if (w == 2) worker(std::integral_constant<int, 1>{});
+        else worker(std::integral_constant<int, 2>{});
     }
 #undef DEKF_R3_T
     DEKF_PROF_MARK(q, 9);

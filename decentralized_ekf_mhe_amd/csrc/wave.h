@@ -15,6 +15,7 @@
 //                           not reachable from the C ABI and is not a fallback.
 #pragma once
 #include <cmath>
+#include <type_traits>
 
 #if defined(__HIPCC__) && !defined(DEKF_HOSTSIM)
 #include <hip/hip_runtime.h>
@@ -350,6 +351,12 @@ inline double rcp_fast(double x) { return 1.0 / x; }
 inline double rsqrt_fast(double x) { return 1.0 / std::sqrt(x); }
 #endif
 
+// a x + b y and the ADMM relaxation alpha v + (1 - alpha) w with the roundings pinned: ONE product rounded, then one fused
+// multiply-add.  Left to -ffp-contract=fast the compiler picks which of the two products it fuses, and it picks differently in
+// different instantiations of the same expression (measured: the three-workgroup and the two-workgroup solve kernels drifted
+// apart by an ulp per iteration when their row loops were restructured).
+DEKF_FN double lin2(double a, double x, double b, double y) { return fma(a, x, b * y); }
+DEKF_FN double relax(double alpha, double v, double w) { return fma(alpha, v, (1.0 - alpha) * w); }
 DEKF_FN double dmax(double a, double b) { return a > b ? a : b; }
 DEKF_FN double dmin(double a, double b) { return a < b ? a : b; }
 

@@ -306,10 +306,14 @@ def test_rccl_allgather_two_ranks_equals_single_rank_results(tmp_path):
 
 
 @pytest.mark.parametrize("maker", [go1_params, cassie_params], ids=["go1", "cassie"])
-def test_three_workgroup_kernel_is_bit_identical_to_the_two_workgroup_kernel(maker):
-    """Full windows of the fixed-horizon shapes run k_mhe_solve_r3_* (three workgroups per CU, row state in registers);
-    dekf_params.solve_workgroups_per_cu = 2 keeps the two-workgroup kernel for every tick.  Same operations in the same order: the states, the
-    residuals and the iteration counts must agree to the last bit, at a batch that uses all 768 slots unevenly."""
+def test_three_workgroup_kernel_agrees_with_the_two_workgroup_kernel(maker):
+    """Full windows of the fixed-horizon shapes run k_mhe_solve_r3_* (three workgroups per CU, row state in registers, one
+    specialised row loop per wavefront); dekf_params.solve_workgroups_per_cu = 2 keeps the two-workgroup kernel for every tick.
+    Same operations on the same operands — but not the same bits: under -ffp-contract=fast the compiler chooses which product
+    of an a b + c d it fuses, and it chooses differently in the two code shapes (the roundings of the relaxations and slack
+    right-hand sides are pinned with explicit fma, wave.h: relax / lin2; the rest is an ulp per iteration).  What must hold: the
+    same iteration counts and refactorisations in every solve, states and residual levels equal far inside the tolerance, at a
+    batch that uses all 768 slots unevenly."""
     p = maker()
     p.ekf_rate = p.rate
     B, K = 1000, p.N + 12
@@ -333,18 +337,19 @@ def test_three_workgroup_kernel_is_bit_identical_to_the_two_workgroup_kernel(mak
     wg2, o2, i2 = run(2)
     assert wg3 > wg2, (wg3, wg2)  # the three-workgroup kernel really was selected (more resident workgroups)
     assert (o3["status"] == 1).all() and (o2["status"] == 1).all()
-    for key in ("x", "v_b", "quat"):
-        assert np.array_equal(o3[key], o2[key]), key
-    assert np.array_equal(i3["iters"], i2["iters"])
-    assert np.array_equal(i3["pri_res"], i2["pri_res"]) and np.array_equal(i3["dua_res"], i2["dua_res"])
+    assert np.array_equal(o3["quat"], o2["quat"])                      # (the EKF does not depend on the solve kernel)
+    for key in ("x", "v_b"):
+        assert np.abs(o3[key] - o2[key]).max() <= 1e-11, key           # 1e-13 measured: 1e-7 of the tolerance
+    assert np.array_equal(i3["iters"], i2["iters"]) and np.array_equal(i3["rho_updates"], i2["rho_updates"])
+    # residual levels against eps = 1e-6: measured differences 6e-15 (primal) and 1e-8 (dual: an ulp of x times weights of 1e9)
+    assert np.abs(i3["pri_res"] - i2["pri_res"]).max() <= 1e-11 and np.abs(i3["dua_res"] - i2["dua_res"]).max() <= 1e-7
 
 
 def test_three_workgroup_kernel_with_vo_rows_and_two_rho_updates():
     """Past tick 40 the VO rows of the window are equalities with weights of 4.4e9 and many solves refactorise twice (100
-    iterations).  There the two kernels are no longer bit-identical (tools/r3_identity_check.py: the first difference is at the
-    first such tick, 8e-11 in the states — rounding differences, amplified by the VO weights into 40 % of the tiny final dual
-    residual); what must hold is what the oracle tests ask of either of them: same iteration counts, states equal far inside
-    the tolerance."""
+    iterations): the kernels' rounding differences are amplified there (1e-8 in the states, tens of percent of the tiny final
+    dual residual: tools/r3_identity_check.py).  What must hold is what the oracle tests ask of either of them: same iteration
+    counts, states equal far inside the tolerance."""
     p = go1_params()
     p.ekf_rate = p.rate
     B, K = 1000, p.N + 30
@@ -363,7 +368,7 @@ def test_three_workgroup_kernel_with_vo_rows_and_two_rho_updates():
     assert (o3["status"] == 1).all() and (o2["status"] == 1).all()
     assert i3["rho_updates"].max() >= 2 and i3["iters"].max() >= 100
     assert np.array_equal(i3["iters"], i2["iters"]) and np.array_equal(i3["rho_updates"], i2["rho_updates"])
-    assert np.abs(o3["x"] - o2["x"]).max() <= 1e-9 and np.abs(o3["v_b"] - o2["v_b"]).max() <= 1e-9
+    assert np.abs(o3["x"] - o2["x"]).max() <= 1e-7 and np.abs(o3["v_b"] - o2["v_b"]).max() <= 1e-7  # 1e-8 measured; tolerance floor 1e-6
 
 
 def test_pipelined_steps_are_bit_identical_to_in_order_steps():
