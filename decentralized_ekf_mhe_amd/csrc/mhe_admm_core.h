@@ -1824,6 +1824,9 @@ DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
     const int ntf = FT ? (K1 * L + 63) >> 6 : 0, ntxf = FT ? (NM * K + 63) >> 6 : 0;
     cdptr qsl = q.tmp + TmpMap<NS>::QSL;
     auto wy = [&](int r) { return E[r] * YR(r); };
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RESID2) && DEKF_DEVICE_BUILD  // per-wavefront: tile phase (slots 24..27), its share of the wait + reduction (28..31)
+    const long long trs0 = clock64();
+#endif
     wtiles(ntm + ntp + 2 * ntd + 3 * ntx + ntf + ntxf, [&](int tile, int lane) {
         if (tile < ntm) {  // Meas leg blocks
             const int e = tile * 64 + lane;
@@ -1955,9 +1958,27 @@ DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
         }
     });
     DEKF_PROF_MARK(q, 21);
-#pragma unroll
-    for (int r = 0; r < 14; ++r) acc[r] = wave_max(acc[r]);
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RESID2) && DEKF_DEVICE_BUILD
+    __builtin_amdgcn_s_waitcnt(0);
+    const long long trs1 = clock64();
+#endif
+    wave_max_n<14>(acc);
     group_combine<14, false>(acc);
+#ifdef DEKF_X_DOUBLE_RED  // experiment: what does the reduction cost?  (idempotent: a second pass leaves the maxima as they are)
+    for (int rep_ = 0; rep_ < DEKF_X_DOUBLE_RED; ++rep_) {
+#pragma unroll
+        for (int r = 0; r < 14; ++r) asm volatile("" : "+v"(acc[r]));
+        wave_max_n<14>(acc);
+        group_combine<14, false>(acc);
+    }
+#endif
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RESID2) && DEKF_DEVICE_BUILD
+    {
+        const long long trs2 = clock64();
+        const int w_ = DEKF_LANE() >> 6;
+        if ((DEKF_LANE() & 63) == 0) { q.prof[24 + w_] += (double)(trs1 - trs0); q.prof[28 + w_] += (double)(trs2 - trs1); }
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < 6; ++r) ra[r] = acc[r];
 #pragma unroll

@@ -117,15 +117,43 @@ DEKF_FN void wfor(int n, F f) {
     for (int i = DEKF_LANE(); i < n; i += st) f(i);
     DEKF_SYNC();
 }
+// broadcast lane `lane`'s value of a double to the whole wavefront (two v_readlane_b32 into an SGPR pair)
+DEKF_FN double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+// Wave-wide maximum, every lane gets it.  DPP all the way (row_shr 1, 2, 4, 8 inside the 16-lane rows, row_bcast 15 / 31 across
+// them, then lane 63 read back): 20 instructions per value.  The __shfl_xor butterfly costs ~20 instructions PER STEP and value
+// (lane-index arithmetic around two ds_bpermute): 14 maxima took 13.7 k cycles per residual check, 4.5 % of a solve (measured by
+// repeating the reduction).  A maximum does not depend on the order, so the result is bit-identical.
+template <int CTRL, int ROW_MASK>
+DEKF_FN double dpp_max_step(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xF, false);  // lanes without a source keep their own value
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xF, false);
+    return fmax(v, __hiloint2double(hi, lo));
+}
 DEKF_FN double wave_max(double v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, WAVE));
-    return v;
+    v = dpp_max_step<0x111, 0xF>(v);  // row_shr:1
+    v = dpp_max_step<0x112, 0xF>(v);  // row_shr:2
+    v = dpp_max_step<0x114, 0xF>(v);  // row_shr:4
+    v = dpp_max_step<0x118, 0xF>(v);  // row_shr:8   -> lane 15 of every row holds the row's maximum
+    v = dpp_max_step<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_max_step<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
+    return readlane_f64(v, 63);
 }
 DEKF_FN double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
     return v;
+}
+// NR maxima at once, all lanes get the results
+template <int NR>
+DEKF_FN void wave_max_n(double* v) {
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = wave_max(v[r]);  // (independent DPP chains: the scheduler interleaves them)
 }
 // combine NR per-wave partials across the group's wavefronts; every lane gets the result
 template <int NR, bool SUM>
@@ -169,8 +197,7 @@ DEKF_FN void wred_maxn(int n, double* out, F f) {
     for (int r = 0; r < NR; ++r) acc[r] = 0.0;
     const int st = DEKF_NLANES();
     for (int i = DEKF_LANE(); i < n; i += st) f(i, acc);
-#pragma unroll
-    for (int r = 0; r < NR; ++r) acc[r] = wave_max(acc[r]);
+    wave_max_n<NR>(acc);
     group_combine<NR, false>(acc);
 #pragma unroll
     for (int r = 0; r < NR; ++r) out[r] = acc[r];
@@ -234,6 +261,8 @@ inline void wred_maxn(int n, double* out, F f) {
     for (int r = 0; r < NR; ++r) out[r] = acc[r];
 }
 inline double wave_max(double v) { return v; }   // one sequential "lane" has seen every item already
+template <int NR>
+inline void wave_max_n(double*) {}
 inline double wave_sum(double v) { return v; }
 template <int NR, bool SUM>
 inline void group_combine(double*) {}
@@ -296,15 +325,6 @@ inline void two_waves(F0 f0, F1 f1) {
 // (tile t by wavefront t mod #wavefronts), so a branch on the tile index is wave-uniform (scalar) and
 // every wavefront runs ONE straight-line body per tile.  f(tile, lane) with lane = 0..63 is called
 // for all 64 lanes of the wavefront (cross-lane reads inside f are legal).  No trailing sync.
-#if DEKF_DEVICE_BUILD
-// broadcast lane `lane`'s value of a double to the whole wavefront (two v_readlane_b32 into an SGPR pair)
-DEKF_FN double readlane_f64(double v, int lane) {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_readlane(lo, lane);
-    hi = __builtin_amdgcn_readlane(hi, lane);
-    return __hiloint2double(hi, lo);
-}
-#endif
 DEKF_FN int wave_count() { return DEKF_NLANES() > WAVE ? DEKF_NLANES() >> 6 : 1; }
 #if DEKF_DEVICE_BUILD
 // exchange a double with the partner lane of an adjacent lane pair (DPP quad_perm [1, 0, 3, 2]): no LDS, no barrier
