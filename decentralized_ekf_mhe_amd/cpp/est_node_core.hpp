@@ -133,13 +133,8 @@ class EstNodeCore {
         robot_store_ = std::make_shared<robot_store>();
         robot_params_ = std::make_shared<robot_params>();
         paramsWrapper(node, *robot_params_, log_name_, timer_interval_ms_);
-        // The DECLARED default of osqp.polish is true (EstSub.cpp:188) while the Go1 parameter file sets it false
-        // (parameters_go1.yaml:44).  The GPU solve has no polish step, so a node started without a parameter file
-        // is refused here, at construction, with the remedy — not on the first eligible timer tick.
-        if (robot_params_->est_type_ == 0 && robot_params_->polish_)
-            throw std::invalid_argument(
-                "est_sub: osqp.polish = true (the declared default) is not implemented by the MI355X solve; "
-                "set osqp.polish: false as go1_example/config/parameters_go1.yaml does");
+        // (The DECLARED default of osqp.polish is true, EstSub.cpp:188, while the Go1 parameter file sets it false,
+        // parameters_go1.yaml:44: both run — the solve kernels polish when asked to, mhe_solve_core.h.)
         const char* home = std::getenv("HOME");
         log_dir_ = std::string(home ? home : ".") + "/log_exp/";  // data_logger.hpp:53-57 of the reference
         x_logged_ = &mhe.x_MHE_;

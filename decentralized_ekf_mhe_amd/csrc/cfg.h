@@ -50,6 +50,8 @@ struct DevCfg {
     double rho0, sigma, alpha, eps_abs, eps_rel;
     int max_iter, scaling, check_termination, adaptive_rho, adaptive_rho_interval;
     double adaptive_rho_tolerance;
+    int polish, polish_refine_iter;  // osqp.polish (DecentralEst.cpp:207), OSQP's polish_refine_iter (default 3)
+    double delta;                    // osqp.delta (DecentralEst.cpp:211)
     // EKF (orien_ekf.cpp:13-31)
     double ekf_dt, ekf_Cgyro[3], ekf_Caccel[3], ekf_Cvo[4], ekf_P0[4], ekf_q0[4];
     int ekf_hist;
@@ -162,6 +164,7 @@ struct DevState {
     // outputs
     double *x_mhe, *v_b;
     int *status, *iters, *rho_updates;
+    int* polish_status;  // 0 polishing off / not reached, 1 polished point accepted, -1 rejected (OSQP's status_polish)
     double *pri_res, *dua_res;
     double* prof;  // [B][DEKF_PROF_SLOTS] section cycles, written by the diagnostic (-DDEKF_PROFILE) build only
 };

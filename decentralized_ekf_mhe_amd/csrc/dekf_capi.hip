@@ -21,23 +21,22 @@ extern "C" {
 __global__ void k_ekf_tick(DevCfg c, DevState s, int count);
 __global__ void k_mhe_initialize(DevCfg c, DevState s);
 __global__ void k_mhe_assemble(DevCfg c, DevState s, int T, int pushes);
-#define DEKF_DECL_SOLVE(LEGS)                                                                        \
-    __global__ void k_mhe_solve_ll_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);     \
-    __global__ void k_mhe_solve_lg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);     \
-    __global__ void k_mhe_solve_gg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);
-__global__ void k_mhe_solve_ll_4_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
-__global__ void k_mhe_solve_lg_2_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
+// every solve kernel and its twin with OSQP's polishing step (kernels.hip: DEKF_SOLVE_KERNEL_BODY)
+#define DEKF_DECL_K(NAME)                                                              \
+    __global__ void NAME(DevCfg c, DevState s, int kstart, int K, int gws_len);        \
+    __global__ void NAME##_pol(DevCfg c, DevState s, int kstart, int K, int gws_len);
+#define DEKF_DECL_SOLVE(LEGS) DEKF_DECL_K(k_mhe_solve_ll_##LEGS) DEKF_DECL_K(k_mhe_solve_lg_##LEGS) DEKF_DECL_K(k_mhe_solve_gg_##LEGS)
+DEKF_DECL_K(k_mhe_solve_ll_4_n20)
+DEKF_DECL_K(k_mhe_solve_lg_2_n20)
 #ifndef DEKF_NO_R3
-__global__ void k_mhe_solve_r3_4_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
-__global__ void k_mhe_solve_r3_2_n20(DevCfg c, DevState s, int kstart, int K, int gws_len);
+DEKF_DECL_K(k_mhe_solve_r3_4_n20)
+DEKF_DECL_K(k_mhe_solve_r3_2_n20)
 #endif
 DEKF_DECL_SOLVE(1)
 DEKF_DECL_SOLVE(2)
 DEKF_DECL_SOLVE(3)
 DEKF_DECL_SOLVE(4)
-#define DEKF_DECL_SOLVE_FOOT(LEGS)                                                                        \
-    __global__ void k_mhe_solve_foot_lg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);     \
-    __global__ void k_mhe_solve_foot_gg_##LEGS(DevCfg c, DevState s, int kstart, int K, int gws_len);
+#define DEKF_DECL_SOLVE_FOOT(LEGS) DEKF_DECL_K(k_mhe_solve_foot_lg_##LEGS) DEKF_DECL_K(k_mhe_solve_foot_gg_##LEGS)
 DEKF_DECL_SOLVE_FOOT(1)
 DEKF_DECL_SOLVE_FOOT(2)
 DEKF_DECL_SOLVE_FOOT(3)
@@ -210,6 +209,9 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     if (device < 0 || device >= ndev) return fail(DEKF_ERR_INVALID, "device ordinal out of range");
     DevCfg c;
     if (const char* msg = fill_cfg(*p, batch, c)) return fail(DEKF_ERR_INVALID, msg);
+#ifdef DEKF_NO_POLISH_KERNELS
+    if (c.polish && c.est_type == 0) return fail(DEKF_ERR_INVALID, "this diagnostic build (-DDEKF_NO_POLISH_KERNELS) carries no polishing kernels");
+#endif
     HIPCHK(hipSetDevice(device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, device));
@@ -239,8 +241,8 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
 #endif
     typedef void (*SolveFn)(DevCfg, DevState, int, int, int);
     {
-        struct Named { SolveFn fn; const char* name; };
-#define DEKF_K(sym) {sym, #sym}
+        struct Named { SolveFn fn; const char* name; SolveFn fn_pol; const char* name_pol; };
+#define DEKF_K(sym) {sym, #sym, sym##_pol, #sym "_pol"}
         static const Named table[4][3] = {
             {DEKF_K(k_mhe_solve_ll_1), DEKF_K(k_mhe_solve_lg_1), DEKF_K(k_mhe_solve_gg_1)}, {DEKF_K(k_mhe_solve_ll_2), DEKF_K(k_mhe_solve_lg_2), DEKF_K(k_mhe_solve_gg_2)},
             {DEKF_K(k_mhe_solve_ll_3), DEKF_K(k_mhe_solve_lg_3), DEKF_K(k_mhe_solve_gg_3)}, {DEKF_K(k_mhe_solve_ll_4), DEKF_K(k_mhe_solve_lg_4), DEKF_K(k_mhe_solve_gg_4)}};
@@ -252,13 +254,18 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
                                              {DEKF_K(k_mhe_solve_foot_lg_3), DEKF_K(k_mhe_solve_foot_gg_3)}, {DEKF_K(k_mhe_solve_foot_lg_4), DEKF_K(k_mhe_solve_foot_gg_4)}};
             pick = foot[c.L - 1][lay.factor_in_lds() ? 0 : 1];
         }
-        h->solve_kernel = pick.fn;
-        h->solve_name = pick.name;
+        // osqp.polish: the twin that carries the polishing step
+        h->solve_kernel = c.polish ? pick.fn_pol : pick.fn;
+        h->solve_name = c.polish ? pick.name_pol : pick.name;
 #ifdef DEKF_PROFILE
         // diagnostic build only: DEKF_DEBUG_PLACEMENT=1|2 forces the _lg / _gg placement (2 also shrinks the LDS request)
         if (const char* pl = getenv("DEKF_DEBUG_PLACEMENT")) {
             int p = atoi(pl);
-            if ((p == 1 || p == 2) && !c.ft) { h->solve_kernel = table[c.L - 1][p].fn; h->solve_name = table[c.L - 1][p].name; }
+            if ((p == 1 || p == 2) && !c.ft) {
+                const Named& t = table[c.L - 1][p];
+                h->solve_kernel = c.polish ? t.fn_pol : t.fn;
+                h->solve_name = c.polish ? t.name_pol : t.name;
+            }
             // the _gg kernels carve D, E, bounds and R behind the iterates when SolveLayout::gg_consts_in_lds() says so
             if (p == 2) h->lds_solve = (size_t)(lay.vec + (lay.gg_consts_in_lds() ? lay.gg_consts() : 0)) * sizeof(double);
         }
@@ -281,7 +288,8 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     h->solve_grid = (int)(slots < batch ? slots : batch);
 #ifndef DEKF_NO_R3
     if (!c.ft && c.N == 20 && (c.L == 4 || c.L == 2) && (cap == 0 || cap > per_cu)) {
-        const SolveFn full = c.L == 4 ? k_mhe_solve_r3_4_n20 : k_mhe_solve_r3_2_n20;
+        const SolveFn full = c.polish ? (c.L == 4 ? k_mhe_solve_r3_4_n20_pol : k_mhe_solve_r3_2_n20_pol) : (c.L == 4 ? k_mhe_solve_r3_4_n20 : k_mhe_solve_r3_2_n20);
+        const char* const full_name = c.polish ? (c.L == 4 ? "k_mhe_solve_r3_4_n20_pol" : "k_mhe_solve_r3_2_n20_pol") : (c.L == 4 ? "k_mhe_solve_r3_4_n20" : "k_mhe_solve_r3_2_n20");
         // the kernel's static LDS (reduction scratch of wave.h) counts against the same allocation as the dynamic part
         hipFuncAttributes fa;
         size_t static_lds = 512;
@@ -302,12 +310,12 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
                 const long g = (long)atoi(e) * prop.multiProcessorCount;
                 h->solve_grid_full = (int)(g < batch ? g : batch);
                 h->solve_kernel_full = full;
-                h->solve_name_full = "k_mhe_solve_r3_4_n20";
+                h->solve_name_full = full_name;
             } else
 #endif
             if (pcf > per_cu && h->solve_grid_full > h->solve_grid) {
                 h->solve_kernel_full = full;
-                h->solve_name_full = c.L == 4 ? "k_mhe_solve_r3_4_n20" : "k_mhe_solve_r3_2_n20";
+                h->solve_name_full = full_name;
             }
         }
     }
@@ -608,6 +616,15 @@ dekf_status dekf_get_solver_info(dekf_handle h, int* iters, int* rho_updates, do
     if ((st = fetch(h, rho_updates, s.rho_updates, B * 4, where))) return st;
     if ((st = fetch(h, pri_res, s.pri_res, B * 8, where))) return st;
     if ((st = fetch(h, dua_res, s.dua_res, B * 8, where))) return st;
+    if (where == DEKF_HOST) HIPCHK(hipStreamSynchronize(h->stream));
+    return DEKF_OK;
+}
+
+dekf_status dekf_get_polish_status(dekf_handle h, int* polish_status, dekf_mem where) {
+    if (!h || !polish_status) return fail(DEKF_ERR_INVALID, "null argument");
+    dekf_status st;
+    if ((st = await_results(h))) return st;
+    if ((st = fetch(h, polish_status, h->sp[h->last_par].polish_status, (size_t)h->c.B * 4, where))) return st;
     if (where == DEKF_HOST) HIPCHK(hipStreamSynchronize(h->stream));
     return DEKF_OK;
 }

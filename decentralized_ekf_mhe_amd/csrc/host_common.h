@@ -42,6 +42,7 @@ inline void default_params(dekf_params* p) {
     set3(p->ekf_gravity_meas_std, 4.0, 4.0, 4.0);
     p->ekf_quaternion_init[0] = 1.0;
     p->ekf_rate = 500; p->ekf_history = 64;
+    p->polish_refine_iter = 3;
     p->arrival_cost_form = 0; p->solve_pipeline = 0; p->solve_workgroups_per_cu = 0;
 }
 
@@ -55,7 +56,9 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     if (p.N < 2 || p.N > 128) return "N out of range [2,128]";
     if (p.rate < 1 || p.ekf_rate < 1) return "rate must be positive";
     if (p.ekf_history < 4) return "ekf_history must be >= 4";
-    if (p.polish) return "osqp.polish = true is not implemented";
+    if (p.polish != 0 && p.polish != 1) return "osqp.polish must be 0 or 1";
+    if (p.polish && !(p.delta > 0)) return "osqp.delta must be positive when osqp.polish is on";
+    if (p.polish_refine_iter < 0 || p.polish_refine_iter > 100) return "polish_refine_iter out of range [0,100]";
     if (p.arrival_cost_form != 0 && p.arrival_cost_form != 1) return "arrival_cost_form must be 0 (reference form) or 1 (information form)";
     if (p.solve_pipeline != 0 && p.solve_pipeline != 1) return "solve_pipeline must be 0 (in order) or 1 (consecutive steps overlap)";
     if (p.solve_workgroups_per_cu < 0 || p.solve_workgroups_per_cu > 8) return "solve_workgroups_per_cu out of range [0,8]";
@@ -102,6 +105,7 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     c.max_iter = p.max_qp_iter; c.scaling = p.scaling_iters; c.check_termination = p.check_termination;
     c.adaptive_rho = p.adapt_rho; c.adaptive_rho_interval = p.adaptive_rho_interval;
     c.adaptive_rho_tolerance = p.adaptive_rho_tolerance;
+    c.polish = p.polish; c.polish_refine_iter = p.polish_refine_iter; c.delta = p.delta;
     c.ekf_dt = 1.0 / (double)p.ekf_rate;
     for (int i = 0; i < 4; ++i) {
         c.ekf_Cvo[i] = sq(p.ekf_vo_meas_std[i]);
@@ -138,7 +142,7 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
     s.gws = D(cp * solve_slots * g.total);
     s.kf_x = D(ns * B); s.kf_C = D(ns * ns * B);
     s.x_mhe = D(cp * ns * B); s.v_b = D(cp * 3 * B);
-    s.status = I(cp * B); s.iters = I(cp * B); s.rho_updates = I(cp * B);
+    s.status = I(cp * B); s.iters = I(cp * B); s.rho_updates = I(cp * B); s.polish_status = I(cp * B);
     s.pri_res = D(cp * B); s.dua_res = D(cp * B);
     s.prof = D(cp * DEKF_PROF_SLOTS * B);
 }
@@ -150,7 +154,7 @@ inline DevState second_set(const DevCfg& c, const DevState& s, int solve_slots) 
     t.snap += (size_t)c.snap_len * B;
     t.gws += (size_t)solve_slots * g.total;
     t.x_mhe += ns * B; t.v_b += 3 * B;
-    t.status += B; t.iters += B; t.rho_updates += B;
+    t.status += B; t.iters += B; t.rho_updates += B; t.polish_status += B;
     t.pri_res += B; t.dua_res += B;
     t.prof += DEKF_PROF_SLOTS * B;
     return t;

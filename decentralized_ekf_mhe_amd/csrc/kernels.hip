@@ -74,13 +74,27 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
 #define DEKF_KSET 0x3FF
 #endif
 #endif
-#define DEKF_STUB_KERNEL(NAME) __global__ void NAME(DevCfg, DevState, int, int, int) {}
-#define DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, ...)                                                                             \
+// Every solve kernel exists twice: NAME, and NAME_pol with OSQP's polishing step behind the iterations (osqp.polish true; chosen
+// by dekf_create).  Two instantiations rather than a run-time branch: compiled into k_mhe_solve_r3_4_n20 the polishing code (a
+// second call site of the factorisation and of the iteration chunk) took its spilled VGPRs from 60 to 147.
+#define DEKF_STUB_KERNEL(NAME)                                  \
+    __global__ void NAME(DevCfg, DevState, int, int, int) {}     \
+    __global__ void NAME##_pol(DevCfg, DevState, int, int, int) {}
+#define DEKF_SOLVE_KERNEL_BODY_(NAME, WAVES, POLISH, ...)                                                                    \
     __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, WAVES) NAME(DevCfg c, DevState s, int kstart, int K, int gws_len) { \
         extern __shared__ double lds[];                                                                                      \
         double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                                                  \
-        for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window<__VA_ARGS__>(c, s, b, kstart, K, lds, gws);            \
+        for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window_t<POLISH, __VA_ARGS__>(c, s, b, kstart, K, lds, gws);  \
     }
+#ifdef DEKF_NO_POLISH_KERNELS  // (A/B and diagnostic builds: half the compile time; osqp.polish true is then refused by the stubs' owner, dekf_create)
+#define DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, ...)            \
+    DEKF_SOLVE_KERNEL_BODY_(NAME, WAVES, false, __VA_ARGS__) \
+    __global__ void NAME##_pol(DevCfg, DevState, int, int, int) {}
+#else
+#define DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, ...)            \
+    DEKF_SOLVE_KERNEL_BODY_(NAME, WAVES, false, __VA_ARGS__) \
+    DEKF_SOLVE_KERNEL_BODY_(NAME##_pol, WAVES, true, __VA_ARGS__)
+#endif
 #define DEKF_SOLVE_KERNEL_IF(BIT, NAME, WAVES, ...) DEKF_SOLVE_KERNEL_IF_(BIT, NAME, WAVES, __VA_ARGS__)
 #define DEKF_SOLVE_KERNEL_IF_(BIT, NAME, WAVES, ...) DEKF_SOLVE_KERNEL_SEL_##BIT(NAME, WAVES, __VA_ARGS__)
 // one selector per bit (the preprocessor cannot branch on an expression inside a macro body)
@@ -230,6 +244,7 @@ __global__ void k_reset_state(DevCfg c, DevState s) {
     s.status[b] = DEKF_SOLVE_NONE;
     s.iters[b] = 0;
     s.rho_updates[b] = 0;
+    s.polish_status[b] = 0;
     s.pri_res[b] = 0.0;
     s.dua_res[b] = 0.0;
     s.vo_ins_idx[b] = 0;

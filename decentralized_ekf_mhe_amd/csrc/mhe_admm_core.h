@@ -1465,7 +1465,9 @@ DEKF_FN void row_regs_load(Q& q, int lane, double sigma, RowRegsT<KIND>& t) {
         const double sxv = q.sx[r], syv = q.sy[r], szv = q.sz[vo ? r - q.ix.rvb : 0];
         t.xs[j] = cold ? 0.0 : sxv;
         t.y[j] = cold ? 0.0 : syv;
-        zz[j] = cold ? 0.0 : (vo ? szv : t.lo[j]);
+        // (polishing restarts with z ON the bound of every equality row; a VO row without bounds starts at 0 like everything else)
+        const bool z_on_bound = q.polishing() && !(KIND == 2 && q.rho_of(t.lo[j], hi[j]) == RHO_MIN);
+        zz[j] = cold ? (z_on_bound ? t.lo[j] : 0.0) : (vo ? szv : t.lo[j]);
         if constexpr (KIND == 2) t.z[j] = zz[j];
         dd[j] = d;
     }
@@ -1662,7 +1664,7 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
                 DEKF_SYNC();  // B2
                 DEKF_R3_T(t2);
                 if constexpr (KIND == 1) __builtin_amdgcn_s_setprio(2);
-                row_regs_iter<KIND>(q, t, alpha, sigma, cold && it == 0);
+                row_regs_iter<KIND>(q, t, alpha, sigma, cold && it == 0 && !q.polishing());
                 if constexpr (KIND == 1) __builtin_amdgcn_s_setprio(0);
 #if defined(DEKF_PROFILE_TL)
                 __builtin_amdgcn_s_waitcnt(0);

@@ -165,8 +165,10 @@ DEKF_FN double mul_rounded(double a, double b) {
     return p;
 }
 
-template <int L, int NF = 0, bool FLDS = true, int FT = 0, bool R3_ = false>
+template <int L, int NF = 0, bool FLDS = true, int FT = 0, bool R3_ = false, bool POLISH_ = false>
 struct SolveCtx {
+    static constexpr bool POLISH = POLISH_;  // the kernel carries OSQP's polishing step (its own instantiations, k_mhe_solve_*_pol:
+                                             // the code behind it costs the others 87 spilled VGPRs when it is merely compiled in)
     static constexpr bool R3 = R3_;  // three workgroups per CU: row state in registers, x blocks compact in LDS (xb)
     static constexpr int LEGS = L;
     static constexpr int NFIXED = NF;  // != 0: horizon known at compile time (sweeps fully unrolled when K == NF)
@@ -194,6 +196,11 @@ struct SolveCtx {
     cdptr vo;  // [wcap][4] VO flag + bound per ring slot, from the solve's input snapshot
     double cc;   // cost scaling c
     double rho;  // current scalar rho
+    double sigma_pol;  // POLISH: the regularisation of the x block while polishing (delta)
+    bool zlo;          // POLISH, while polishing: the cold start puts z on the bound of every equality row (x = y = 0 as usual)
+    // the regularisation of the x block in the linear system: settings sigma; delta while polishing
+    DEKF_FN double sigma() const { if constexpr (POLISH) return zlo ? sigma_pol : c.sigma; else return c.sigma; }
+    DEKF_FN bool polishing() const { if constexpr (POLISH) return zlo; else return false; }
     dptr Pst;  // unscaled P blocks staged by solve_scale (aliases Sinv | Wk until the first factorisation)
     bool staged;  // Pst valid
     dptr prof;         // diagnostic build only
@@ -842,7 +849,7 @@ DEKF_FN bool solve_factor(Q& q) {
     constexpr int L = Q::LEGS, FT = Q::FOOT, NS = Q::NS, NS2 = Q::NS2;
     const int K = q.K;
     const auto& ix = q.ix;
-    const double sigma = c.sigma, cc = q.cc;
+    const double sigma = q.sigma(), cc = q.cc;
     // 3a. slack blocks: one lane per block, P blocks from the staged copy (Sinv | Wk are dead here:
     //     the previous factor is being replaced)
     constexpr int PS = 6 * L + 27 + 6 * L * FT, NB = L + 2 + L * FT;  // blocks per step: Meas legs, Dyn p+v+bias, VO, [foot Dyn]
@@ -1385,13 +1392,14 @@ DEKF_FN bool solve_factor(Q& q) {
 struct SolveInfo {
     int iters, status, rho_updates;
     double pri_res, dua_res, rho;
+    int polished = 0;  // 0 polishing off or not reached, 1 the polished point was accepted, -1 rejected (the ADMM iterate stays)
 };
 
 // osqp_setup + osqp_solve + extraction.  window = steps kstart .. kstart+K-1 (newest = T).
 // FACTOR_LDS / PA_LDS are compile-time so that every pointer has a provable address space
 // (ds_read/ds_write instead of flat_load) — see SolveLayout::factor_in_lds / pa_in_lds.
-template <int L, bool FACTOR_LDS, bool PA_LDS, int NFIX = 0, int FT = 0, bool R3 = false>
-DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, dptr lds, dptr gws) {
+template <bool POLISH, int L, bool FACTOR_LDS, bool PA_LDS, int NFIX = 0, int FT = 0, bool R3 = false>
+DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int kstart, int K, dptr lds, dptr gws) {
     // NFIX != 0: the horizon is a compile-time constant, so every LDS array sits at a constant offset
     // (folded into the ds_read/ds_write immediates instead of living in scalar registers)
     const int NH = NFIX ? NFIX : c.N;
@@ -1401,7 +1409,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     lay.init(NH, L, FT);
     Gws g;
     g.init(NH, L, FT);
-    SolveCtx<L, NFIX, FACTOR_LDS, FT, R3> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
+    SolveCtx<L, NFIX, FACTOR_LDS, FT, R3, POLISH> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
     q.xb = nullptr;
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time.  Every array is handed out with its
         // extent (DEKF_SPAN: a plain pointer in the product builds, a checked one in the -DDEKF_BOUNDS build, wave.h)
@@ -1510,6 +1518,8 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         q.vo = DEKF_CSPAN(sn + NS2 + NS, 4 * c.wcap);
     }
     q.cc = 1.0;
+    q.sigma_pol = c.delta;
+    q.zlo = false;
     q.Pst = DEKF_SPAN(raw_of(q.Sinv), 2 * NH * NS2);  // Sinv | Wk are adjacent in both placements and dead until a factorisation writes them
     q.staged = false;
     const int n = q.n, m = q.m;
@@ -1663,6 +1673,73 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         xT[j] = q.D[ix.x(K - 1, j)] * (R3 ? q.xb[NS * (K - 1) + j] : x[ix.x(K - 1, j)]);
         if (!(fabs(xT[j]) <= 1e300)) finite = false;
     }
+    // ---- solution polishing (osqp.polish, OSQP paper sec. 4 / polish.c; the node's declared default, EstSub.cpp:188).
+    // OSQP guesses the active set from the dual iterate, solves the equality-constrained QP on it through the regularised system
+    //     [P + delta I, A_a'; A_a, -delta I] [x; y_a] = [-q; b_a]
+    // and refines the result polish_refine_iter times against the unregularised matrix:  K_reg s+ = rhs + delta [x; -y].  That
+    // recursion IS the ADMM step of this solver with sigma = delta, 1 / rho = delta on the active rows, alpha = 1 and z held at the
+    // bound b — started from x = y = 0 (first solve: K_reg s = rhs).  Every Meas / Dyn row and every VO row with a bound is an
+    // equality, hence active whatever the sign of its multiplier; a VO row without bounds stays a free row (rho = RHO_MIN; OSQP
+    // leaves it out: the difference is a proximal term of 1e-6 against weights of 1e9).  So: one more factorisation, 1 +
+    // polish_refine_iter iterations of the kernels above, the residuals of the result, and OSQP's acceptance test.
+    if constexpr (POLISH) if (c.polish && ok && finite && info.status == DEKF_SOLVE_OK) {
+        const double pri0 = info.pri_res, dua0 = info.dua_res, rho_keep = q.rho;
+        DEKF_SYNC();
+        q.rho = dmin(dmax(1.0 / (c.delta * RHO_EQ_OVER_RHO_INEQ), RHO_MIN), RHO_MAX);  // rho of an equality row: 1 / delta
+        q.zlo = true;
+        if constexpr (R3) {
+            q.cold = true;
+            wfor(K * NS, [&](int e) { q.xb[e] = 0.0; });
+        } else {
+            wfor(n + m, [&](int e) {
+                if (e < n) { x[e] = 0.0; return; }
+                const int r = e - n;
+                const bool free_row = r >= q.ix.rvb && q.rho_of(q.lo[r], q.hi[r - q.ix.rvb]) == RHO_MIN;
+                z[r] = free_row ? 0.0 : q.lo[r];
+                y[r] = 0.0;
+            });
+        }
+        bool okp = solve_factor(q);
+        if constexpr (!R3) {
+            if (okp) phase_rows<true>(q, 1.0, q.sigma());
+        }
+        const int npol = 1 + (c.polish_refine_iter > 0 ? c.polish_refine_iter : 0);
+        if (okp) {
+#if DEKF_DEVICE_BUILD
+            if constexpr (R3) {
+                admm_chunk_r3<NFIX>(q, npol, 1.0, q.sigma());
+            } else
+#endif
+            {
+                for (int it = 0; it < npol; ++it) {
+                    phase_xcols(q, q.sigma());
+                    phase_sweeps_rows(q, 1.0, q.sigma());
+                }
+            }
+            double ra[6], va[8];
+            residual_norms(q, ra, va);
+            const double prp = ra[0], dup = cinv * va[0];
+            const bool good = (prp < pri0 && dup < dua0) || (prp < pri0 && dua0 < 1e-10) || (dup < dua0 && pri0 < 1e-10);
+            double xP[NS];
+            bool finp = true;
+            for (int j = 0; j < NS; ++j) {
+                xP[j] = q.D[ix.x(K - 1, j)] * (R3 ? q.xb[NS * (K - 1) + j] : x[ix.x(K - 1, j)]);
+                if (!(fabs(xP[j]) <= 1e300)) finp = false;
+            }
+            if (good && finp) {  // status_polish = 1: the polished point replaces the iterate
+                for (int j = 0; j < NS; ++j) xT[j] = xP[j];
+                info.pri_res = prp;
+                info.dua_res = dup;
+                info.polished = 1;
+            } else {
+                info.polished = -1;
+            }
+        } else {
+            info.polished = -1;
+        }
+        q.rho = rho_keep;
+        q.zlo = false;
+    }
     if (!finite) info.status = DEKF_SOLVE_NUMERIC;
 #if defined(DEKF_BOUNDS) && DEKF_DEVICE_BUILD
     // an out-of-range dereference while this instance was being solved (by this or a concurrent workgroup: the counter is global)
@@ -1682,6 +1759,7 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
         s.status[b] = info.status;
         s.iters[b] = info.iters;
         s.rho_updates[b] = info.rho_updates;
+        s.polish_status[b] = info.polished;
         s.pri_res[b] = info.pri_res;
         s.dua_res[b] = info.dua_res;
     }
@@ -1691,6 +1769,11 @@ DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int ks
     if (DEKF_LANE() == 0) q.prof[13] = (double)(clock64() - prof_t0);
 #endif
     return info;
+}
+// the kernels without the polishing step (osqp.polish false: parameters_go1.yaml:44 — the benchmark configuration)
+template <int L, bool FACTOR_LDS, bool PA_LDS, int NFIX = 0, int FT = 0, bool R3 = false>
+DEKF_FN SolveInfo solve_window(const DevCfg& c, const DevState& s, int b, int kstart, int K, dptr lds, dptr gws) {
+    return solve_window_t<false, L, FACTOR_LDS, PA_LDS, NFIX, FT, R3>(c, s, b, kstart, K, lds, gws);
 }
 
 }  // namespace dekf

@@ -132,6 +132,8 @@ class BatchedEstimator:
         out = dict(iters=np.zeros(B, np.int32), rho_updates=np.zeros(B, np.int32), pri_res=np.zeros(B), dua_res=np.zeros(B))
         capi.check(self.lib.dekf_get_solver_info(self.h, *[C.c_void_p(out[k].ctypes.data) for k in ("iters", "rho_updates", "pri_res", "dua_res")],
                                                  capi.DEKF_HOST))
+        out["polish_status"] = np.zeros(B, np.int32)
+        capi.check(self.lib.dekf_get_polish_status(self.h, C.c_void_p(out["polish_status"].ctypes.data), capi.DEKF_HOST))
         return out
 
     def ekf_cov(self):

@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define DEKF_ABI_VERSION 2 /* 2: dekf_params.solve_workgroups_per_cu, dekf_solve_kernel_name, dekf_launch_info; dim_state-sized rows */
+#define DEKF_ABI_VERSION 3 /* 3: osqp.polish implemented: dekf_params.polish_refine_iter, dekf_get_polish_status;
+                            * 2: dekf_params.solve_workgroups_per_cu, dekf_solve_kernel_name, dekf_launch_info; dim_state-sized rows */
 #define DEKF_MAX_LEGS 4
 #define DEKF_MAX_JOINTS 8 /* joints per leg */
 
@@ -90,7 +91,8 @@ typedef struct dekf_params {
     int est_type; /* 0 MHE, 1 KF */
     /* osqp.* (DecentralEst.cpp:204-217) */
     double rho, alpha, delta, sigma;
-    int verbose, adapt_rho, polish, max_qp_iter;
+    int verbose, adapt_rho, polish, max_qp_iter; /* polish: OSQP's solution polishing after a solved QP (DecentralEst.cpp:207;
+                                                   * declared default true, EstSub.cpp:188; parameters_go1.yaml:44 sets false) */
     double rel_tol, abs_tol, prim_tol, dual_tol;
     double time_limit; /* accepted, NOT honoured: runs are deterministic */
     /* OSQP defaults the reference leaves implicit, made explicit here */
@@ -107,6 +109,8 @@ typedef struct dekf_params {
     int ekf_rate;                   /* 500 */
     int ekf_history;                /* depth of the rewind ring (reference: unbounded); size it as
                                      * ceil(worst VO pose latency * ekf_rate) + 2, INTEGRATION.md section 5 */
+    int polish_refine_iter;         /* OSQP's polish_refine_iter (refinement steps of the polishing solve; OSQP default 3, the
+                                     * reference does not set it).  Used when `polish` is on. */
     int arrival_cost_form;          /* leg_odom_type 1 only.  0: the reference's covariance-form saddle inverse
                                      * (MheSrb.cpp:527-651).  1: information form (same arrival cost in exact arithmetic,
                                      * computed from gains only). leg_odom_type 0 always uses the reference form. */
@@ -201,6 +205,10 @@ dekf_status dekf_get_ekf_cov(dekf_handle h, double* cov, dekf_mem where);
  * pri_res[B], dua_res[B] (unscaled OSQP residuals). Any pointer may be NULL. */
 dekf_status dekf_get_solver_info(dekf_handle h, int* iters, int* rho_updates, double* pri_res,
                                  double* dua_res, dekf_mem where);
+/* Outcome of OSQP's polishing step per instance, polish_status[B] (int; OSQP's info->status_polish): 0 polishing off or the
+ * solve did not end OSQP_SOLVED, 1 the polished point replaced the ADMM iterate (pri_res / dua_res are then its residuals),
+ * -1 polishing ran and was rejected (the ADMM iterate is returned). */
+dekf_status dekf_get_polish_status(dekf_handle h, int* polish_status, dekf_mem where);
 /* KF covariance C_KF_[B][dim_state][dim_state] (est_type 1). */
 dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where);
 

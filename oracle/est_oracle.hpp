@@ -434,6 +434,8 @@ class EstOracle {
         qp.settings.scaling = prm.scaling_iters; qp.settings.check_termination = prm.check_termination;
         qp.settings.adaptive_rho_interval = prm.adaptive_rho_interval;
         qp.settings.adaptive_rho_tolerance = prm.adaptive_rho_tolerance;
+        qp.settings.polish = prm.polish; qp.settings.delta = prm.delta;  // DecentralEst.cpp:207,211
+        qp.settings.polish_refine_iter = prm.polish_refine_iter;
         get_measurement(0);
         Q_prior = Mat(ns, ns);
         Q_prior.set_block(0, 0, gain3(prm.p_init_std));

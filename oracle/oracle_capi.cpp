@@ -165,6 +165,12 @@ void orc_est_solver_info(void* h, int* iters, int* status, int* rho_updates, int
     if (nnzL) *nnzL = o.ldl.nnzL();
     if (rho) *rho = o.s.rho;
 }
+void orc_est_polish_info(void* h, int* status, double* pri_res, double* dua_res) {
+    const OsqpRestate& o = ((EstOracle*)h)->qp.osqp;
+    if (status) *status = o.polish_status;
+    if (pri_res) *pri_res = o.pol_pri_res;
+    if (dua_res) *dua_res = o.pol_dua_res;
+}
 void orc_est_scaling(void* h, double* D, double* E, double* c) {
     const OsqpRestate& o = ((EstOracle*)h)->qp.osqp;
     if (D) std::memcpy(D, o.D.data(), o.D.size() * sizeof(double));

@@ -12,9 +12,9 @@
 // file restates the published algorithm: B. Stellato, G. Banjac, P. Goulart, A. Bemporad,
 // S. Boyd, "OSQP: an operator splitting solver for quadratic programs", Math. Prog. Comp.
 // 12 (2020) — Algorithm 1, sec. 5.1 (linear system), 5.2 (rho selection / adaptive rho),
-// 3.4 (termination), 5.1 Ruiz equilibration — with OSQP 0.6.x's constants and update order
+// 3.4 (termination), 5.1 Ruiz equilibration, 4 (polishing) — with OSQP 0.6.x's constants and update order
 // (RHO_MIN 1e-6, RHO_MAX 1e6, RHO_EQ_OVER_RHO_INEQ 1e3, RHO_TOL 1e-4, MIN/MAX_SCALING
-// 1e-4/1e4, OSQP_INFTY 1e30, scaled_termination off, polish off).
+// 1e-4/1e4, OSQP_INFTY 1e30, scaled_termination off, polish_refine_iter 3).
 //
 // Deliberate, documented deviations (both make runs deterministic):
 //  * adaptive_rho_interval: OSQP 0.6 derives it from wall-clock (0.4 x setup time, rounded
@@ -69,6 +69,10 @@ struct OsqpSettings {
     int adaptive_rho = 1;
     int adaptive_rho_interval = 25;
     double adaptive_rho_tolerance = 5.0;
+    // solution polishing (OSQP paper sec. 4; osqp.polish / osqp.delta of the reference, EstSub.cpp:184-188, DecentralEst.cpp:207,211)
+    int polish = 0;
+    double delta = 1e-6;
+    int polish_refine_iter = 3;  // OSQP default; the reference does not set it
 };
 
 enum OsqpStatus {
@@ -265,6 +269,8 @@ class OsqpRestate {
     int iters = 0, status = OSQP_R_UNSOLVED, rho_updates = 0, factorizations = 0;
     double pri_res = 0, dua_res = 0;
     Vec x_sol, y_sol;
+    int polish_status = 0;  // 0 not run, 1 successful (the polished point replaced the ADMM iterate), -1 unsuccessful
+    double pol_pri_res = 0, pol_dua_res = 0;
 
     static double limit1(double v) {
         v = v < MIN_SCALING ? 1.0 : v;
@@ -537,6 +543,74 @@ class OsqpRestate {
         return true;
     }
 
+    // Solution polishing (OSQP paper sec. 4, Algorithm 2 / polish.c of OSQP 0.6): guess the active set from the signs of the
+    // dual iterate, solve the equality-constrained QP on it through the regularised KKT system
+    //     [P + delta I, A_act'; A_act, -delta I] [x; y_act] = [-q; b_act]
+    // with polish_refine_iter steps of iterative refinement against the unregularised matrix, and keep the result if it
+    // improves the residuals.  Works on the scaled problem, like OSQP.
+    void polish() {
+        std::vector<int> act;        // row -> index in the reduced system, or -1
+        std::vector<double> bact;
+        act.assign(m, -1);
+        int mr = 0;
+        for (int i = 0; i < m; ++i) {
+            if (z[i] - l[i] < -y[i]) { act[i] = mr++; bact.push_back(l[i]); }       // lower-active
+            else if (u[i] - z[i] < y[i]) { act[i] = mr++; bact.push_back(u[i]); }   // upper-active
+        }
+        const int N = n + mr;
+        std::vector<int> ti, tj;
+        std::vector<double> tv, tv0;  // regularised / plain values on the same pattern
+        std::vector<char> has_diag(n, 0);
+        for (int j = 0; j < n; ++j)
+            for (int p = P.p[j]; p < P.p[j + 1]; ++p) {
+                double v = P.x[p];
+                ti.push_back(P.i[p]); tj.push_back(j); tv0.push_back(v);
+                if (P.i[p] == j) { v += s.delta; has_diag[j] = 1; }
+                tv.push_back(v);
+            }
+        for (int j = 0; j < n; ++j)
+            if (!has_diag[j]) { ti.push_back(j); tj.push_back(j); tv.push_back(s.delta); tv0.push_back(0.0); }
+        for (int j = 0; j < n; ++j)
+            for (int p = A.p[j]; p < A.p[j + 1]; ++p)
+                if (act[A.i[p]] >= 0) { ti.push_back(j); tj.push_back(n + act[A.i[p]]); tv.push_back(A.x[p]); tv0.push_back(A.x[p]); }
+        for (int i = 0; i < mr; ++i) { ti.push_back(n + i); tj.push_back(n + i); tv.push_back(-s.delta); tv0.push_back(0.0); }
+        SparseLDL pl;
+        pl.analyze(N, ti, tj);
+        if (!pl.factor(ti, tj, tv)) { polish_status = -1; return; }
+        Vec rhs(N), sol(N), res(N);
+        for (int j = 0; j < n; ++j) rhs[j] = -q[j];
+        for (int i = 0; i < mr; ++i) rhs[n + i] = bact[i];
+        sol = rhs;
+        pl.solve(sol);
+        for (int it = 0; it < s.polish_refine_iter; ++it) {
+            // res = rhs - K sol, K the unregularised symmetric matrix given by its upper triplets
+            res = rhs;
+            for (size_t k = 0; k < ti.size(); ++k) {
+                const int a = ti[k], b = tj[k];
+                res[a] -= tv0[k] * sol[b];
+                if (a != b) res[b] -= tv0[k] * sol[a];
+            }
+            pl.solve(res);
+            for (int k = 0; k < N; ++k) sol[k] += res[k];
+        }
+        // the polished point: x, z = proj(A x), y (zero on the inactive rows)
+        Vec xp(sol.begin(), sol.begin() + n), zp(m, 0.0), yp(m, 0.0);
+        mat_vec(A, xp, zp, false);
+        for (int i = 0; i < m; ++i) {
+            zp[i] = std::min(std::max(zp[i], l[i]), u[i]);
+            if (act[i] >= 0) yp[i] = sol[n + act[i]];
+        }
+        // its residuals, computed like those of the iterate
+        Vec xs = x, zs = z, ys = y;
+        const double pr0 = pri_res, du0 = dua_res;
+        x = xp; z = zp; y = yp;
+        pol_pri_res = compute_pri_res();
+        pol_dua_res = compute_dua_res();
+        const bool good = (pol_pri_res < pr0 && pol_dua_res < du0) || (pol_pri_res < pr0 && du0 < 1e-10) || (pol_dua_res < du0 && pr0 < 1e-10);
+        if (good) { polish_status = 1; pri_res = pol_pri_res; dua_res = pol_dua_res; }
+        else { polish_status = -1; x = xs; z = zs; y = ys; pri_res = pr0; dua_res = du0; }
+    }
+
     // osqp_solve
     int solve() {
         if (status == OSQP_R_NUMERIC) return status;
@@ -581,6 +655,8 @@ class OsqpRestate {
             if (!can_check) { update_info(); check_termination(false); }
             if (status == OSQP_R_UNSOLVED && !check_termination(true)) status = OSQP_R_MAX_ITER;
         }
+        polish_status = 0;
+        if (s.polish && status == OSQP_R_SOLVED) polish();
         // store_solution: unscale
         x_sol.resize(n); y_sol.resize(m);
         for (int j = 0; j < n; ++j) x_sol[j] = D[j] * x[j];

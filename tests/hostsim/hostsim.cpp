@@ -93,12 +93,12 @@ void hs_update(void* hv, int T) {
             SolveLayout lay; lay.init(h->c.N, h->c.L, h->c.ft);
             int K = T - kstart + 1;
 #define HS_SOLVE(LEGS)                                                                                      \
-    if (lay.pa_in_lds()) solve_window<LEGS, true, true>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws); \
-    else if (lay.factor_in_lds()) solve_window<LEGS, true, false>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws); \
-    else solve_window<LEGS, false, false>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);
+    if (lay.pa_in_lds()) solve_window_t<true, LEGS, true, true>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws); \
+    else if (lay.factor_in_lds()) solve_window_t<true, LEGS, true, false>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws); \
+    else solve_window_t<true, LEGS, false, false>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);
 #define HS_SOLVE_FOOT(LEGS)                                                                                              \
-    if (lay.factor_in_lds()) solve_window<LEGS, true, false, 0, 1>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);     \
-    else solve_window<LEGS, false, false, 0, 1>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);
+    if (lay.factor_in_lds()) solve_window_t<true, LEGS, true, false, 0, 1>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);     \
+    else solve_window_t<true, LEGS, false, false, 0, 1>(h->c, h->s, b, kstart, K, h->lds.data(), h->s.gws);
             if (h->c.ft) {
                 switch (h->c.L) {
                     case 1: HS_SOLVE_FOOT(1) break;
@@ -130,6 +130,15 @@ void hs_get(void* hv, double* x, double* vb, double* quat, double* p_vo, int* st
     if (status) std::memcpy(status, h->s.status, B * 4);
     if (iters) std::memcpy(iters, h->s.iters, B * 4);
     if (rho_updates) std::memcpy(rho_updates, h->s.rho_updates, B * 4);
+}
+void hs_get_polish_status(void* hv, int* st) {
+    Sim* h = (Sim*)hv;
+    std::memcpy(st, h->s.polish_status, (size_t)h->c.B * 4);
+}
+void hs_get_residuals(void* hv, double* pri, double* dua) {
+    Sim* h = (Sim*)hv;
+    std::memcpy(pri, h->s.pri_res, (size_t)h->c.B * 8);
+    std::memcpy(dua, h->s.dua_res, (size_t)h->c.B * 8);
 }
 void hs_get_ekf_cov(void* hv, double* P) {
     Sim* h = (Sim*)hv; size_t B = h->c.B;

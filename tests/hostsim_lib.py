@@ -52,6 +52,8 @@ def lib():
         L.hs_update.argtypes = [vp, C.c_int]
         L.hs_get.argtypes = [vp, _dp, _dp, _dp, _dp, _ip, _ip, _ip]
         L.hs_get_ekf_cov.argtypes = [vp, _dp]
+        L.hs_get_polish_status.argtypes = [vp, _ip]
+        L.hs_get_residuals.argtypes = [vp, _dp, _dp]
         L.hs_get_arrival.argtypes = [vp, _dp, _dp]
         L.hs_get_scaling.argtypes = [vp, C.c_int, C.c_int, _dp, _dp]
         _lib = L
@@ -90,7 +92,11 @@ class HostSim:
         x, vb, q, pv = np.zeros((B, self.p.dim_state)), np.zeros((B, 3)), np.zeros((B, 4)), np.zeros((B, 3))
         st, it, ru = (np.zeros(B, np.int32) for _ in range(3))
         lib().hs_get(self.h, _p(x), _p(vb), _p(q), _p(pv), _p(st), _p(it), _p(ru))
-        return dict(x=x, v_b=vb, quat=q, p_vo=pv, status=st, iters=it, rho_updates=ru)
+        ps = np.zeros(B, np.int32)
+        lib().hs_get_polish_status(self.h, _p(ps))
+        pr, du = np.zeros(B), np.zeros(B)
+        lib().hs_get_residuals(self.h, _p(pr), _p(du))
+        return dict(x=x, v_b=vb, quat=q, p_vo=pv, status=st, iters=it, rho_updates=ru, polish_status=ps, pri_res=pr, dua_res=du)
 
     def ekf_cov(self):
         P = np.zeros((self.B, 4, 4))

@@ -77,6 +77,7 @@ def lib():
         L.orc_est_qp_copy.argtypes = [vp, _dp, _dp, _dp, _dp, _dp]
         L.orc_est_solution.argtypes = [vp, _dp]
         L.orc_est_solver_info.argtypes = [vp, _ip, _ip, _ip, _ip, _dp, _dp, _ip, _dp]
+        L.orc_est_polish_info.argtypes = [vp, _ip, _dp, _dp]
         L.orc_est_scaling.argtypes = [vp, _dp, _dp, _dp]
         L.orc_est_arrival.argtypes = [vp, _dp, _dp]
         L.orc_est_kf_cov.argtypes = [vp, _dp]
@@ -208,6 +209,11 @@ class Est:
                                   C.byref(du), C.byref(nz), C.byref(rho))
         return dict(iters=it.value, status=st.value, rho_updates=ru.value, factorizations=fa.value,
                     pri_res=pr.value, dua_res=du.value, nnzL=nz.value, rho=rho.value)
+
+    def polish_info(self):
+        st, pr, du = C.c_int(), C.c_double(), C.c_double()
+        lib().orc_est_polish_info(self.h, C.byref(st), C.byref(pr), C.byref(du))
+        return dict(status=st.value, pri_res=pr.value, dua_res=du.value)
 
     def scaling(self):
         n, m = C.c_int(), C.c_int()
