@@ -44,7 +44,8 @@ def run(name, maker, B, steps, **kw):
     est.close()
     print(json.dumps({"shape": name, "legs": p.num_legs, "N": p.N, "batch": B, "steps": steps,
                       "estimator_steps_per_s": B * steps / dt, "ms_per_step": 1e3 * dt / steps,
-                      "mean_iters": float(info["iters"].mean()), "solved_frac": float((o["status"] == 1).mean())}), flush=True)
+                      "mean_iters": float(info["iters"].mean()), "solved_frac": float((o["status"] == 1).mean()),
+                      "polish_accepted_frac": float((info["polish_status"] == 1).mean())}), flush=True)
 
 
 if __name__ == "__main__":
@@ -52,6 +53,8 @@ if __name__ == "__main__":
     run("go1 N=20, per-rank batch of the 8-GPU config", go1_params, 8192, 60)
     run("cassie N=20", cassie_params, 4096, 100)
     run("pogox N=100", pogox_params, 1024, 60)
+    run("go1 N=20 with osqp.polish (the node's declared default; k_mhe_solve_r3_4_n20_pol)", go1_params, 4096, 100, polish=1)
+    run("pogox N=100 with osqp.polish", pogox_params, 1024, 40, polish=1)
     run("go1 KF mode (est_type 1: recursion instead of the QP)", go1_params, 4096, 200, est_type=1)
     run("go1 KF mode, batch 65536", go1_params, 65536, 100, est_type=1)
     run("go1 with foot-position states (leg_odom_type 1, 21-dim blocks)", go1_params, 4096, 40, leg_odom_type=1)

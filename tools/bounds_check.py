@@ -57,6 +57,11 @@ CASES = [  # (kernel set = library suffix, name, params maker, batch, ticks, ove
     ("foot2", "cassie leg_odom_type 1, N=8 (factor in LDS)", "cassie", 64, 30, dict(leg_odom_type=1, N=8)),
     ("foot1", "one leg, leg_odom_type 1, N=30", "go1", 64, 50, dict(leg_odom_type=1, num_legs=1, N=30)),
     ("foot3", "three legs, leg_odom_type 1, N=5", "go1", 64, 20, dict(leg_odom_type=1, num_legs=3, N=5)),
+    # osqp.polish: the kernels' twins with the polishing step (a second factorisation and 1 + polish_refine_iter iterations per solve)
+    ("go1", "go1 N=20 with osqp.polish (k_mhe_solve_ll_4_n20_pol, k_mhe_solve_r3_4_n20_pol)", "go1", 800, 50, dict(polish=1)),
+    ("cassie", "cassie N=20 with osqp.polish (k_mhe_solve_lg_2_n20_pol, k_mhe_solve_r3_2_n20_pol)", "cassie", 800, 45, dict(polish=1)),
+    ("legs1", "pogox N=100 with osqp.polish (factor streamed from the slab)", "pogox", 64, 110, dict(polish=1)),
+    ("foot4", "go1 leg_odom_type 1 with osqp.polish", "go1", 128, 30, dict(leg_odom_type=1, polish=1)),
 ]
 MAKERS = {"go1": go1_params, "cassie": cassie_params, "pogox": pogox_params}
 
