@@ -1,20 +1,37 @@
 #!/bin/bash
 # Builds libdekf.so (the C-ABI shared library, gfx950 only) in-tree.
-#   DEKF_OUT=libdekf_prof.so DEKF_UNITY=1 bash build.sh -DDEKF_PROFILE     diagnostic / A-B variants under another name
-# DEKF_UNITY=1 compiles both sources as ONE translation unit without -fgpu-rdc (no link-time code generation): the
-# -DDEKF_PROFILE variant trips a code-generator bug of this ROCm in the LTO step ("Illegal instruction detected:
-# V_CMP_NE_U32_e32 0, $src_shared_base"); the unity build does not.
+#   bash build.sh                                            the product: every kernel, compiled as 12 translation units in parallel
+#   DEKF_OUT=libdekf_prof.so DEKF_UNITY=1 bash build.sh -DDEKF_PROFILE -DDEKF_GO1_ONLY     diagnostic / A-B variants under another name
+# Product build: kernels.hip is compiled once per kernel set (-DDEKF_KSET=<bit> -DDEKF_KSET_ONLY: the unit carries only its set;
+# bit 1024 = the kernels that are not solves) next to dekf_capi.hip, DEKF_JOBS units at a time (default: all of them at once — they
+# are independent, no -fgpu-rdc: a kernel is launched through its host stub, which any unit can reference), then linked.  One
+# translation unit of everything takes 4.6 minutes, the slowest set 70 s.
+# DEKF_UNITY=1 compiles both sources as ONE translation unit (variants that select their kernels with -DDEKF_KSET / -DDEKF_GO1_ONLY,
+# the -DDEKF_BOUNDS build with its device-side counter).
 set -e
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 OUT=${DEKF_OUT:-libdekf.so}
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I/opt/rocm/include -I$(pwd)"
 if [ -n "$DEKF_UNITY" ]; then
     U=$(mktemp /tmp/dekf_unity_XXXXXX.hip)
     printf '#include "%s/kernels.hip"\n#include "%s/dekf_capi.hip"\n' "$(pwd)" "$(pwd)" > "$U"
-    $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I/opt/rocm/include -I"$(pwd)" -o "$OUT" "$U" -ldl "$@"
+    $HIPCC $FLAGS -shared -o "$OUT" "$U" -ldl "$@"
     rm -f "$U"
 else
-    $HIPCC --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fgpu-rdc \
-        -I/opt/rocm/include -o "$OUT" kernels.hip dekf_capi.hip -ldl "$@"
+    T=$(mktemp -d /tmp/dekf_build_XXXXXX)
+    trap 'rm -rf "$T"' EXIT
+    JOBS=${DEKF_JOBS:-12}
+    pids=()
+    run() { "$@" & pids+=($!); while [ "$(jobs -rp | wc -l)" -ge "$JOBS" ]; do sleep 0.2; done; }
+    # heaviest sets first (foot-state kernels, then the generic ones)
+    for m in 512 256 128 64 32 16 8 4 1 2 1024; do
+        run $HIPCC $FLAGS -c -DDEKF_KSET=$m -DDEKF_KSET_ONLY -o "$T/k_$m.o" kernels.hip "$@"
+    done
+    run $HIPCC $FLAGS -c -o "$T/capi.o" dekf_capi.hip "$@"
+    rc=0
+    for p in "${pids[@]}"; do wait "$p" || rc=1; done
+    [ $rc -eq 0 ] || { echo "build failed"; exit 1; }
+    $HIPCC --offload-arch=gfx950 -fPIC -shared -o "$OUT" "$T"/*.o -ldl
 fi
 echo "built $(pwd)/$OUT"

@@ -34,6 +34,14 @@ extern "C" __global__ void k_bounds_selftest(double* a) {
 
 extern "C" {
 
+// -DDEKF_KSET_ONLY (the parallel product build, build.sh): this translation unit carries ONLY the kernels of its mask — no stubs
+// for the others (another unit defines them) — and the kernels that are not solves only with bit 1024.
+#if !defined(DEKF_KSET_ONLY) || (defined(DEKF_KSET) && (DEKF_KSET & 1024))
+#define DEKF_MISC_KERNELS 1
+#else
+#define DEKF_MISC_KERNELS 0
+#endif
+#if DEKF_MISC_KERNELS
 __global__ void __launch_bounds__(64) k_ekf_tick(DevCfg c, DevState s, int count) {
     int b = blockIdx.x * 64 + threadIdx.x;
     if (b < c.B) ekf_tick(c, s, b, count);
@@ -49,6 +57,7 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
     extern __shared__ double lds[];
     assemble_update(c, s, blockIdx.x, T, pushes, lds);
 }
+#endif  // DEKF_MISC_KERNELS
 
 // three placements of the factor (mhe_solve_core.h: SolveLayout): _ll all in LDS (Go1, N = 20),
 // _lg LDS factor with the factor-time temporary in HBM (fewer legs), _gg factor streamed from HBM
@@ -77,9 +86,13 @@ __global__ void __launch_bounds__(64) k_mhe_assemble(DevCfg c, DevState s, int T
 // Every solve kernel exists twice: NAME, and NAME_pol with OSQP's polishing step behind the iterations (osqp.polish true; chosen
 // by dekf_create).  Two instantiations rather than a run-time branch: compiled into k_mhe_solve_r3_4_n20 the polishing code (a
 // second call site of the factorisation and of the iteration chunk) took its spilled VGPRs from 60 to 147.
+#ifdef DEKF_KSET_ONLY
+#define DEKF_STUB_KERNEL(NAME)
+#else
 #define DEKF_STUB_KERNEL(NAME)                                  \
     __global__ void NAME(DevCfg, DevState, int, int, int) {}     \
     __global__ void NAME##_pol(DevCfg, DevState, int, int, int) {}
+#endif
 #define DEKF_SOLVE_KERNEL_BODY_(NAME, WAVES, POLISH, ...)                                                                    \
     __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, WAVES) NAME(DevCfg c, DevState s, int kstart, int K, int gws_len) { \
         extern __shared__ double lds[];                                                                                      \
@@ -176,6 +189,7 @@ DEKF_SOLVE_KERNELS_FOOT(7, 2)
 DEKF_SOLVE_KERNELS_FOOT(8, 3)
 DEKF_SOLVE_KERNELS_FOOT(9, 4)
 
+#if DEKF_MISC_KERNELS
 __global__ void __launch_bounds__(64) k_kf_initialize(DevCfg c, DevState s) {
     extern __shared__ double lds[];
     kf_initialize(c, s, blockIdx.x, lds);
@@ -250,5 +264,7 @@ __global__ void k_reset_state(DevCfg c, DevState s) {
     s.vo_ins_idx[b] = 0;
     s.vo_ins_dtime[b] = 0;
 }
+
+#endif  // DEKF_MISC_KERNELS
 
 }  // extern "C"
