@@ -655,16 +655,56 @@ DEKF_FN void solve_scale(Q& q) {
 #endif
             wtiles(ntiles, [&](int tile, int lane) { psum += fused(tile, lane, cc, Dr, Er, Dw, Ew); });
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
+            long long tr1 = 0, tr2 = 0;
+#endif
+#ifdef DEKF_X_RUIZ_3BARRIERS  // (A/B: the form with the sum behind the x_0 norms, two more barriers per pass)
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
             __builtin_amdgcn_s_waitcnt(0);
-            const long long tr1 = clock64();
+            tr1 = clock64();
 #endif
             DEKF_SYNC();
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
-            const long long tr2 = clock64();
+            tr2 = clock64();
 #endif
             wtiles(ntiles, [&](int tile, int lane) { psum += fused_x0(tile, lane, Dw); });
             psum = wave_sum(psum);
             group_combine<1, true>(&psum);
+#else
+            // ONE barrier per pass: every wavefront leaves the sum of its tiles in LDS before it (two sets of slots, by parity of
+            // the pass: a wavefront that is already in the next pass must not overwrite what a slower one still reads), and behind
+            // it every wavefront adds up the four partials in the same order and computes the nine arrival-cost norms itself
+            // (lanes 0..8; their owner lanes store them for their own next pass).  Was: barrier | x_0 norms | sum through
+            // group_combine with two more barriers.
+            {
+                const int wv = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), ln = DEKF_LANE() & 63;
+                dptr part = q.tmp + 176 + 4 * (it & 1);  // (the Gauss-Jordan scratch, dead during the scaling)
+                psum = wave_sum_dpp(psum);
+                if (ln == 0) part[wv] = psum;
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
+                __builtin_amdgcn_s_waitcnt(0);
+                tr1 = clock64();
+#endif
+                DEKF_SYNC();
+#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
+                tr2 = clock64();
+#endif
+                const int j = ln < 9 ? ln : 8;
+                const double dj = Dw[j];
+                double mj[9], dt9[9], v = 0.0;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) { mj[t] = symget(Mst, j, t, 9); dt9[t] = Dw[t]; }
+#pragma unroll
+                for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * mj[t] * dt9[t]));
+                // pc of column j of x_0 is read by the wavefront that owns the column's tile (lane j % 3 of the first tile of
+                // kind j / 3) in ITS next pass: that wavefront stores it (LDS serves a wavefront's accesses in order)
+                if (ln < 9 && ((ntm + ntp + 2 * ntd + (j / 3) * ntx) & (DEKF_NLANES() / WAVE - 1)) == wv) pc[j] = v;
+                const double x0 = wave_sum_dpp(ln < 9 ? v : 0.0);
+                const int nw = DEKF_NLANES() >> 6;
+                double tot = part[0];
+                for (int i = 1; i < nw; ++i) tot += part[i];
+                psum = tot + x0;
+            }
+#endif
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
             {
                 const long long tr3 = clock64();
@@ -1163,7 +1203,7 @@ DEKF_FN bool solve_factor(Q& q) {
     (void)nph; (void)bufs; (void)gj_step; (void)pivot_ok; (void)store_sinv; (void)build_s;
     // S of block k, element p (device form: three independent accumulators per sum, no symmetrisation —
     // W C' = C S^-1 C' is symmetric up to rounding and the Gauss-Jordan sweep does not need more)
-    auto build_s3 = [&](int k, bool use_top, bool use_bot, int p, dptr dst) {
+    auto build_s3 = [&](int k, bool use_top, bool use_bot, int p, dptr dst) -> double {
         const int i = p / 9, j = p - 9 * i;
         const int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
         double acc = q.Sinv[k * 81 + 9 * lo_ + hi_];
@@ -1184,17 +1224,54 @@ DEKF_FN bool solve_factor(Q& q) {
             acc -= s0 + (s1 + s2);
         }
         dst[p] = acc;
+        return acc;
     };
     auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, dptr tb) -> bool {
         // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]
         const int lane = DEKF_LANE() & 63;
         dptr ts = tb;        // S, then the full inverse
-        for (int p = lane; p < 81; p += WAVE) build_s3(k, use_top, use_bot, p, ts);
+#ifdef DEKF_X_LDL_FULL_S  // (A/B: all 81 entries of S, two rounds of the wavefront)
+        for (int p = lane; p < 81; p += WAVE) (void)build_s3(k, use_top, use_bot, p, ts);
+#else
+        // S is symmetric (T_kk exactly, the Schur terms up to rounding): its 45 upper entries in ONE round of the wavefront,
+        // each stored to both places (the Gauss-Jordan sweep below reads columns)
+        if (lane < 45) {
+            const int e = lane;
+            const int i = (e >= 9) + (e >= 17) + (e >= 24) + (e >= 30) + (e >= 35) + (e >= 39) + (e >= 42) + (e >= 44);
+            const int j = e - (9 * i - ((i * (i - 1)) >> 1)) + i;
+            ts[9 * j + i] = build_s3(k, use_top, use_bot, 9 * i + j, ts);
+        }
+#endif
         wave_sync();
+#ifdef DEKF_X_LDL_W_PRODUCT  // (A/B: the inverse alone in the sweep, W = C S^-1 as a product behind it)
         const int j = lane < 9 ? lane : 8;
+        const int li = lane;
         double a[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) a[i] = ts[9 * i + j];
+#else
+        // AUGMENTED sweep: next to the nine columns of S the wavefront carries the nine columns of C' (W_k = C_k S^-1: row c of C) or
+        // of C (W^_{k-1} = C_{k-1}' S^-1: column c of C); the Gauss-Jordan sweep turns a column v into S^-1 v, i.e. into row c of
+        // the W block — with the SAME nine DPP instructions per pivot, which every lane executes anyway.  A DPP broadcast stays
+        // inside its 16-lane row, so rows 0 and 1 both hold the columns of S (lanes 0..8) and share the eighteen others: row 0
+        // lanes 9..15 take c = 0..6, row 1 lanes 9, 10 take c = 7, 8.  No copy of the inverse for a product, no product: the
+        // block's critical path loses two LDS round trips and the two rounds of the 81-entry product.
+        const int li = lane & 15, rw = lane >> 4;
+        const int j = li < 9 ? li : 8;
+        const int cidx = li - 9 + (rw == 0 ? 0 : 7);
+        const bool ccol = wmode != 0 && li >= 9 && ((rw == 0) || (rw == 1 && li < 11));
+        const int kw = wmode == 1 ? k : k - 1;
+        double a[9];
+        if (ccol) {  // (two loops, not one pointer select: C may sit in the HBM slab while the scratch is LDS)
+            cdptr src = q.PA + kw * 81 + (wmode == 1 ? 9 * cidx : cidx);
+            const int st = wmode == 1 ? 1 : 9;
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[i] = src[st * i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[i] = ts[9 * i + j];
+        }
+#endif
         bool good = true;
         // pivot pv: every lane needs column pv (lane pv's registers).  The pivot itself goes through one
         // v_readlane pair; the other eight entries are consumed straight from lane pv by the update FMA
@@ -1213,7 +1290,7 @@ DEKF_FN bool solve_factor(Q& q) {
         // Own lane: base 0 through a multiplication by `keep` (one f64 multiply instead of two 32-bit selects).
 #define DEKF_GJ_PIVOT(PV, NX)                                                    \
         {                                                                        \
-            const bool own = lane == PV;                                         \
+            const bool own = li == PV;                                           \
             const double keep = own ? 0.0 : 1.0;                                 \
             const double m = own ? d : a[PV] * d;                                \
             if (NX < 9) {                                                        \
@@ -1239,6 +1316,7 @@ DEKF_FN bool solve_factor(Q& q) {
 #undef DEKF_GJ_UPD
 #undef DEKF_GJ_PIVOT
 #undef DEKF_GJ_DPP
+#ifdef DEKF_X_LDL_W_PRODUCT
         wave_sync();  // every lane has read its column of S
         if (lane < 9) {
             // column j of the inverse: to the scratch copy for the W product and to S^-1[k] (full 9x9: a row is
@@ -1264,6 +1342,21 @@ DEKF_FN bool solve_factor(Q& q) {
                 q.Wk[kw * 81 + p] = s0 + (s1 + s2);
             }
         }
+#else
+        if (li < 9 && rw == 0) {
+            // column j of the inverse to S^-1[k] (full 9x9: a row is contiguous, so the solve phases address it with immediates
+            // instead of packed-index arithmetic); the meeting block also leaves it in the scratch for the joint middle
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                q.Sinv[k * 81 + 9 * i + j] = a[i];
+                if (wmode == 0) ts[9 * i + j] = a[i];
+            }
+        }
+        if (ccol) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) q.Wk[kw * 81 + 9 * cidx + t] = a[t];
+        }
+#endif
         wave_sync();
         return good;
     };

@@ -144,6 +144,24 @@ DEKF_FN double wave_max(double v) {
     v = dpp_max_step<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the wave's maximum
     return readlane_f64(v, 63);
 }
+// Wave-wide sum by DPP (row_shr 1, 2, 4, 8 inside the rows, row_bcast 15 / 31 across them; a lane without a source adds 0), every
+// lane gets lane 63's total.  Deterministic, but not the association of the butterfly in wave_sum below.
+template <int CTRL, int ROW_MASK>
+DEKF_FN double dpp_add_step(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
+DEKF_FN double wave_sum_dpp(double v) {
+    v = dpp_add_step<0x111, 0xF>(v);
+    v = dpp_add_step<0x112, 0xF>(v);
+    v = dpp_add_step<0x114, 0xF>(v);
+    v = dpp_add_step<0x118, 0xF>(v);
+    v = dpp_add_step<0x142, 0xA>(v);
+    v = dpp_add_step<0x143, 0xC>(v);
+    return readlane_f64(v, 63);
+}
 DEKF_FN double wave_sum(double v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
