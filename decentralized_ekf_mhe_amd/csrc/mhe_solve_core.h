@@ -309,8 +309,14 @@ DEKF_FN void solve_scale(Q& q) {
         if (td < 2 * ntd) { bool vo = td >= ntd; kind = vo ? 3 : 2; k = (td - (vo ? ntd : 0)) * 64 + lane; sub = 0; return k < K1; }
         td -= 2 * ntd;
         if (td < 3 * ntx) {
-            int ck = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2);
-            int e = (td - ck * ntx) * 64 + lane;
+#ifdef DEKF_X_RUIZ_COLS_PVB  // (A/B: column tiles in the order position, velocity, bias)
+            int pos = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2), ck = pos;
+#else
+            // column tiles in the order velocity, position, bias: with one tile per kind (K <= 21) the wavefront that owns the Dyn
+            // lane pairs — the longest row tile — then also gets the position columns, the shortest column tile
+            int pos = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2), ck = pos == 0 ? 1 : (pos == 1 ? 0 : 2);
+#endif
+            int e = (td - pos * ntx) * 64 + lane;
             kind = 4 + ck; k = e / 3; sub = e - 3 * k;
             return e < 3 * K;
         }
@@ -591,9 +597,11 @@ DEKF_FN void solve_scale(Q& q) {
             for (int a = 0; a < 3; ++a)
 #pragma unroll
                 for (int t = 0; t < 6; ++t) {
-                    const double p0 = q21[a < t ? symidx(a, t, 6) : symidx(t, a, 6)];
-                    const double p1 = q21[3 + a < t ? symidx(3 + a, t, 6) : symidx(t, 3 + a, 6)];
-                    pq[a][t] = sub ? p1 : p0;
+                    // ONE load per entry: the lane's half (position / velocity rows) selects the INDEX (a 32-bit select of two
+                    // constants), not one of two loaded values — 18 LDS reads instead of 36 in the longest tile of a pass
+                    const int i0 = a < t ? symidx(a, t, 6) : symidx(t, a, 6);
+                    const int i1 = 3 + a < t ? symidx(3 + a, t, 6) : symidx(t, 3 + a, 6);
+                    pq[a][t] = q21[sub ? i1 : i0];
                 }
 #pragma unroll
             for (int a = 0; a < 3; ++a) {
@@ -697,7 +705,12 @@ DEKF_FN void solve_scale(Q& q) {
                 for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * mj[t] * dt9[t]));
                 // pc of column j of x_0 is read by the wavefront that owns the column's tile (lane j % 3 of the first tile of
                 // kind j / 3) in ITS next pass: that wavefront stores it (LDS serves a wavefront's accesses in order)
-                if (ln < 9 && ((ntm + ntp + 2 * ntd + (j / 3) * ntx) & (DEKF_NLANES() / WAVE - 1)) == wv) pc[j] = v;
+#ifdef DEKF_X_RUIZ_COLS_PVB
+                const int cpos = j / 3;
+#else
+                const int cpos = j < 3 ? 1 : (j < 6 ? 0 : 2);  // (the order of the column tiles: velocity, position, bias)
+#endif
+                if (ln < 9 && ((ntm + ntp + 2 * ntd + cpos * ntx) & (DEKF_NLANES() / WAVE - 1)) == wv) pc[j] = v;
                 const double x0 = wave_sum_dpp(ln < 9 ? v : 0.0);
                 const int nw = DEKF_NLANES() >> 6;
                 double tot = part[0];
