@@ -1216,12 +1216,19 @@ DEKF_FN bool solve_factor(Q& q) {
     (void)nph; (void)bufs; (void)gj_step; (void)pivot_ok; (void)store_sinv; (void)build_s;
     // S of block k, element p (device form: three independent accumulators per sum, no symmetrisation —
     // W C' = C S^-1 C' is symmetric up to rounding and the Gauss-Jordan sweep does not need more)
-    auto build_s3 = [&](int k, bool use_top, bool use_bot, int p, dptr dst) -> double {
+#ifdef DEKF_X_LDL_NO_TW  // (A/B: every block reads its predecessor's W from the slab)
+    constexpr bool W_DIRECT = true;
+#else
+    constexpr bool W_DIRECT = Q::FACTOR_LDS;
+#endif
+    // twp / twh: with the factor in the HBM slab, the LDS copies of W_{k-1} / W^_k that the previous block of the leg left behind
+    // (a block must not wait for its predecessor's W to travel to L2 and back: 2-3 us per block of a PogoX window)
+    auto build_s3 = [&](int k, bool use_top, bool use_bot, int p, dptr dst, cdptr twp, cdptr twh) -> double {
         const int i = p / 9, j = p - 9 * i;
         const int lo_ = i < j ? i : j, hi_ = i < j ? j : i;
         double acc = q.Sinv[k * 81 + 9 * lo_ + hi_];
         if (use_top) {
-            cdptr Wp = q.Wk + (k - 1) * 81 + 9 * i;
+            cdptr Wp = (W_DIRECT ? q.Wk + (k - 1) * 81 : twp) + 9 * i;
             cdptr Cp = q.PA + (k - 1) * 81 + 9 * j;
             double s0 = Wp[0] * Cp[0] + Wp[3] * Cp[3] + Wp[6] * Cp[6];
             double s1 = Wp[1] * Cp[1] + Wp[4] * Cp[4] + Wp[7] * Cp[7];
@@ -1229,7 +1236,7 @@ DEKF_FN bool solve_factor(Q& q) {
             acc -= s0 + (s1 + s2);
         }
         if (use_bot) {
-            cdptr Wh = q.Wk + k * 81 + 9 * i;
+            cdptr Wh = (W_DIRECT ? q.Wk + k * 81 : twh) + 9 * i;
             cdptr Ck = q.PA + k * 81 + j;
             double s0 = Wh[0] * Ck[0] + Wh[3] * Ck[27] + Wh[6] * Ck[54];
             double s1 = Wh[1] * Ck[9] + Wh[4] * Ck[36] + Wh[7] * Ck[63];
@@ -1239,20 +1246,51 @@ DEKF_FN bool solve_factor(Q& q) {
         dst[p] = acc;
         return acc;
     };
-    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, dptr tb) -> bool {
-        // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]
+    // Slab-resident factor: what an entry of S_k needs from the slab — T_kk(i, j) and the nine entries of row / column j of the
+    // coupling block — is requested one block AHEAD (the leg loops below), so that the loads travel while the previous block is
+    // being inverted; the W rows come from the LDS copy.  Same arithmetic, same order as build_s3.
+    struct SOps { double t, c[9]; };
+    auto s_entry = [&](int e, int& i, int& j) {
+        i = (e >= 9) + (e >= 17) + (e >= 24) + (e >= 30) + (e >= 35) + (e >= 39) + (e >= 42) + (e >= 44);
+        j = e - (9 * i - ((i * (i - 1)) >> 1)) + i;
+    };
+    auto s_ops_load = [&](int k, bool use_top, SOps& o) {  // use_top: a block of the top leg (k > 0), else of the bottom leg (k < K - 1)
+        const int e = (DEKF_LANE() & 63) < 45 ? (DEKF_LANE() & 63) : 44;
+        int i, j;
+        s_entry(e, i, j);
+        o.t = q.Sinv[k * 81 + 9 * i + j];
+        cdptr cp = use_top ? q.PA + (k - 1) * 81 + 9 * j : q.PA + k * 81 + j;
+        const int st = use_top ? 1 : 9;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) o.c[t] = cp[st * t];
+    };
+    auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, dptr tb, cdptr twp, cdptr twh, dptr two, const SOps* po = nullptr) -> bool {
+        // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]; two: where the LDS
+        // copy of that W block goes when the factor itself lives in the HBM slab
         const int lane = DEKF_LANE() & 63;
         dptr ts = tb;        // S, then the full inverse
 #ifdef DEKF_X_LDL_FULL_S  // (A/B: all 81 entries of S, two rounds of the wavefront)
-        for (int p = lane; p < 81; p += WAVE) (void)build_s3(k, use_top, use_bot, p, ts);
+        for (int p = lane; p < 81; p += WAVE) (void)build_s3(k, use_top, use_bot, p, ts, twp, twh);
 #else
         // S is symmetric (T_kk exactly, the Schur terms up to rounding): its 45 upper entries in ONE round of the wavefront,
         // each stored to both places (the Gauss-Jordan sweep below reads columns)
         if (lane < 45) {
-            const int e = lane;
-            const int i = (e >= 9) + (e >= 17) + (e >= 24) + (e >= 30) + (e >= 35) + (e >= 39) + (e >= 42) + (e >= 44);
-            const int j = e - (9 * i - ((i * (i - 1)) >> 1)) + i;
-            ts[9 * j + i] = build_s3(k, use_top, use_bot, 9 * i + j, ts);
+            int i, j;
+            s_entry(lane, i, j);
+            if (po && (use_top != use_bot)) {  // operands prefetched by the leg loop
+                cdptr Wr = (use_top ? twp : twh) + 9 * i;
+                const double s0 = Wr[0] * po->c[0] + Wr[3] * po->c[3] + Wr[6] * po->c[6];
+                const double s1 = Wr[1] * po->c[1] + Wr[4] * po->c[4] + Wr[7] * po->c[7];
+                const double s2 = Wr[2] * po->c[2] + Wr[5] * po->c[5] + Wr[8] * po->c[8];
+                const double acc = po->t - (s0 + (s1 + s2));
+                ts[9 * i + j] = acc;
+                ts[9 * j + i] = acc;
+            } else if (po) {  // first block of a leg: T_kk alone
+                ts[9 * i + j] = po->t;
+                ts[9 * j + i] = po->t;
+            } else {
+                ts[9 * j + i] = build_s3(k, use_top, use_bot, 9 * i + j, ts, twp, twh);
+            }
         }
 #endif
         wave_sync();
@@ -1368,6 +1406,10 @@ DEKF_FN bool solve_factor(Q& q) {
         if (ccol) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) q.Wk[kw * 81 + 9 * cidx + t] = a[t];
+            if constexpr (!W_DIRECT) {
+#pragma unroll
+                for (int t = 0; t < 9; ++t) two[9 * cidx + t] = a[t];
+            }
         }
 #endif
         wave_sync();
@@ -1382,19 +1424,39 @@ DEKF_FN bool solve_factor(Q& q) {
     two_waves(
         [&] {
             bool g = true;
-            for (int k = 0; k < mid; ++k) g = factor_block(k, k > 0, false, 1, q.tmp) && g;
+            if constexpr (W_DIRECT) {
+                for (int k = 0; k < mid; ++k) g = factor_block(k, k > 0, false, 1, q.tmp, q.tmp + 81, q.tmp + 81, q.tmp + 81) && g;
+            } else {
+                SOps nx;
+                if (mid > 0) s_ops_load(0, false, nx);  // (block 0 has no Schur term: only its T entry is used)
+                for (int k = 0; k < mid; ++k) {
+                    const SOps cu = nx;
+                    if (k + 1 < mid) s_ops_load(k + 1, true, nx);
+                    g = factor_block(k, k > 0, false, 1, q.tmp, q.tmp + 81, q.tmp + 81, q.tmp + 81, &cu) && g;
+                }
+            }
             if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
         },
         [&] {
             bool g = true;
-            for (int k = K - 1; k > mid; --k) g = factor_block(k, false, k < K - 1, 2, q.tmp + 176) && g;
+            if constexpr (W_DIRECT) {
+                for (int k = K - 1; k > mid; --k) g = factor_block(k, false, k < K - 1, 2, q.tmp + 176, q.tmp + 257, q.tmp + 257, q.tmp + 257) && g;
+            } else {
+                SOps nx;
+                if (K - 1 > mid) s_ops_load(K - 1, true, nx);  // (block K - 1 has no Schur term; `true` only keeps the address in range)
+                for (int k = K - 1; k > mid; --k) {
+                    const SOps cu = nx;
+                    if (k - 1 > mid) s_ops_load(k - 1, false, nx);
+                    g = factor_block(k, false, k < K - 1, 2, q.tmp + 176, q.tmp + 257, q.tmp + 257, q.tmp + 257, &cu) && g;
+                }
+            }
             if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
         });
     DEKF_SYNC();
     DEKF_PROF_MARK(q, 22);
     two_waves(
         [&] {
-            bool g = factor_block(mid, mid > 0, mid < K - 1, 0, q.tmp);
+            bool g = factor_block(mid, mid > 0, mid < K - 1, 0, q.tmp, q.tmp + 81, q.tmp + 257, q.tmp + 81);
             if (!g && (DEKF_LANE() & 63) == 0) *fail = 1.0;
             // JOINT MIDDLE for the fixed-horizon one-wavefront solve (sweeps_one_wave): blocks m and m + 1 are solved together,
             //   [u_m; u_{m+1}] = [P11 P12; P12' P22] [f_m; f^_{m+1}],   P11 = S_m^-1 (just computed),
