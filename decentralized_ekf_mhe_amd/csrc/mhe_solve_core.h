@@ -811,12 +811,16 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
                 const int i = p / NS, j = p - NS * i;
                 cdptr wr = W + NS * i;
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+                // C couples the base states among themselves (9 x 9) and every foot with itself (3 x 3): row / column j of C is
+                // exactly zero outside [t0, t1) (solve_factor 3b-3c writes those zeros), so only that range is summed — in the
+                // same three accumulators, i.e. bit-identical to the full sum: 5.6 products per entry instead of 21
+                const int t0 = j < 9 ? 0 : 9 + 3 * ((j - 9) / 3), t1 = j < 9 ? 9 : t0 + 3;
                 if (top) {  // W_{k-1} C_{k-1}'
                     cdptr cr = C + NS * j;
-                    for (int t = 0; t + 2 < NS; t += 3) { s0 += wr[t] * cr[t]; s1 += wr[t + 1] * cr[t + 1]; s2 += wr[t + 2] * cr[t + 2]; }
+                    for (int t = t0; t < t1; t += 3) { s0 += wr[t] * cr[t]; s1 += wr[t + 1] * cr[t + 1]; s2 += wr[t + 2] * cr[t + 2]; }
                 } else {    // What_k C_k
                     cdptr cc = C + j;
-                    for (int t = 0; t + 2 < NS; t += 3) { s0 += wr[t] * cc[NS * t]; s1 += wr[t + 1] * cc[NS * (t + 1)]; s2 += wr[t + 2] * cc[NS * (t + 2)]; }
+                    for (int t = t0; t < t1; t += 3) { s0 += wr[t] * cc[NS * t]; s1 += wr[t + 1] * cc[NS * (t + 1)]; s2 += wr[t + 2] * cc[NS * (t + 2)]; }
                 }
                 ts[p] -= s0 + (s1 + s2);
             }
@@ -828,25 +832,47 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
         wave_sync();
         bool good;
 #if DEKF_DEVICE_BUILD
+        // AUGMENTED sweep (as in the 9-state form, solve_factor 3d): lanes NS .. 2 NS - 1 carry the columns of C' (W_k = C_k S^-1: row c
+        // of C) or of C (W^_{k-1} = C_{k-1}' S^-1: column c); the sweep turns a column v into S^-1 v = row c of the W block with the
+        // instructions every lane executes anyway (the pivot column travels by v_readlane, i.e. to all 64 lanes) — no product.
+        constexpr bool AUG = 2 * NS <= WAVE;
         {
             const int j = lane < NS ? lane : NS - 1;
+            const int kw_ = wmode == 1 ? k : k - 1;
+            const bool ccol = AUG && wmode != 0 && lane >= NS && lane < 2 * NS;
+            const int cidx = ccol ? lane - NS : 0;
             double a[NS];
+            if (ccol) {
+                cdptr src = q.PA + kw_ * NS2 + (wmode == 1 ? NS * cidx : cidx);
+                const int cst = wmode == 1 ? 1 : NS;
 #pragma unroll
-            for (int i = 0; i < NS; ++i) a[i] = ts[NS * i + j];
+                for (int i = 0; i < NS; ++i) a[i] = src[cst * i];
+            } else {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) a[i] = ts[NS * i + j];
+            }
             good = gj_columns<NS>(a, lane);
             wave_sync();  // every lane has read its column of S
             if (lane < NS) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) ts[NS * i + lane] = a[i];
             }
+            if (ccol) {
+#pragma unroll
+                for (int t = 0; t < NS; ++t) {
+                    if (staged) wa[NS * cidx + t] = a[t];
+                    q.Wk[kw_ * NS2 + NS * cidx + t] = a[t];
+                }
+            }
         }
 #else
+        constexpr bool AUG = false;
         good = winverse_definite(ts, NS, ts + NS2);
 #endif
         if (staged && wmode != 0) copy_panel(ca, q.PA + (wmode == 1 ? k : k - 1) * NS2);
         wave_sync();
         copy_panel(q.Sinv + k * NS2, ts);
-        if (wmode != 0) {
+        if (wmode != 0 && !AUG) {
             const int kw = wmode == 1 ? k : k - 1;
             cdptr cs0 = staged ? ca : q.PA + kw * NS2;
             for (int p = l0; p < NS2; p += st) {
