@@ -742,6 +742,11 @@ DEKF_FN void sweep_mid_block_generic(Q& q, int lane, double alpha) {
     dptr ft = q.tmp + TmpMap<NS>::SIDE0;  // factor-time scratch, free during the iterations
 #if DEKF_DEVICE_BUILD
     const int i = lane < NS ? lane : NS - 1;
+    // row i of S_m^-1 is requested FIRST: it does not depend on the product in front of it, and with the factor in the HBM slab the
+    // two dependent mat-vecs otherwise pay two memory round trips (the fence between them keeps the compiler from hoisting the loads)
+    double si[NS];
+#pragma unroll
+    for (int t = 0; t < NS; ++t) si[t] = Si[NS * i + t];
     double f = xs[NS * mid + i];
     if (mid < K - 1) {
         cdptr W = q.Wk + mid * NS2 + NS * i;
@@ -755,7 +760,7 @@ DEKF_FN void sweep_mid_block_generic(Q& q, int lane, double alpha) {
     wave_sync();
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
 #pragma unroll
-    for (int t = 0; t + 2 < NS; t += 3) { a0 += Si[NS * i + t] * ft[t]; a1 += Si[NS * i + t + 1] * ft[t + 1]; a2 += Si[NS * i + t + 2] * ft[t + 2]; }
+    for (int t = 0; t + 2 < NS; t += 3) { a0 += si[t] * ft[t]; a1 += si[t + 1] * ft[t + 1]; a2 += si[t + 2] * ft[t + 2]; }
     const double u = a0 + (a1 + a2);
     if (lane < NS) {
         const int xi = mid * SV + i;

@@ -649,7 +649,11 @@ DEKF_FN void solve_scale(Q& q) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) gq[j] = g[j];
 #if DEKF_DEVICE_BUILD
+#ifdef DEKF_X_RUIZ_3BARRIERS
     if constexpr (FT == 0) {
+#else
+    {
+#endif
         // One Ruiz pass = ONE tile phase (equilibrate + the new column norms of the owned slack blocks, ping-pong between the two
         // pairs of scaling vectors instead of a copy), a barrier, the nine x_0 lanes' arrival-cost norms, the sum.  Same
         // arithmetic, same lanes, same order of the sum as the two-phase form below (which the lane-sequential build and the
@@ -696,13 +700,18 @@ DEKF_FN void solve_scale(Q& q) {
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
                 tr2 = clock64();
 #endif
-                const int j = ln < 9 ? ln : 8;
+                const int j = ln < NS ? ln : NS - 1;
                 const double dj = Dw[j];
-                double mj[9], dt9[9], v = 0.0;
+                double v = 0.0;
+                if constexpr (FT) {
+                    for (int t = 0; t < NS; ++t) v = dmax(v, fabs(dj * symget(Mst, j, t, NS) * Dw[t]));
+                } else {
+                    double mj[9], dt9[9];
 #pragma unroll
-                for (int t = 0; t < 9; ++t) { mj[t] = symget(Mst, j, t, 9); dt9[t] = Dw[t]; }
+                    for (int t = 0; t < 9; ++t) { mj[t] = symget(Mst, j, t, 9); dt9[t] = Dw[t]; }
 #pragma unroll
-                for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * mj[t] * dt9[t]));
+                    for (int t = 0; t < 9; ++t) v = dmax(v, fabs(dj * mj[t] * dt9[t]));
+                }
                 // pc of column j of x_0 is read by the wavefront that owns the column's tile (lane j % 3 of the first tile of
                 // kind j / 3) in ITS next pass: that wavefront stores it (LDS serves a wavefront's accesses in order)
 #ifdef DEKF_X_RUIZ_COLS_PVB
@@ -710,8 +719,10 @@ DEKF_FN void solve_scale(Q& q) {
 #else
                 const int cpos = j < 3 ? 1 : (j < 6 ? 0 : 2);  // (the order of the column tiles: velocity, position, bias)
 #endif
-                if (ln < 9 && ((ntm + ntp + 2 * ntd + cpos * ntx) & (DEKF_NLANES() / WAVE - 1)) == wv) pc[j] = v;
-                const double x0 = wave_sum_dpp(ln < 9 ? v : 0.0);
+                // (a foot-position column of x_0 sits in lane j - 9 of the first foot-column tile)
+                const int otile = j < 9 ? ntm + ntp + 2 * ntd + cpos * ntx : ntm + ntp + 2 * ntd + 3 * ntx + ntf;
+                if (ln < NS && (otile & (DEKF_NLANES() / WAVE - 1)) == wv) pc[j] = v;
+                const double x0 = wave_sum_dpp(ln < NS ? v : 0.0);
                 const int nw = DEKF_NLANES() >> 6;
                 double tot = part[0];
                 for (int i = 1; i < nw; ++i) tot += part[i];
