@@ -120,6 +120,13 @@ def main():
             ok &= case(f"go1 leg_odom_type 1, 32 x 2000 ticks of a 5 Hz gait, arrival cost in {label}",
                        go1_params, 32, 2000, th, stream_kw=dict(gait_hz=5.0), oracle_key="type1-long", leg_odom_type=1, arrival_cost_form=form)
         sys.exit(0 if ok else 1)
+    if len(sys.argv) > 1 and sys.argv[1] == "soak":
+        # long runs of the benchmark shapes: every tick of 5000 (Go1, Cassie) against the oracle — drift, a rare failed solve or an
+        # iteration count that differs would show here and nowhere else
+        ok &= case("go1 N=20, 48 x 5000 ticks", go1_params, 48, 5000, th)
+        ok &= case("cassie N=20, 32 x 5000 ticks", cassie_params, 32, 5000, th)
+        ok &= case("go1 N=20 with osqp.polish, 32 x 1500 ticks", go1_params, 32, 1500, th, polish=1)
+        sys.exit(0 if ok else 1)
     ok &= case("go1 N=20 (BASELINE configs[1] shape)", go1_params, 256, 400, th)
     ok &= case("go1 N=20, KF mode", go1_params, 64, 200, th, est_type=1)
     ok &= case("cassie N=20", cassie_params, 128, 200, th)
