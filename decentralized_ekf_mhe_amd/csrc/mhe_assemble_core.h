@@ -336,6 +336,27 @@ DEKF_FN bool gj_columns(double (&a)[N], int lane) {
     return ok;
 }
 
+// The same sweep WITHOUT the in-place handling of the pivot column: every lane runs the plain elimination a_i -= s_ip (a_p / s_pp).
+// For a caller that lets the columns of the identity ride along in other lanes (they end as the columns of the inverse; the lanes
+// that hold the matrix itself end as junk): two selects less per row and pivot.
+template <int N>
+DEKF_FN bool gj_columns_plain(double (&a)[N], int lane) {
+    (void)lane;
+    bool ok = true;
+    for (int p = 0; p < N; ++p) {
+        const double piv = readlane_f64(a[0], p);
+        if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) { ok = false; break; }  // wave-uniform
+        const double rd = a[0] * rcp_fast(piv);
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            const double ci = readlane_f64(a[i], p);
+            a[i - 1] = fma(-ci, rd, a[i]);
+        }
+        a[N - 1] = rd;
+    }
+    return ok;
+}
+
 // column j (0..5) of the 6x6 process covariance G C G' of a step with rotation R (the matrix step_gains inverts)
 DEKF_FN void cov6_column(const DevCfg& c, const double* R, int j, double (&col)[6]) {
     const double dt = c.dt;

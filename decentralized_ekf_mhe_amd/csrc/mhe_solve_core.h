@@ -852,6 +852,11 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
             const int kw_ = wmode == 1 ? k : k - 1;
             const bool ccol = AUG && wmode != 0 && lane >= NS && lane < 2 * NS;
             const int cidx = ccol ? lane - NS : 0;
+            // ... and, when they fit too, the columns of the identity (lanes 2 NS .. 3 NS - 1), which end as the columns of S^-1: the
+            // sweep then needs no in-place handling of the pivot column (gj_columns_plain)
+            constexpr bool IDC = AUG && 3 * NS <= WAVE;
+            const bool icol = IDC && lane >= 2 * NS && lane < 3 * NS;
+            const int ic = icol ? lane - 2 * NS : 0;
             double a[NS];
             if (ccol) {
                 cdptr src = q.PA + kw_ * NS2 + (wmode == 1 ? NS * cidx : cidx);
@@ -862,11 +867,17 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) a[i] = ts[NS * i + j];
             }
-            good = gj_columns<NS>(a, lane);
-            wave_sync();  // every lane has read its column of S
-            if (lane < NS) {
+            if (icol) {
 #pragma unroll
-                for (int i = 0; i < NS; ++i) ts[NS * i + lane] = a[i];
+                for (int i = 0; i < NS; ++i) a[i] = i == ic ? 1.0 : 0.0;
+            }
+            if constexpr (IDC) good = gj_columns_plain<NS>(a, lane);
+            else good = gj_columns<NS>(a, lane);
+            wave_sync();  // every lane has read its column of S
+            if (IDC ? icol : lane < NS) {
+                const int jc = IDC ? ic : lane;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) ts[NS * i + jc] = a[i];
             }
             if (ccol) {
 #pragma unroll
@@ -1349,6 +1360,16 @@ DEKF_FN bool solve_factor(Q& q) {
         const int cidx = li - 9 + (rw == 0 ? 0 : 7);
         const bool ccol = wmode != 0 && li >= 9 && ((rw == 0) || (rw == 1 && li < 11));
         const int kw = wmode == 1 ? k : k - 1;
+        // ... and the nine columns of the IDENTITY ride along too (row 1 lanes 11..15: c = 0..4, row 2 lanes 9..12: c = 5..8): they end
+        // as the columns of S^-1, so the sweep needs no in-place handling of the pivot column (a multiplication by 0 / 1 and a select
+        // per row and pivot): every lane runs the plain elimination a_i -= s_ip (a_p / s_pp).  Same values as the in-place form.
+#ifdef DEKF_X_LDL_INPLACE
+        const bool icol = false;
+        const int ic = 0;
+#else
+        const bool icol = (rw == 1 && li >= 11) || (rw == 2 && li >= 9 && li <= 12);
+        const int ic = rw == 1 ? li - 11 : li - 9 + 5;
+#endif
         double a[9];
         if (ccol) {  // (two loops, not one pointer select: C may sit in the HBM slab while the scratch is LDS)
             cdptr src = q.PA + kw * 81 + (wmode == 1 ? 9 * cidx : cidx);
@@ -1359,6 +1380,10 @@ DEKF_FN bool solve_factor(Q& q) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) a[i] = ts[9 * i + j];
         }
+        if (icol) {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) a[i] = i == ic ? 1.0 : 0.0;
+        }
 #endif
         bool good = true;
         // pivot pv: every lane needs column pv (lane pv's registers).  The pivot itself goes through one
@@ -1367,18 +1392,28 @@ DEKF_FN bool solve_factor(Q& q) {
         // column is -col * d.  Two wait states between the VALU write of a[i] and its DPP read: the s_nop.
 #define DEKF_GJ_DPP(acc, src, mul, PV) \
     asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:" #PV " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul))
+#if defined(DEKF_X_LDL_INPLACE) || defined(DEKF_X_LDL_W_PRODUCT)
 #define DEKF_GJ_UPD(I, PV)                                                       \
             {                                                                    \
                 double t = a[I] * keep;                                          \
                 DEKF_GJ_DPP(t, a[I], m, PV);                                     \
                 a[I] = t;                                                        \
             }
+#define DEKF_GJ_OWN(PV) (li == PV)
+#else
+#define DEKF_GJ_UPD(I, PV)                                                       \
+            {                                                                    \
+                (void)keep;                                                      \
+                DEKF_GJ_DPP(a[I], a[I], m, PV);                                  \
+            }
+#define DEKF_GJ_OWN(PV) false
+#endif
         // The row that holds the NEXT pivot is updated first and its reciprocal started at once, so that the
         // v_rcp + Newton chain runs underneath the seven remaining (quarter-rate) DPP FMAs of this pivot.
         // Own lane: base 0 through a multiplication by `keep` (one f64 multiply instead of two 32-bit selects).
 #define DEKF_GJ_PIVOT(PV, NX)                                                    \
         {                                                                        \
-            const bool own = li == PV;                                           \
+            const bool own = DEKF_GJ_OWN(PV);                                    \
             const double keep = own ? 0.0 : 1.0;                                 \
             const double m = own ? d : a[PV] * d;                                \
             if (NX < 9) {                                                        \
@@ -1402,6 +1437,7 @@ DEKF_FN bool solve_factor(Q& q) {
         DEKF_GJ_PIVOT(0, 1) DEKF_GJ_PIVOT(1, 2) DEKF_GJ_PIVOT(2, 3) DEKF_GJ_PIVOT(3, 4) DEKF_GJ_PIVOT(4, 5)
         DEKF_GJ_PIVOT(5, 6) DEKF_GJ_PIVOT(6, 7) DEKF_GJ_PIVOT(7, 8) DEKF_GJ_PIVOT(8, 9)
 #undef DEKF_GJ_UPD
+#undef DEKF_GJ_OWN
 #undef DEKF_GJ_PIVOT
 #undef DEKF_GJ_DPP
 #ifdef DEKF_X_LDL_W_PRODUCT
@@ -1431,13 +1467,20 @@ DEKF_FN bool solve_factor(Q& q) {
             }
         }
 #else
-        if (li < 9 && rw == 0) {
-            // column j of the inverse to S^-1[k] (full 9x9: a row is contiguous, so the solve phases address it with immediates
+#ifdef DEKF_X_LDL_INPLACE
+        const bool inv_lane = li < 9 && rw == 0;
+        const int jc = j;
+#else
+        const bool inv_lane = icol;
+        const int jc = ic;
+#endif
+        if (inv_lane) {
+            // column jc of the inverse to S^-1[k] (full 9x9: a row is contiguous, so the solve phases address it with immediates
             // instead of packed-index arithmetic); the meeting block also leaves it in the scratch for the joint middle
 #pragma unroll
             for (int i = 0; i < 9; ++i) {
-                q.Sinv[k * 81 + 9 * i + j] = a[i];
-                if (wmode == 0) ts[9 * i + j] = a[i];
+                q.Sinv[k * 81 + 9 * i + jc] = a[i];
+                if (wmode == 0) ts[9 * i + jc] = a[i];
             }
         }
         if (ccol) {
