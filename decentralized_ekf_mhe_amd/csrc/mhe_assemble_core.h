@@ -408,13 +408,15 @@ DEKF_FN bool marginalize_regs(const DevCfg& c, const DevState& s, int b, const d
     const int j9 = lane < 9 ? lane : 8;
 
     // M^-1: lane j holds column j
+    // (both sweeps below carry the columns of the identity in other lanes — lanes 16..24 here, 32..32 + NA - 1 for S — which end as
+    // the columns of the inverse: gj_columns_plain, no in-place handling of the pivot column, two selects less per row and pivot)
     double m9[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) m9[i] = Mp[9 * i + j9];
-    bool ok = gj_columns<9>(m9, lane);
-    if (lane < 9) {
+    for (int i = 0; i < 9; ++i) m9[i] = (lane >= 16 && lane < 25) ? (i == lane - 16 ? 1.0 : 0.0) : Mp[9 * i + j9];
+    bool ok = gj_columns_plain<9>(m9, lane);
+    if (lane >= 16 && lane < 25) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Minv[9 * i + lane] = m9[i];
+        for (int i = 0; i < 9; ++i) Minv[9 * i + lane - 16] = m9[i];
     }
     DEKF_SYNC();
     // row `ia` of [A_dyn; A_cam] and of Am M^-1 (lanes < NA), M^-1 n (lanes < 9)
@@ -491,7 +493,13 @@ DEKF_FN bool marginalize_regs(const DevCfg& c, const DevState& s, int b, const d
         u[lane] = v;
     }
     DEKF_SYNC();
-    ok = gj_columns<DIM>(a, lane) && ok;
+    // only the columns 0 .. NA - 1 of S^-1 are used below: their identity columns ride along in lanes 32 .. 32 + NA - 1
+    const int jl = lane - 32;  // the column of S^-1 this lane ends up with (0 <= jl < NA)
+    if (jl >= 0 && jl < NA) {
+#pragma unroll
+        for (int i = 0; i < DIM; ++i) a[i] = i == jl ? 1.0 : 0.0;
+    }
+    ok = gj_columns_plain<DIM>(a, lane) && ok;
     // (S^-1 u)_j through column j (S^-1 is symmetric)
     double yu = 0;
 #pragma unroll
@@ -509,16 +517,16 @@ DEKF_FN bool marginalize_regs(const DevCfg& c, const DevState& s, int b, const d
 #pragma unroll
         for (int i = 0; i < 3; ++i) fold[i] += __shfl_down(a[9 + i], 9);
         const double yf = __shfl_down(yu, 9);
-        if (lane < 3) {
+        if (jl >= 0 && jl < 3) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) out[i] += fold[i];
             yu += yf;
         }
     }
-    if (lane < 9) {
+    if (jl >= 0 && jl < 9) {
 #pragma unroll
-        for (int i = 0; i < 9; ++i) Mp[9 * i + lane] = -out[i];
-        np[lane] = -yu;
+        for (int i = 0; i < 9; ++i) Mp[9 * i + jl] = -out[i];
+        np[jl] = -yu;
     }
     DEKF_SYNC();
     return ok;
