@@ -250,12 +250,15 @@ def _quat_to_euler(q):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("est_type", [0, 1])
-def test_replayed_nodes_reproduce_oracle_and_log(tmp_path, est_type):
+@pytest.mark.parametrize("est_type,polish", [(0, 0), (1, 0), (0, 1)])
+def test_replayed_nodes_reproduce_oracle_and_log(tmp_path, est_type, polish):
+    """polish = 1: osqp.polish as the node DECLARES it (EstSub.cpp:188; the Go1 parameter file turns it off) — the node core used to
+    refuse that at construction"""
     exe = _build(tmp_path, "go1_nodes_replay")
     p = go1_params()
     p.ekf_rate = p.rate  # one orien_sub tick per est_sub tick in this replay
     p.est_type = est_type
+    p.polish = polish
     K, GATE, TIME_INIT = 50, 9, 100.0  # est_sub starts on the tick after its 10th IMU message
     s = make_streams(p, 1, K)
     yaml_path = tmp_path / "params.yaml"
