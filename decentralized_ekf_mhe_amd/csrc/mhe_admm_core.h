@@ -1384,6 +1384,9 @@ struct RowRegsT {
     double z[KIND == 2 ? 3 : 1];
     double a[6];                                  // slack-block inverse: own 3x3 (symmetric, packed)
     double b[KIND == 1 ? 9 : (KIND == 2 ? 3 : 1)];  // kind 1: coupling to the partner lane; kind 2: upper bounds
+#ifndef DEKF_X_R_FROM_LDS
+    double rk[KIND == 1 ? 9 : 1];                 // kind 1: the step's rotation R_k (nine LDS reads per iteration otherwise)
+#endif
     DEKF_FN void apply(cdptr in, dptr out) const {
         double pin[3] = {0.0, 0.0, 0.0};
         if constexpr (KIND == 1) {
@@ -1495,6 +1498,10 @@ DEKF_FN void row_regs_load(Q& q, int lane, double sigma, RowRegsT<KIND>& t) {
     if constexpr (KIND == 1) {
         const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
         cdptr R = q.R + 9 * t.k;
+#ifndef DEKF_X_R_FROM_LDS
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.rk[i] = R[i];
+#endif
         double u[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -1527,9 +1534,14 @@ DEKF_FN void row_regs_iter(Q& q, RowRegsT<KIND>& t, double alpha, double sigma, 
     cdptr xk = q.xd + 9 * t.k;
     double ar[3], Rk[9];
     if constexpr (KIND == 1) {
+#ifndef DEKF_X_R_FROM_LDS
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Rk[i] = t.rk[i];
+#else
         cdptr R = q.R + 9 * t.k;
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rk[i] = R[i];
+#endif
         const bool vel = t.vel;
         const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
         const int o = vel ? 3 : 0;
@@ -1613,6 +1625,53 @@ DEKF_FN void xcols_tile_r3(Q& q, int kind, int lane, double sigma) {
     }
     q.xs[i] = fma(dv, g, fma(sigma, xv, -(k == 0 ? qv : 0.0)));
 }
+// The same tile with everything an iteration does not change in registers for a whole chunk (XKIND is a compile-time constant of
+// the worker's loop): the entry's index, its scaling D, the linear cost of x_0 and the row indices of the gather — 2 LDS reads and
+// the index arithmetic (a division by 3, the clamps at the window's ends) less per iteration, in the phase that the solve waits for.
+template <int XKIND>
+struct XcolRegs {
+    bool valid, hn, hp;
+    int i;        // entry of xb / xs
+    int r[4];     // XKIND 0: rd(kn, a), rv(kn, a), rd(kp, a), rv(kp, a); 1: rm(k, a), rd(kn, 3 + a), rd(kn, a), rd(kp, 3 + a); 2: rd(kn, 6 + a), 3 kn + a (gb), rd(kp, 6 + a)
+    double dv, q0;
+};
+template <int XKIND, class Q>
+DEKF_FN void xcols_regs_load(const Q& q, int lane, XcolRegs<XKIND>& x) {
+    const int K = q.K;
+    x.valid = lane < 3 * K;
+    const int ln = x.valid ? lane : 0;
+    const int k = ln / 3, a = ln - 3 * k, j = 3 * XKIND + a;
+    x.i = 9 * k + j;
+    x.hn = k < K - 1; x.hp = k > 0;
+    const int kn = x.hn ? k : 0, kp = x.hp ? k - 1 : 0;
+    if constexpr (XKIND == 0) { x.r[0] = q.ix.rd(kn, a); x.r[1] = q.ix.rv(kn, a); x.r[2] = q.ix.rd(kp, a); x.r[3] = q.ix.rv(kp, a); }
+    else if constexpr (XKIND == 1) { x.r[0] = q.ix.rm(k, a); x.r[1] = q.ix.rd(kn, 3 + a); x.r[2] = q.ix.rd(kn, a); x.r[3] = q.ix.rd(kp, 3 + a); }
+    else { x.r[0] = q.ix.rd(kn, 6 + a); x.r[1] = 3 * kn + a; x.r[2] = q.ix.rd(kp, 6 + a); x.r[3] = 0; }
+    x.dv = q.D[k * (21 + 3 * Q::LEGS) + j];
+    const double qv = (q.tmp + TmpMap<9>::QSL)[j];
+    x.q0 = k == 0 ? qv : 0.0;
+}
+template <int XKIND, class Q>
+DEKF_FN void xcols_regs_tile(Q& q, const XcolRegs<XKIND>& x, double sigma) {
+    if (!x.valid) return;
+    cdptr at = q.at;
+    const double xv = q.xb[x.i];
+    double g;
+    if constexpr (XKIND == 0) {  // (gather_pcol)
+        const double n0 = at[x.r[0]], n1 = at[x.r[1]], p0 = at[x.r[2]], p1 = at[x.r[3]];
+        g = (x.hn ? n0 + n1 : 0.0) - (x.hp ? p0 + p1 : 0.0);
+    } else if constexpr (XKIND == 1) {  // (gather_vcol)
+        const double n0 = at[x.r[1]], n1 = at[x.r[2]], p0 = at[x.r[3]];
+        double gm = 0.0;
+#pragma unroll
+        for (int leg = 0; leg < Q::LEGS; ++leg) gm += at[x.r[0] + 3 * leg];
+        g = gm + (x.hn ? n0 + q.c.dt * n1 : 0.0) - (x.hp ? p0 : 0.0);
+    } else {
+        const double n0 = at[x.r[0]], n1 = q.gb[x.r[1]], p0 = at[x.r[2]];
+        g = (x.hn ? n0 - n1 : 0.0) - (x.hp ? p0 : 0.0);
+    }
+    q.xs[x.i] = fma(x.dv, g, fma(sigma, xv, -x.q0));
+}
 template <int NF, class Q>
 DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
     constexpr int L = Q::LEGS, SV = 21 + 3 * L;
@@ -1656,11 +1715,19 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
             RowRegsT<KIND> t;
             row_regs_load<KIND>(q, lane, sigma, t);
             DEKF_SYNC();  // B0
-            const int xkind = KIND == 0 ? 1 : (KIND == 1 ? 2 : 0);  // velocity columns (the longest gather) next to the shortest row tile
+            constexpr int xkind = KIND == 0 ? 1 : (KIND == 1 ? 2 : 0);  // velocity columns (the longest gather) next to the shortest row tile
             const bool cold = q.cold;
+#ifndef DEKF_X_XCOLS_RELOAD
+            XcolRegs<xkind> xc;
+            xcols_regs_load<xkind>(q, lane, xc);
+#endif
             for (int it = 0; it < iters; ++it) {
                 DEKF_R3_T(t0);
+#ifndef DEKF_X_XCOLS_RELOAD
+                xcols_regs_tile<xkind>(q, xc, sigma);
+#else
                 xcols_tile_r3(q, xkind, lane, sigma);
+#endif
 #if defined(DEKF_PROFILE_TL)
                 __builtin_amdgcn_s_waitcnt(0);
 #endif
