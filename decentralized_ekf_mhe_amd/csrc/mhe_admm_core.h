@@ -369,11 +369,14 @@ DEKF_FN double rows01_from_rows23(double v) {  // [r0 r1 r2 r3] -> [r2 r3 r2 r3]
 // source from rows 0 and 1 through v_permlane32_swap.  Then the meeting block in row 0 (f^_{m+1} comes over
 // from row 1 by v_permlane16_swap), u_m is copied to row 1, and rows 0 and 1 substitute outwards.
 // Needs an even compile-time horizon (both forward legs equally long) and the full window.
+// lane_in >= 0: the caller's lane id, read ONCE outside its iteration loop (the three-workgroup kernels' solve loop): the per-lane
+// pointers and strides below are then loop-invariant for the compiler, which may keep them in registers across the iterations —
+// this wavefront's loop holds nothing else.  (Everywhere else the lane id stays opaque at every use, see DEKF_LANE.)
 template <int NF, class Q>
-DEKF_FN void sweeps_one_wave(Q& q, double alpha) {
+DEKF_FN void sweeps_one_wave(Q& q, double alpha, int lane_in = -1) {
     constexpr int SV = 21 + 3 * Q::LEGS, K = NF, M = mid_block(NF);
     static_assert(NF % 2 == 0 && K - 2 - M == M, "equal forward legs");
-    const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15;
+    const int lane = lane_in >= 0 ? lane_in : (DEKF_LANE() & 63), row = lane >> 4, li = lane & 15;
     const int i = li < 9 ? li : 8;
     const bool act = li < 9, leg = row < 2, top = (row & 1) == 0;
     // the x blocks of x and D: inside the full variable vector (stride SV per step), or compact (R3: [K][9] in LDS)
@@ -1695,7 +1698,11 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
             DEKF_SYNC();  // B1
             DEKF_R3_T(t1);
             __builtin_amdgcn_s_setprio(3);
+#ifdef DEKF_X_SOLVE_LANE_OPAQUE
             sweeps_one_wave<NF>(q, alpha);
+#else
+            sweeps_one_wave<NF>(q, alpha, lane);
+#endif
             __builtin_amdgcn_s_setprio(0);
 #if defined(DEKF_PROFILE_TL)
             __builtin_amdgcn_s_waitcnt(0);
