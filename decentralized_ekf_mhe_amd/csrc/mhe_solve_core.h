@@ -659,13 +659,21 @@ DEKF_FN void solve_scale(Q& q) {
         // arithmetic, same lanes, same order of the sum as the two-phase form below (which the lane-sequential build and the
         // foot-state shapes keep): bit-identical D, E, c.
         dptr Dr = D, Er = E, Dw = Dn, Ew = En;
+        // (lane and wavefront are read ONCE in front of the passes: what a tile's lane derives from them — its block, the indices,
+        // the constants it loads — is then loop-invariant for the compiler)
+        const int rz_lane = DEKF_LANE() & 63, rz_wave = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), rz_nw = DEKF_NLANES() > WAVE ? DEKF_NLANES() >> 6 : 1;
+        (void)rz_lane; (void)rz_wave; (void)rz_nw;
         for (int it = 0; it < q.c.scaling; ++it) {
             const double cc = q.cc;
             double psum = 0.0;
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)  // per-wavefront: tile phase | wait at its barrier | x_0 norms + sum (slots 24.., 28.., 20..)
             const long long tr0 = clock64();
 #endif
+#ifdef DEKF_X_RUIZ_LANE_OPAQUE
             wtiles(ntiles, [&](int tile, int lane) { psum += fused(tile, lane, cc, Dr, Er, Dw, Ew); });
+#else
+            for (int t = rz_wave; t < ntiles; t += rz_nw) psum += fused(t, rz_lane, cc, Dr, Er, Dw, Ew);
+#endif
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
             long long tr1 = 0, tr2 = 0;
 #endif
@@ -1312,10 +1320,16 @@ DEKF_FN bool solve_factor(Q& q) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) o.c[t] = cp[st * t];
     };
+    const int ldl_lane = DEKF_LANE() & 63;
+    (void)ldl_lane;
     auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, dptr tb, cdptr twp, cdptr twh, dptr two, const SOps* po = nullptr) -> bool {
         // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]; two: where the LDS
         // copy of that W block goes when the factor itself lives in the HBM slab
+#ifdef DEKF_X_LDL_LANE_OPAQUE
         const int lane = DEKF_LANE() & 63;
+#else
+        const int lane = ldl_lane;  // (read once in front of the leg loops: a block's lane roles and addresses are loop-invariant)
+#endif
         dptr ts = tb;        // S, then the full inverse
 #ifdef DEKF_X_LDL_FULL_S  // (A/B: all 81 entries of S, two rounds of the wavefront)
         for (int p = lane; p < 81; p += WAVE) (void)build_s3(k, use_top, use_bot, p, ts, twp, twh);
