@@ -484,6 +484,8 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
     constexpr int RING = Q::FACTOR_LDS ? 4 : DEKF_GG_RING;
     const int K = q.K, M = mid_block(K), NOUT = K - 1 - M;  // K even: K - 2 - M == M, both forward legs M steps
+    // (the lane id stays opaque here: taken from q.lane0, i.e. loop-invariant, the run-time ring of operand sets and the hoisted
+    // addresses together spill 63 VGPRs of the 256 and PogoX drops from 102 k to 80 k steps/s)
     const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15;
     const int i = li < 9 ? li : 8;
     const bool act = li < 9, leg = row < 2, top = (row & 1) == 0;
@@ -649,7 +651,11 @@ DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
     const int nst[2] = {mid, BWD ? K - 1 - mid : K - 2 - mid};
     const int wof[2] = {BWD ? 0 : -1, BWD ? -1 : 0};
 #if DEKF_DEVICE_BUILD
+#ifdef DEKF_X_SWEEP_LANE_OPAQUE
     const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15, side = row >> 1, half = row & 1;
+#else
+    const int lane = q.lane0, row = lane >> 4, li = lane & 15, side = row >> 1, half = row & 1;
+#endif
     const int ic = half * 16 + li;
     const bool act = ic < NS;
     const int i = act ? ic : NS - 1;

@@ -196,6 +196,9 @@ struct SolveCtx {
     cdptr vo;  // [wcap][4] VO flag + bound per ring slot, from the solve's input snapshot
     double cc;   // cost scaling c
     double rho;  // current scalar rho
+    int lane0;   // this lane's index inside its wavefront, read ONCE per solve: the solve phases that run on the critical wavefront take
+                 // it from here, so that their per-lane pointers and strides are loop-invariant across the iterations (DEKF_LANE() is
+                 // opaque at every use, on purpose, everywhere else)
     double sigma_pol;  // POLISH: the regularisation of the x block while polishing (delta)
     bool zlo;          // POLISH, while polishing: the cold start puts z on the bound of every equality row (x = y = 0 as usual)
     // the regularisation of the x block in the linear system: settings sigma; delta while polishing
@@ -1780,6 +1783,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
         q.vo = DEKF_CSPAN(sn + NS2 + NS, 4 * c.wcap);
     }
     q.cc = 1.0;
+    q.lane0 = DEKF_LANE() & 63;
     q.sigma_pol = c.delta;
     q.zlo = false;
     q.Pst = DEKF_SPAN(raw_of(q.Sinv), 2 * NH * NS2);  // Sinv | Wk are adjacent in both placements and dead until a factorisation writes them
