@@ -305,14 +305,6 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             h->solve_grid_full = (int)(sf < batch ? sf : batch);
             // only where the batch really fills more slots than the two-workgroup kernel offers: below that the row state
             // would travel through the slab for no residency gained
-#ifdef DEKF_X_ALWAYS_R3  // experiment builds only: the three-workgroup kernel at a forced residency (DEKF_X_R3_CAP workgroups per CU)
-            if (const char* e = getenv("DEKF_X_R3_CAP")) {
-                const long g = (long)atoi(e) * prop.multiProcessorCount;
-                h->solve_grid_full = (int)(g < batch ? g : batch);
-                h->solve_kernel_full = full;
-                h->solve_name_full = full_name;
-            } else
-#endif
             if (pcf > per_cu && h->solve_grid_full > h->solve_grid) {
                 h->solve_kernel_full = full;
                 h->solve_name_full = full_name;

@@ -58,6 +58,9 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     if (p.ekf_history < 4) return "ekf_history must be >= 4";
     if (p.polish != 0 && p.polish != 1) return "osqp.polish must be 0 or 1";
     if (p.polish && !(p.delta > 0)) return "osqp.delta must be positive when osqp.polish is on";
+    // the polishing solve runs as an ADMM step with 1 / rho = delta on the equality rows, and rho lives in [RHO_MIN, RHO_MAX] * 1e3:
+    // outside this range the device would silently solve a differently regularised system than OSQP does
+    if (p.polish && !(p.delta >= 1e-9 && p.delta <= 1e3)) return "osqp.delta must lie in [1e-9, 1e3] when osqp.polish is on";
     if (p.polish_refine_iter < 0 || p.polish_refine_iter > 100) return "polish_refine_iter out of range [0,100]";
     if (p.arrival_cost_form != 0 && p.arrival_cost_form != 1) return "arrival_cost_form must be 0 (reference form) or 1 (information form)";
     if (p.solve_pipeline != 0 && p.solve_pipeline != 1) return "solve_pipeline must be 0 (in order) or 1 (consecutive steps overlap)";

@@ -651,11 +651,7 @@ DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
     const int nst[2] = {mid, BWD ? K - 1 - mid : K - 2 - mid};
     const int wof[2] = {BWD ? 0 : -1, BWD ? -1 : 0};
 #if DEKF_DEVICE_BUILD
-#ifdef DEKF_X_SWEEP_LANE_OPAQUE
-    const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15, side = row >> 1, half = row & 1;
-#else
     const int lane = q.lane0, row = lane >> 4, li = lane & 15, side = row >> 1, half = row & 1;
-#endif
     const int ic = half * 16 + li;
     const bool act = ic < NS;
     const int i = act ? ic : NS - 1;
@@ -1393,9 +1389,7 @@ struct RowRegsT {
     double z[KIND == 2 ? 3 : 1];
     double a[6];                                  // slack-block inverse: own 3x3 (symmetric, packed)
     double b[KIND == 1 ? 9 : (KIND == 2 ? 3 : 1)];  // kind 1: coupling to the partner lane; kind 2: upper bounds
-#ifndef DEKF_X_R_FROM_LDS
     double rk[KIND == 1 ? 9 : 1];                 // kind 1: the step's rotation R_k (nine LDS reads per iteration otherwise)
-#endif
     DEKF_FN void apply(cdptr in, dptr out) const {
         double pin[3] = {0.0, 0.0, 0.0};
         if constexpr (KIND == 1) {
@@ -1507,10 +1501,8 @@ DEKF_FN void row_regs_load(Q& q, int lane, double sigma, RowRegsT<KIND>& t) {
     if constexpr (KIND == 1) {
         const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
         cdptr R = q.R + 9 * t.k;
-#ifndef DEKF_X_R_FROM_LDS
 #pragma unroll
         for (int i = 0; i < 9; ++i) t.rk[i] = R[i];
-#endif
         double u[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
@@ -1543,14 +1535,8 @@ DEKF_FN void row_regs_iter(Q& q, RowRegsT<KIND>& t, double alpha, double sigma, 
     cdptr xk = q.xd + 9 * t.k;
     double ar[3], Rk[9];
     if constexpr (KIND == 1) {
-#ifndef DEKF_X_R_FROM_LDS
 #pragma unroll
         for (int i = 0; i < 9; ++i) Rk[i] = t.rk[i];
-#else
-        cdptr R = q.R + 9 * t.k;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) Rk[i] = R[i];
-#endif
         const bool vel = t.vel;
         const double c1 = vel ? 0.0 : dt, c2 = vel ? dt : hdt2;
         const int o = vel ? 3 : 0;
@@ -1704,11 +1690,7 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
             DEKF_SYNC();  // B1
             DEKF_R3_T(t1);
             __builtin_amdgcn_s_setprio(3);
-#ifdef DEKF_X_SOLVE_LANE_OPAQUE
-            sweeps_one_wave<NF>(q, alpha);
-#else
             sweeps_one_wave<NF>(q, alpha, lane);
-#endif
             __builtin_amdgcn_s_setprio(0);
 #if defined(DEKF_PROFILE_TL)
             __builtin_amdgcn_s_waitcnt(0);
@@ -1730,17 +1712,11 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
             DEKF_SYNC();  // B0
             constexpr int xkind = KIND == 0 ? 1 : (KIND == 1 ? 2 : 0);  // velocity columns (the longest gather) next to the shortest row tile
             const bool cold = q.cold;
-#ifndef DEKF_X_XCOLS_RELOAD
             XcolRegs<xkind> xc;
             xcols_regs_load<xkind>(q, lane, xc);
-#endif
             for (int it = 0; it < iters; ++it) {
                 DEKF_R3_T(t0);
-#ifndef DEKF_X_XCOLS_RELOAD
                 xcols_regs_tile<xkind>(q, xc, sigma);
-#else
-                xcols_tile_r3(q, xkind, lane, sigma);
-#endif
 #if defined(DEKF_PROFILE_TL)
                 __builtin_amdgcn_s_waitcnt(0);
 #endif
@@ -2051,14 +2027,6 @@ DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
 #endif
     wave_max_n<14>(acc);
     group_combine<14, false>(acc);
-#ifdef DEKF_X_DOUBLE_RED  // experiment: what does the reduction cost?  (idempotent: a second pass leaves the maxima as they are)
-    for (int rep_ = 0; rep_ < DEKF_X_DOUBLE_RED; ++rep_) {
-#pragma unroll
-        for (int r = 0; r < 14; ++r) asm volatile("" : "+v"(acc[r]));
-        wave_max_n<14>(acc);
-        group_combine<14, false>(acc);
-    }
-#endif
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RESID2) && DEKF_DEVICE_BUILD
     {
         const long long trs2 = clock64();

@@ -312,13 +312,9 @@ DEKF_FN void solve_scale(Q& q) {
         if (td < 2 * ntd) { bool vo = td >= ntd; kind = vo ? 3 : 2; k = (td - (vo ? ntd : 0)) * 64 + lane; sub = 0; return k < K1; }
         td -= 2 * ntd;
         if (td < 3 * ntx) {
-#ifdef DEKF_X_RUIZ_COLS_PVB  // (A/B: column tiles in the order position, velocity, bias)
-            int pos = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2), ck = pos;
-#else
             // column tiles in the order velocity, position, bias: with one tile per kind (K <= 21) the wavefront that owns the Dyn
             // lane pairs — the longest row tile — then also gets the position columns, the shortest column tile
             int pos = td < ntx ? 0 : (td < 2 * ntx ? 1 : 2), ck = pos == 0 ? 1 : (pos == 1 ? 0 : 2);
-#endif
             int e = (td - pos * ntx) * 64 + lane;
             kind = 4 + ck; k = e / 3; sub = e - 3 * k;
             return e < 3 * K;
@@ -652,11 +648,7 @@ DEKF_FN void solve_scale(Q& q) {
 #pragma unroll
     for (int j = 0; j < NS; ++j) gq[j] = g[j];
 #if DEKF_DEVICE_BUILD
-#ifdef DEKF_X_RUIZ_3BARRIERS
-    if constexpr (FT == 0) {
-#else
     {
-#endif
         // One Ruiz pass = ONE tile phase (equilibrate + the new column norms of the owned slack blocks, ping-pong between the two
         // pairs of scaling vectors instead of a copy), a barrier, the nine x_0 lanes' arrival-cost norms, the sum.  Same
         // arithmetic, same lanes, same order of the sum as the two-phase form below (which the lane-sequential build and the
@@ -672,27 +664,10 @@ DEKF_FN void solve_scale(Q& q) {
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)  // per-wavefront: tile phase | wait at its barrier | x_0 norms + sum (slots 24.., 28.., 20..)
             const long long tr0 = clock64();
 #endif
-#ifdef DEKF_X_RUIZ_LANE_OPAQUE
-            wtiles(ntiles, [&](int tile, int lane) { psum += fused(tile, lane, cc, Dr, Er, Dw, Ew); });
-#else
             for (int t = rz_wave; t < ntiles; t += rz_nw) psum += fused(t, rz_lane, cc, Dr, Er, Dw, Ew);
-#endif
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
             long long tr1 = 0, tr2 = 0;
 #endif
-#ifdef DEKF_X_RUIZ_3BARRIERS  // (A/B: the form with the sum behind the x_0 norms, two more barriers per pass)
-#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
-            __builtin_amdgcn_s_waitcnt(0);
-            tr1 = clock64();
-#endif
-            DEKF_SYNC();
-#if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
-            tr2 = clock64();
-#endif
-            wtiles(ntiles, [&](int tile, int lane) { psum += fused_x0(tile, lane, Dw); });
-            psum = wave_sum(psum);
-            group_combine<1, true>(&psum);
-#else
             // ONE barrier per pass: every wavefront leaves the sum of its tiles in LDS before it (two sets of slots, by parity of
             // the pass: a wavefront that is already in the next pass must not overwrite what a slower one still reads), and behind
             // it every wavefront adds up the four partials in the same order and computes the nine arrival-cost norms itself
@@ -725,11 +700,7 @@ DEKF_FN void solve_scale(Q& q) {
                 }
                 // pc of column j of x_0 is read by the wavefront that owns the column's tile (lane j % 3 of the first tile of
                 // kind j / 3) in ITS next pass: that wavefront stores it (LDS serves a wavefront's accesses in order)
-#ifdef DEKF_X_RUIZ_COLS_PVB
-                const int cpos = j / 3;
-#else
                 const int cpos = j < 3 ? 1 : (j < 6 ? 0 : 2);  // (the order of the column tiles: velocity, position, bias)
-#endif
                 // (a foot-position column of x_0 sits in lane j - 9 of the first foot-column tile)
                 const int otile = j < 9 ? ntm + ntp + 2 * ntd + cpos * ntx : ntm + ntp + 2 * ntd + 3 * ntx + ntf;
                 if (ln < NS && (otile & (DEKF_NLANES() / WAVE - 1)) == wv) pc[j] = v;
@@ -739,7 +710,6 @@ DEKF_FN void solve_scale(Q& q) {
                 for (int i = 1; i < nw; ++i) tot += part[i];
                 psum = tot + x0;
             }
-#endif
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
             {
                 const long long tr3 = clock64();
@@ -1275,11 +1245,7 @@ DEKF_FN bool solve_factor(Q& q) {
     (void)nph; (void)bufs; (void)gj_step; (void)pivot_ok; (void)store_sinv; (void)build_s;
     // S of block k, element p (device form: three independent accumulators per sum, no symmetrisation —
     // W C' = C S^-1 C' is symmetric up to rounding and the Gauss-Jordan sweep does not need more)
-#ifdef DEKF_X_LDL_NO_TW  // (A/B: every block reads its predecessor's W from the slab)
-    constexpr bool W_DIRECT = true;
-#else
     constexpr bool W_DIRECT = Q::FACTOR_LDS;
-#endif
     // twp / twh: with the factor in the HBM slab, the LDS copies of W_{k-1} / W^_k that the previous block of the leg left behind
     // (a block must not wait for its predecessor's W to travel to L2 and back: 2-3 us per block of a PogoX window)
     auto build_s3 = [&](int k, bool use_top, bool use_bot, int p, dptr dst, cdptr twp, cdptr twh) -> double {
@@ -1328,15 +1294,8 @@ DEKF_FN bool solve_factor(Q& q) {
     auto factor_block = [&](int k, bool use_top, bool use_bot, int wmode, dptr tb, cdptr twp, cdptr twh, dptr two, const SOps* po = nullptr) -> bool {
         // wmode 0: none (meeting block), 1: W_k = C_k S^-1 -> Wk[k], 2: What_{k-1} = C_{k-1}' S^-1 -> Wk[k-1]; two: where the LDS
         // copy of that W block goes when the factor itself lives in the HBM slab
-#ifdef DEKF_X_LDL_LANE_OPAQUE
-        const int lane = DEKF_LANE() & 63;
-#else
         const int lane = ldl_lane;  // (read once in front of the leg loops: a block's lane roles and addresses are loop-invariant)
-#endif
         dptr ts = tb;        // S, then the full inverse
-#ifdef DEKF_X_LDL_FULL_S  // (A/B: all 81 entries of S, two rounds of the wavefront)
-        for (int p = lane; p < 81; p += WAVE) (void)build_s3(k, use_top, use_bot, p, ts, twp, twh);
-#else
         // S is symmetric (T_kk exactly, the Schur terms up to rounding): its 45 upper entries in ONE round of the wavefront,
         // each stored to both places (the Gauss-Jordan sweep below reads columns)
         if (lane < 45) {
@@ -1357,15 +1316,7 @@ DEKF_FN bool solve_factor(Q& q) {
                 ts[9 * j + i] = build_s3(k, use_top, use_bot, 9 * i + j, ts, twp, twh);
             }
         }
-#endif
         wave_sync();
-#ifdef DEKF_X_LDL_W_PRODUCT  // (A/B: the inverse alone in the sweep, W = C S^-1 as a product behind it)
-        const int j = lane < 9 ? lane : 8;
-        const int li = lane;
-        double a[9];
-#pragma unroll
-        for (int i = 0; i < 9; ++i) a[i] = ts[9 * i + j];
-#else
         // AUGMENTED sweep: next to the nine columns of S the wavefront carries the nine columns of C' (W_k = C_k S^-1: row c of C) or
         // of C (W^_{k-1} = C_{k-1}' S^-1: column c of C); the Gauss-Jordan sweep turns a column v into S^-1 v, i.e. into row c of
         // the W block — with the SAME nine DPP instructions per pivot, which every lane executes anyway.  A DPP broadcast stays
@@ -1380,13 +1331,8 @@ DEKF_FN bool solve_factor(Q& q) {
         // ... and the nine columns of the IDENTITY ride along too (row 1 lanes 11..15: c = 0..4, row 2 lanes 9..12: c = 5..8): they end
         // as the columns of S^-1, so the sweep needs no in-place handling of the pivot column (a multiplication by 0 / 1 and a select
         // per row and pivot): every lane runs the plain elimination a_i -= s_ip (a_p / s_pp).  Same values as the in-place form.
-#ifdef DEKF_X_LDL_INPLACE
-        const bool icol = false;
-        const int ic = 0;
-#else
         const bool icol = (rw == 1 && li >= 11) || (rw == 2 && li >= 9 && li <= 12);
         const int ic = rw == 1 ? li - 11 : li - 9 + 5;
-#endif
         double a[9];
         if (ccol) {  // (two loops, not one pointer select: C may sit in the HBM slab while the scratch is LDS)
             cdptr src = q.PA + kw * 81 + (wmode == 1 ? 9 * cidx : cidx);
@@ -1401,7 +1347,6 @@ DEKF_FN bool solve_factor(Q& q) {
 #pragma unroll
             for (int i = 0; i < 9; ++i) a[i] = i == ic ? 1.0 : 0.0;
         }
-#endif
         bool good = true;
         // pivot pv: every lane needs column pv (lane pv's registers).  The pivot itself goes through one
         // v_readlane pair; the other eight entries are consumed straight from lane pv by the update FMA
@@ -1409,22 +1354,12 @@ DEKF_FN bool solve_factor(Q& q) {
         // column is -col * d.  Two wait states between the VALU write of a[i] and its DPP read: the s_nop.
 #define DEKF_GJ_DPP(acc, src, mul, PV) \
     asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, -%2 row_newbcast:" #PV " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(mul))
-#if defined(DEKF_X_LDL_INPLACE) || defined(DEKF_X_LDL_W_PRODUCT)
-#define DEKF_GJ_UPD(I, PV)                                                       \
-            {                                                                    \
-                double t = a[I] * keep;                                          \
-                DEKF_GJ_DPP(t, a[I], m, PV);                                     \
-                a[I] = t;                                                        \
-            }
-#define DEKF_GJ_OWN(PV) (li == PV)
-#else
 #define DEKF_GJ_UPD(I, PV)                                                       \
             {                                                                    \
                 (void)keep;                                                      \
                 DEKF_GJ_DPP(a[I], a[I], m, PV);                                  \
             }
 #define DEKF_GJ_OWN(PV) false
-#endif
         // The row that holds the NEXT pivot is updated first and its reciprocal started at once, so that the
         // v_rcp + Newton chain runs underneath the seven remaining (quarter-rate) DPP FMAs of this pivot.
         // Own lane: base 0 through a multiplication by `keep` (one f64 multiply instead of two 32-bit selects).
@@ -1457,40 +1392,8 @@ DEKF_FN bool solve_factor(Q& q) {
 #undef DEKF_GJ_OWN
 #undef DEKF_GJ_PIVOT
 #undef DEKF_GJ_DPP
-#ifdef DEKF_X_LDL_W_PRODUCT
-        wave_sync();  // every lane has read its column of S
-        if (lane < 9) {
-            // column j of the inverse: to the scratch copy for the W product and to S^-1[k] (full 9x9: a row is
-            // contiguous, so the solve phases address it with immediates instead of packed-index arithmetic)
-#pragma unroll
-            for (int i = 0; i < 9; ++i) {
-                ts[9 * i + j] = a[i];
-                q.Sinv[k * 81 + 9 * i + j] = a[i];
-            }
-        }
-        wave_sync();
-        if (wmode != 0) {
-            const int kw = wmode == 1 ? k : k - 1;
-            cdptr Ck = q.PA + kw * 81;
-            for (int p = lane; p < 81; p += WAVE) {
-                const int i = p / 9, jj = p - 9 * i;
-                cdptr cr = wmode == 1 ? Ck + 9 * i : Ck + i;  // row i of C, or column i (C')
-                const int cs = wmode == 1 ? 1 : 9;
-                cdptr tc = ts + jj;
-                double s0 = cr[0] * tc[0] + cr[3 * cs] * tc[27] + cr[6 * cs] * tc[54];
-                double s1 = cr[cs] * tc[9] + cr[4 * cs] * tc[36] + cr[7 * cs] * tc[63];
-                double s2 = cr[2 * cs] * tc[18] + cr[5 * cs] * tc[45] + cr[8 * cs] * tc[72];
-                q.Wk[kw * 81 + p] = s0 + (s1 + s2);
-            }
-        }
-#else
-#ifdef DEKF_X_LDL_INPLACE
-        const bool inv_lane = li < 9 && rw == 0;
-        const int jc = j;
-#else
         const bool inv_lane = icol;
         const int jc = ic;
-#endif
         if (inv_lane) {
             // column jc of the inverse to S^-1[k] (full 9x9: a row is contiguous, so the solve phases address it with immediates
             // instead of packed-index arithmetic); the meeting block also leaves it in the scratch for the joint middle
@@ -1508,16 +1411,12 @@ DEKF_FN bool solve_factor(Q& q) {
                 for (int t = 0; t < 9; ++t) two[9 * cidx + t] = a[t];
             }
         }
-#endif
         wave_sync();
         return good;
     };
     dptr fail = q.tmp + 172;  // [162, 171) is the scaled q
     if (DEKF_LANE() == 0) *fail = 0.0;
     DEKF_SYNC();
-#ifdef DEKF_X_LDL_PRIO
-    __builtin_amdgcn_s_setprio(DEKF_X_LDL_PRIO);
-#endif
     two_waves(
         [&] {
             bool g = true;
@@ -1594,9 +1493,6 @@ DEKF_FN bool solve_factor(Q& q) {
             }
         },
         [&] {});
-#ifdef DEKF_X_LDL_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     DEKF_SYNC();
     ok = *fail == 0.0;
     DEKF_SYNC();
@@ -1802,9 +1698,6 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     if (DEKF_LANE() == 0)
         for (int i = 0; i < DEKF_PROF_SLOTS; ++i) q.prof[i] = 0.0;
 #endif
-#if defined(DEKF_X_SETUP_PRIO) && DEKF_DEVICE_BUILD
-    __builtin_amdgcn_s_setprio(DEKF_X_SETUP_PRIO);
-#endif
     wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });
     if constexpr (R3) {
         // D and E stay in LDS for the whole solve; the Ruiz passes' temporaries pc, En, Dn sit behind the staged P blocks inside
@@ -1854,9 +1747,6 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     if (ok) phase_rows<true>(q, alpha, sigma);  // cold start: cf, t = 0, w = 0 (the factorisation scratch aliased xt | zt | at)
     }
     DEKF_PROF_MARK(q, 1);
-#if defined(DEKF_X_SETUP_PRIO) && DEKF_DEVICE_BUILD
-    __builtin_amdgcn_s_setprio(0);
-#endif
     while (ok && !done && iter < c.max_iter) {
 #if DEKF_DEVICE_BUILD
         if constexpr (R3) {

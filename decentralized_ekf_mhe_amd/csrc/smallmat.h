@@ -66,11 +66,7 @@ template <int N>
 DEKF_FN void inv_spd_unrolled(double* A) {
 #pragma unroll
     for (int p = 0; p < N; ++p) {
-#ifdef DEKF_X_RCP
-        double d = rcp_fast(A[p * N + p]);
-#else
         double d = 1.0 / A[p * N + p];
-#endif
 #pragma unroll
         for (int j = 0; j < N; ++j)
             if (j != p) A[p * N + j] *= d;
@@ -93,11 +89,7 @@ DEKF_FN bool inv3_sym(const double* s, double* o) {
     double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
     double det = a * c00 + b * c01 + c * c02;
     if (det == 0.0) return false;
-#ifdef DEKF_X_RCP
-    double id = rcp_fast(det);
-#else
     double id = 1.0 / det;
-#endif
     o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
     o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id;
     o[5] = (a * d - b * b) * id;

@@ -73,11 +73,9 @@ typedef struct dekf_params {
     int num_legs;       /* leg_odom.num_leg */
     int joints_per_leg; /* 3 on Go1 (hard-coded block<3,3> in the reference) */
     int leg_odom_type;  /* 0: foot-velocity measurements, dim_state 9.  1: foot positions are states,
-                         * dim_state = 9 + 3 num_legs (21 on Go1), DecentralEst.cpp:20.
-                         * Deviation for type 1: the arrival cost is updated in INFORMATION form (same cost in exact
-                         * arithmetic), not through the covariance-form saddle inverse of MheSrb.cpp:527-651, which
-                         * loses the measurement information of a swinging foot (covariance dt^2 * 1e14) to rounding;
-                         * agreement with the reference form is tested over long runs. */
+                         * dim_state = 9 + 3 num_legs (21 on Go1), DecentralEst.cpp:20.  How the arrival cost of type 1 is
+                         * updated is chosen by `arrival_cost_form` below; its default (0) is the reference's covariance-form
+                         * saddle inverse (MheSrb.cpp:527-651). */
     double joint_position_std[DEKF_MAX_JOINTS];
     double joint_velocity_std[DEKF_MAX_JOINTS];
     double foot_slide_std[3];
@@ -122,9 +120,12 @@ typedef struct dekf_params {
                                      * order, so results are bit-identical.  Measured on MI355X, Go1: +7 % at B = 768, +1 % at 4096,
                                      * +2 % at 8192: it hides the 0.1 ms of EKF + assemble + launch gaps, the
                                      * partial last round of a launch costs nothing to begin with. */
-    int solve_workgroups_per_cu;    /* 0: as many as the CU holds (3 for full Go1 / Cassie windows); 1 or 2: cap —
-                                     * 2 keeps the two-workgroup solve kernels for full windows too (bit-identical
-                                     * results: the A/B and the identity test use it) */
+    int solve_workgroups_per_cu;    /* 0: as many as the CU holds (3 for full Go1 / Cassie windows when the batch exceeds the 512
+                                     * slots of the two-workgroup kernels); 1 or 2: cap — 2 keeps the two-workgroup solve kernels
+                                     * for full windows too.  The two kernel families run the same algorithm with the same
+                                     * iteration and rho-update counts; their states agree to about 1e-8 (1e-2 of the tolerance),
+                                     * not bit for bit — so an instance's last bits depend on whether its batch is above 512
+                                     * (tests/test_gpu_configs.py). */
 } dekf_params;
 
 typedef struct dekf_handle_s* dekf_handle;

@@ -32,3 +32,26 @@ def test_bench_line_has_the_contract_fields():
     assert d["value"] > 0 and d["solver"]["solved_frac"] == 1.0
     # value = instances x steps / elapsed
     assert abs(d["value"] - 256 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6
+
+
+@pytest.mark.gpu
+def test_bench_at_the_8_gpu_per_rank_batch_on_one_gpu():
+    """BASELINE config 4 gives every rank 8192 instances; `bench.py --gpus 8` has never had its 8 GPUs.  What one GPU can keep warm:
+    the very command line a rank runs, at the per-rank batch, with a single-rank world — workload string from the actual batch, no
+    collective, no committed PMC figure quoted for a batch it was not collected at, every instance solved on the three-workgroup
+    kernel.  The first real --gpus 8 lease is then a matter of RCCL only."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "8192", "--steps", "4", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["window_fill_steps_before_warmup"] == 48
+    assert d["config"]["workload"] == "Go1, batch=8192 synthetic IMU+encoder+vision streams, 20-step MHE, 1xMI355X"
+    assert d["config"]["batch_per_gpu"] == 8192 and d["config"]["global_batch"] == 8192
+    assert d["config"]["allgather"] == "none"
+    assert d["roofline"]["traffic"] is None and "batch 8192" in d["roofline"]["traffic_source"]
+    assert d["roofline"]["kernel"] == "k_mhe_solve_r3_4_n20" and d["roofline"]["units_per_launch"] == 8192
+    assert d["roofline"]["solve_workgroups"] == 768
+    assert d["solver"]["solved_frac"] == 1.0
+    assert abs(d["value"] - 8192 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-6

@@ -11,8 +11,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DRIVER = r'''
 #include "hostsim.cpp"
 #include <cstdio>
-static int run(int L, int nj, int N, int steps, int ft = 0) {
-    dekf_params p; default_params(&p); p.ekf_rate = 200; p.num_legs = L; p.joints_per_leg = nj; p.N = N; p.leg_odom_type = ft;
+static int run(int L, int nj, int N, int steps, int ft = 0, int form = 0) {
+    dekf_params p; default_params(&p); p.ekf_rate = 200; p.num_legs = L; p.joints_per_leg = nj; p.N = N; p.leg_odom_type = ft; p.arrival_cost_form = form;
     const int ns = 9 + 3 * L * ft;
     int B = 2;
     void* h = hs_create(&p, B);
@@ -38,13 +38,17 @@ static int run(int L, int nj, int N, int steps, int ft = 0) {
     }
     std::vector<double> x(ns * B); std::vector<int> st(B), it(B);
     hs_get(h, x.data(), nullptr, nullptr, nullptr, st.data(), it.data(), nullptr);
-    std::printf("L=%d nj=%d N=%d leg_odom_type=%d: status %d iters %d v=%g\n", L, nj, N, ft, st[0], it[0], x[3]);
+    std::printf("L=%d nj=%d N=%d leg_odom_type=%d arrival_cost_form=%d: status %d iters %d v=%g\n", L, nj, N, ft, form, st[0], it[0], x[3]);
     hs_destroy(h);
     return st[0] == 1 ? 0 : 2;
 }
-// leg_odom_type 1 (foot positions as states, 21-dim blocks on Go1: its own solve family, factor in the slab, information-form
-// marginalisation) through window fill, marginalisation with swinging feet and VO updates; and a 2-leg shape of it
-int main() { return run(4, 3, 20, 60) | run(2, 5, 8, 30) | run(1, 3, 40, 70) | run(4, 3, 20, 34, 1) | run(2, 5, 6, 24, 1); }
+// leg_odom_type 1 (foot positions as states, 21-dim blocks on Go1: its own solve family, factor in the slab) through window fill,
+// marginalisation with swinging feet and VO updates, with BOTH forms of the arrival cost: 0 = the reference's covariance form
+// (the default: pivoted generic inverse in the enlarged AsmScratch), 1 = information form (marginalize_info); and a 2-leg shape
+int main() {
+    return run(4, 3, 20, 60) | run(2, 5, 8, 30) | run(1, 3, 40, 70) | run(4, 3, 20, 34, 1, 0) | run(4, 3, 20, 34, 1, 1) |
+           run(2, 5, 6, 24, 1, 0) | run(2, 5, 6, 24, 1, 1);
+}
 '''
 
 

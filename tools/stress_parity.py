@@ -21,7 +21,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib as O  # noqa: E402
 from decentralized_ekf_mhe_amd import cassie_params, go1_params, pogox_params  # noqa: E402
-from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_host  # noqa: E402
+from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_host, streams_to_device  # noqa: E402
 from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
 
 RTOL, ATOL = 1e-4, 1e-6
@@ -68,7 +68,15 @@ class heartbeat:
 _oracle_cache = {}
 
 
-def case(name, maker, B, K, threads, stream_kw=None, oracle_key=None, **kw):
+def _tile(s, reps):
+    return {k: (np.ascontiguousarray(np.tile(v, (1, reps) + (1,) * (v.ndim - 2))) if isinstance(v, np.ndarray) else v)
+            for k, v in s.items()}
+
+
+def case(name, maker, B, K, threads, stream_kw=None, oracle_key=None, reps=1, **kw):
+    """B distinct logs through the oracle; the device runs them tiled `reps` times in one batch (B * reps > 512 is what makes
+    dekf_create launch the three-workgroup kernels k_mhe_solve_r3_* for Go1 / Cassie at N = 20) and every tile must carry the same
+    bits; the first tile is compared with the oracle at every tick."""
     p = maker()
     p.ekf_rate = p.rate
     for k, v in kw.items():
@@ -83,19 +91,27 @@ def case(name, maker, B, K, threads, stream_kw=None, oracle_key=None, **kw):
         if oracle_key is not None:
             _oracle_cache[oracle_key] = (x_ref, vb_ref, q_ref, it_ref)
     t_cpu = time.time() - t0
-    est = BatchedEstimator(p, B)
-    sd = streams_host(s)
+    est = BatchedEstimator(p, B * reps)
+    kernels = {"full_window": est.solve_kernel_name(True), "window_fill": est.solve_kernel_name(False)}
+    sd = streams_to_device(_tile(s, reps)) if reps > 1 else streams_host(s)
     xs, qs, its, sts = [], [], [], []
+    tiles_identical = True
     t0 = time.time()
     for k in range(K):
         est.push_stream_step(sd, k)
         est.step(k)
         o = est.get()
-        xs.append(o["x"]); qs.append(o["quat"]); sts.append(o["status"]); its.append(est.solver_info()["iters"])
+        it = est.solver_info()["iters"]
+        if reps > 1:
+            for a in (o["x"], o["quat"], o["status"], it):
+                t = a.reshape((reps, B) + a.shape[1:])
+                tiles_identical &= bool(np.array_equal(t, np.broadcast_to(t[0], t.shape)))
+        xs.append(o["x"][:B]); qs.append(o["quat"][:B]); sts.append(o["status"][:B]); its.append(it[:B])
     t_gpu = time.time() - t0
     est.close()
     x, q, it, st = np.array(xs), np.array(qs), np.array(its), np.array(sts)
-    res = {"case": name, "instances": B, "ticks": K, "swing_phases_per_foot_min": swing_phases_per_foot(s),
+    res = {"case": name, "instances": B, "batch_on_device": B * reps, "solve_kernels": kernels, "tiles_bit_identical": tiles_identical,
+           "ticks": K, "swing_phases_per_foot_min": swing_phases_per_foot(s),
            "worst_block_error_over_tolerance": block_err(x[1:], x_ref[1:]),
            "worst_base_block_error_over_tolerance": block_err(x[1:, :, :9], x_ref[1:, :, :9]),
            "max_abs_dx": float(np.abs(x[1:] - x_ref[1:]).max()), "max_abs_dquat": float(np.abs(q - q_ref).max()),
@@ -105,7 +121,7 @@ def case(name, maker, B, K, threads, stream_kw=None, oracle_key=None, **kw):
     print(json.dumps(res), flush=True)
     # foot-position blocks (leg_odom_type 1) after touch-downs carry the reference formula's own cancellation noise: 10 x
     limit = 10.0 if p.leg_odom_type == 1 else 1.0
-    return (res["worst_base_block_error_over_tolerance"] <= 1.0 and res["worst_block_error_over_tolerance"] <= limit and
+    return (tiles_identical and res["worst_base_block_error_over_tolerance"] <= 1.0 and res["worst_block_error_over_tolerance"] <= limit and
             res["max_abs_dquat"] < 1e-9 and res["all_solved"] is not False)
 
 
@@ -123,13 +139,15 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "soak":
         # long runs of the benchmark shapes: every tick of 5000 (Go1, Cassie) against the oracle — drift, a rare failed solve or an
         # iteration count that differs would show here and nowhere else
-        ok &= case("go1 N=20, 48 x 5000 ticks", go1_params, 48, 5000, th)
-        ok &= case("cassie N=20, 32 x 5000 ticks", cassie_params, 32, 5000, th)
-        ok &= case("go1 N=20 with osqp.polish, 32 x 1500 ticks", go1_params, 32, 1500, th, polish=1)
+        # (tiled past 512 instances: the full windows then run the three-workgroup kernels the benchmark is priced on)
+        ok &= case("go1 N=20, 48 x 5000 ticks, tiled x 17 (B = 816)", go1_params, 48, 5000, th, reps=17)
+        ok &= case("cassie N=20, 32 x 5000 ticks, tiled x 25 (B = 800)", cassie_params, 32, 5000, th, reps=25)
+        ok &= case("go1 N=20 with osqp.polish, 32 x 1500 ticks, tiled x 25 (B = 800)", go1_params, 32, 1500, th, reps=25, polish=1)
+        ok &= case("cassie N=20 with osqp.polish, 32 x 1500 ticks, tiled x 25 (B = 800)", cassie_params, 32, 1500, th, reps=25, polish=1)
         sys.exit(0 if ok else 1)
-    ok &= case("go1 N=20 (BASELINE configs[1] shape)", go1_params, 256, 400, th)
+    ok &= case("go1 N=20 (BASELINE configs[1] shape), 256 x 400 ticks tiled x 4 (B = 1024)", go1_params, 256, 400, th, reps=4)
     ok &= case("go1 N=20, KF mode", go1_params, 64, 200, th, est_type=1)
-    ok &= case("cassie N=20", cassie_params, 128, 200, th)
+    ok &= case("cassie N=20, 128 x 200 ticks tiled x 7 (B = 896)", cassie_params, 128, 200, th, reps=7)
     ok &= case("pogox N=100", pogox_params, 32, 260, th)
     ok &= case("go1 N=5", go1_params, 64, 120, th, N=5)
     ok &= case("go1 N=20, foot positions as states (leg_odom_type 1)", go1_params, 32, 120, th, leg_odom_type=1)
