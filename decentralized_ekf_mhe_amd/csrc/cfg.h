@@ -39,6 +39,11 @@ struct DevCfg {
     int est_type;
     int marg_info;        // leg_odom_type 1: fold a step into the arrival cost in information form (dekf_params.arrival_cost_form)
     double dt;
+    // Uniform constants the solve kernels would otherwise COMPUTE (f64 arithmetic is vector-only: the result sits in a VGPR pair,
+    // gets hoisted to the top of the kernel and stays live across the whole solve — spilled at 168 VGPRs) or could not encode as
+    // an instruction literal; as kernel arguments they arrive in SGPRs: dt^2 / 2, the clamped initial rho, OSQP's "infinite bound"
+    // threshold OSQP_INFTY * MIN_SCALING (rho_of)
+    double hdt2, rho0c, inf_thr;
     // estimator constants (DecentralEst.cpp:39-51, 236-253)
     double C_p[3], C_accel[3], C_accel_bias[3], C_gyro[3];
     double C_enc_pos[DEKF_MAX_JOINTS], C_enc_vel[DEKF_MAX_JOINTS];

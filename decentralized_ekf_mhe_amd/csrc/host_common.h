@@ -80,6 +80,8 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     c.est_type = p.est_type;
     c.marg_info = p.leg_odom_type == 1 && p.arrival_cost_form == 1;
     c.dt = 1.0 / (double)p.rate;
+    c.hdt2 = 0.5 * c.dt * c.dt;
+    c.inf_thr = OSQP_INFTY * MIN_SCALING;
     auto sq = [](double v) { return v * v; };
     for (int i = 0; i < 3; ++i) {
         c.C_p[i] = sq(p.p_process_std[i]);
@@ -104,7 +106,7 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
         c.ekf_Caccel[i] = sq(p.ekf_gravity_meas_std[i]);
     }
     for (int i = 0; i < c.nj; ++i) { c.C_enc_pos[i] = sq(p.joint_position_std[i]); c.C_enc_vel[i] = sq(p.joint_velocity_std[i]); }
-    c.rho0 = p.rho; c.sigma = p.sigma; c.alpha = p.alpha; c.eps_abs = p.abs_tol; c.eps_rel = p.rel_tol;
+    c.rho0 = p.rho; c.rho0c = p.rho < RHO_MIN ? RHO_MIN : (p.rho > RHO_MAX ? RHO_MAX : p.rho); c.sigma = p.sigma; c.alpha = p.alpha; c.eps_abs = p.abs_tol; c.eps_rel = p.rel_tol;
     c.max_iter = p.max_qp_iter; c.scaling = p.scaling_iters; c.check_termination = p.check_termination;
     c.adaptive_rho = p.adapt_rho; c.adaptive_rho_interval = p.adaptive_rho_interval;
     c.adaptive_rho_tolerance = p.adaptive_rho_tolerance;

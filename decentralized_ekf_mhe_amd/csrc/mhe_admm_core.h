@@ -64,7 +64,7 @@ template <class Q, class WF>
 DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
     const bool hn = k < q.K - 1, hp = k > 0;
     const int kn = hn ? k : 0, kp = hp ? k - 1 : 0;
-    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double dt = q.c.dt, hdt2 = q.c.hdt2;
     cdptr R = q.R + 9 * kn;
     const int rn = q.ix.rd(kn, 0);
     const double p0 = w(q.ix.rd(kp, 6 + a));
@@ -959,7 +959,7 @@ DEKF_FN void row_block_load(const Q& q, int r0, int sv0, bool has_hi, RowPre<NR>
 template <int NR, bool EQ, class Q, class SM>
 DEKF_FN void row_block_compute(Q& q, int r0, int sv0, cdptr ar, const SM& S, const RowPre<NR>& p, double alpha, double sigma,
                                bool has_hi = true, dptr wout = nullptr) {
-    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+    const double rho_eq = uni(RHO_EQ_OVER_RHO_INEQ * q.rho);
     double c2[NR], hi[NR], v[NR], sl[NR], xn[NR], zn[NR], yn[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
@@ -1013,7 +1013,7 @@ DEKF_FN void row_block_update(Q& q, int r0, int sv0, cdptr ar, const SM& S, doub
 // the same block from (x, z, y) alone: after a (re)factorisation, and for the cold start
 template <int NR, bool EQ, class Q, class SM>
 DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma, dptr wout = nullptr) {
-    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+    const double rho_eq = uni(RHO_EQ_OVER_RHO_INEQ * q.rho);
     double e[NR], cf[NR], un[NR], rhs[NR], t[NR];
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
@@ -1120,7 +1120,7 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
 #else
     const int ntp = (K1 + 63) >> 6;      // host build: one (sequential) lane per 6-block
 #endif
-    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double dt = q.c.dt, hdt2 = q.c.hdt2;
     cdptr xd = q.xd, E = q.E;
     // Tile order [Meas | Dyn | VO + bias | foot-position Dyn].  VO blocks and Dyn bias blocks share tiles and ONE code
     // path (3 rows, a 3x3 symmetric slack-block inverse that is diagonal for the bias rows, the generic projection):
@@ -1312,7 +1312,7 @@ DEKF_FN void row_tile_load(const Q& q, int tile, int lane, RowTile& t) {
 template <class Q>
 DEKF_FN void row_tile_finish(Q& q, const RowTile& t, double alpha, double sigma) {
     if (t.kind < 0) return;
-    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double dt = q.c.dt, hdt2 = q.c.hdt2;
     cdptr xk = q.xd + 9 * t.k;
     cdptr E = q.E;
     double ar[3];
@@ -1482,7 +1482,7 @@ DEKF_FN void row_regs_load(Q& q, int lane, double sigma, RowRegsT<KIND>& t) {
         if constexpr (KIND == 2) t.z[j] = zz[j];
         dd[j] = d;
     }
-    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+    const double rho_eq = uni(RHO_EQ_OVER_RHO_INEQ * q.rho);
     double un[3], rhs[3], tn[3], wo[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -1499,7 +1499,7 @@ DEKF_FN void row_regs_load(Q& q, int lane, double sigma, RowRegsT<KIND>& t) {
         q.at[t.r0 + j] = wo[j];
     }
     if constexpr (KIND == 1) {
-        const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+        const double dt = q.c.dt, hdt2 = q.c.hdt2;
         cdptr R = q.R + 9 * t.k;
 #pragma unroll
         for (int i = 0; i < 9; ++i) t.rk[i] = R[i];
@@ -1531,7 +1531,7 @@ DEKF_FN void row_regs_store(Q& q, const RowRegsT<KIND>& t) {
 template <int KIND, class Q>
 DEKF_FN void row_regs_iter(Q& q, RowRegsT<KIND>& t, double alpha, double sigma, bool first_cold) {
     if (!t.valid) return;
-    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double dt = q.c.dt, hdt2 = q.c.hdt2;
     cdptr xk = q.xd + 9 * t.k;
     double ar[3], Rk[9];
     if constexpr (KIND == 1) {
@@ -1553,7 +1553,7 @@ DEKF_FN void row_regs_iter(Q& q, RowRegsT<KIND>& t, double alpha, double sigma, 
         for (int a = 0; a < 3; ++a) ar[a] = t.e[a] * (xk[t.xo + a] - xk[9 + t.xo + a]);
     }
     constexpr bool eq = KIND != 2;
-    const double rho_eq = RHO_EQ_OVER_RHO_INEQ * q.rho;
+    const double rho_eq = uni(RHO_EQ_OVER_RHO_INEQ * q.rho);
     double v[3], sl[3], un[3], rhs[3], tn[3], wo[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) v[j] = t.cf[j] * ar[j];
@@ -1825,7 +1825,7 @@ template <class Q>
 DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
     constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, SV = 2 * NS + 3 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
-    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt, cc = q.cc;
+    const double dt = q.c.dt, hdt2 = q.c.hdt2, cc = q.cc;
     dptr x = q.x, z = q.z, y = q.y, xd = q.xd;
     cdptr D = q.D, E = q.E;
     // Where the iterates are.  Three-workgroup kernels (R3): x blocks compact in LDS (xb); the slack x and y by ROW in sx / sy, z of
@@ -1875,7 +1875,7 @@ DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
     auto block_sym3 = [&](int r0, int sv0, cdptr ar, cdptr q6, bool vo = false) {
         double p6[6], dx[3], ps[3];
 #pragma unroll
-        for (int t = 0; t < 6; ++t) p6[t] = q6[t];
+        for (int t = 0; t < 6; ++t) p6[t] = ld_stream_resid(q6, t);
 #pragma unroll
         for (int a = 0; a < 3; ++a) dx[a] = D[sv0 + a] * XS(sv0 + a, r0 + a);
 #pragma unroll
@@ -1913,7 +1913,7 @@ DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
             cdptr q21 = q.rec(k) + Rec::QD;
             double p21[21], dx[6], ps[3], ar[3];
 #pragma unroll
-            for (int t = 0; t < 21; ++t) p21[t] = q21[t];
+            for (int t = 0; t < 21; ++t) p21[t] = ld_stream_resid(q21, t);
 #pragma unroll
             for (int t = 0; t < 6; ++t) dx[t] = D[w0 + t] * XS(w0 + t, q.ix.rd(k, t));
             cdptr xk = xd + NS * k;

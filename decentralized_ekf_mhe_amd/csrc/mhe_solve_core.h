@@ -215,7 +215,7 @@ struct SolveCtx {
     DEKF_FN double adyn(int k, int r, int j) const { return adyn_entry(R + 9 * k, c.dt, r, j); }
     // per-row rho from the scaled bounds (OSQP set_rho_vec / osqp_update_rho)
     DEKF_FN double rho_of(double lb, double ub) const {
-        if (lb < -OSQP_INFTY * MIN_SCALING && ub > OSQP_INFTY * MIN_SCALING) return RHO_MIN;
+        if (lb < -c.inf_thr && ub > c.inf_thr) return RHO_MIN;
         return (ub - lb < RHO_TOL) ? RHO_EQ_OVER_RHO_INEQ * rho : rho;
     }
     // Meas and Dyn rows are equalities by construction (l == u): only the VO rows keep an upper bound
@@ -226,8 +226,8 @@ struct SolveCtx {
     // the same for a ring slot computed once (the modulo by a run-time ring size is a ~40-instruction software division)
     DEKF_FN void bounds_at(int slot, int kind, int o, double& lb, double& ub) const {
         cdptr r = DEKF_CSPAN(s.rec + ((size_t)b * c.wcap + slot) * c.rec, c.rec);
-        if (kind == 0) lb = ub = r[Rec::BM + o];
-        else if (kind == 1) lb = ub = (o < 3 ? -0.5 * c.dt * c.dt * r[Rec::AS + o] : (o < 6 ? -c.dt * r[Rec::AS + o - 3] : 0.0));
+        if (kind == 0) lb = ub = ld_stream(r, Rec::BM + o);
+        else if (kind == 1) lb = ub = (o < 3 ? -c.hdt2 * ld_stream(r, Rec::AS + o) : (o < 6 ? -c.dt * ld_stream(r, Rec::AS + o - 3) : 0.0));
         else {  // VO flag and bound come from the step's snapshot, not from the record (update(T + 1) may be rewriting them)
             cdptr v = vo + 4 * slot;
             if (v[0] != 0.0) lb = ub = v[1 + o];
@@ -268,12 +268,12 @@ DEKF_FN void stage_p(Q& q) {
             int k = e / PS, o = e - k * PS;
             cdptr r = q.rec(k);
             // [Qm 6L | Qd 21 | Qc 6 | Qf 6L (foot states)]: the last block is contiguous with Qm in the record
-            Pst[e] = o < 6 * L ? r[Rec::qm(NM) + o]
-                               : (o < 6 * L + 21 ? r[Rec::QD + o - 6 * L] : (o < 6 * L + 27 ? r[Rec::QC + o - 6 * L - 21] : r[Rec::qf(NM) + o - 6 * L - 27]));
+            Pst[e] = ld_stream(r, o < 6 * L ? Rec::qm(NM) + o
+                                             : (o < 6 * L + 21 ? Rec::QD + o - 6 * L : (o < 6 * L + 27 ? Rec::QC + o - 6 * L - 21 : Rec::qf(NM) + o - 6 * L - 27)));
         } else {
             int p = e - K * PS, i = 0;
             while (p >= NS - i) { p -= NS - i; ++i; }
-            Pst[e] = q.Mp[NS * i + i + p];
+            Pst[e] = ld_stream(q.Mp, NS * i + i + p);
         }
     });
     q.staged = true;
@@ -283,7 +283,7 @@ template <class Q>
 DEKF_FN void solve_scale(Q& q) {
     constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, SV = 2 * NS + 3 + NM, PS = 6 * L + 27 + 6 * L * FT;
     const int n = q.n, m = q.m, K = q.K, K1 = q.K - 1, nmeas = K * L;
-    const double dt = q.c.dt, hdt2 = 0.5 * dt * dt;
+    const double dt = q.c.dt, hdt2 = q.c.hdt2;
     dptr D = q.D, E = q.E, Pst = q.Pst, pc = q.x, Dn = q.xt, En = q.zt;  // (R3: the caller points all of these at LDS)
     cdptr g = q.np;
     const auto& ix = q.ix;
@@ -721,8 +721,8 @@ DEKF_FN void solve_scale(Q& q) {
             double qn = 0.0;
 #pragma unroll
             for (int j = 0; j < NS; ++j) qn = dmax(qn, fabs(cc * Dw[j] * gq[j]));
-            double ct = 1.0 / limit_scaling(dmax(psum / (double)n, limit_scaling(qn)));
-            q.cc = cc * ct;
+            double ct = 1.0 / limit_scaling(dmax(psum / uni((double)n), limit_scaling(qn)));
+            q.cc = uni_pin(cc * ct);
             dptr t0 = Dr; Dr = Dw; Dw = t0;
             dptr t1 = Er; Er = Ew; Ew = t1;
         }
@@ -748,8 +748,8 @@ DEKF_FN void solve_scale(Q& q) {
         double qn = 0.0;
 #pragma unroll
         for (int j = 0; j < NS; ++j) qn = dmax(qn, fabs(cc * D[j] * gq[j]));
-        double ct = 1.0 / limit_scaling(dmax(psum / (double)n, limit_scaling(qn)));
-        q.cc = cc * ct;
+        double ct = 1.0 / limit_scaling(dmax(psum / uni((double)n), limit_scaling(qn)));
+        q.cc = uni_pin(cc * ct);
     }
     DEKF_SYNC();
 }
@@ -1021,7 +1021,7 @@ DEKF_FN bool solve_factor(Q& q) {
     //     compile-time structure; only the component a = j mod 3 is a run-time select.  (Was three sweeps
     //     over 1539 + 2439 + 1539 items with per-item index decoding: 57 k cycles per factorisation.)
     {
-        const double dt = c.dt, hdt2 = 0.5 * dt * dt;
+        const double dt = c.dt, hdt2 = c.hdt2;
         const int K1 = K - 1, ntx = (3 * K + 63) >> 6, ntxf = FT ? (3 * L * K + 63) >> 6 : 0;
         wtiles(3 * ntx + ntxf, [&](int tile, int lane) {
             if (FT && tile >= 3 * ntx) {
@@ -1698,7 +1698,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     if (DEKF_LANE() == 0)
         for (int i = 0; i < DEKF_PROF_SLOTS; ++i) q.prof[i] = 0.0;
 #endif
-    wfor(K * 9, [&](int e) { q.R[e] = q.rec(e / 9)[Rec::R + e % 9]; });
+    wfor(K * 9, [&](int e) { q.R[e] = ld_stream(q.rec(e / 9), Rec::R + e % 9); });
     if constexpr (R3) {
         // D and E stay in LDS for the whole solve; the Ruiz passes' temporaries pc, En, Dn sit behind the staged P blocks inside
         // S^-1 | W, which are not live before the first factorisation.
@@ -1717,7 +1717,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
     }
     DEKF_PROF_MARK(q, 0);
-    q.rho = dmin(dmax(c.rho0, RHO_MIN), RHO_MAX);
+    q.rho = uni_pin(c.rho0c);
     // scaled bounds, cold start
     dptr x = q.x, z = q.z, y = q.y, at = q.at;
     wfor(R3 ? m : n + m, [&](int e0) {
@@ -1740,7 +1740,8 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     // scaled linear cost on x_0 (LDS copy for the per-lane look-ups)
     wfor(NS, [&](int j) { q.tmp[TM::QSL + j] = q.cc * q.D[ix.x(0, j)] * q.np[j]; });
     const double sigma = c.sigma, alpha = c.alpha;
-    const double cinv = 1.0 / q.cc;
+    const double cinv = uni_pin(1.0 / q.cc);
+    const double eps_rel_cinv = uni_pin(c.eps_rel * cinv);  // (the compiler forms and hoists this product anyway: into a VGPR pair that lives for the whole solve)
     int iter = 0;
     bool done = false;
     if constexpr (!R3) {  // (R3: the first chunk's load of the row blocks is the restart)
@@ -1778,11 +1779,11 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
                 for (int i_ = 0; i_ < 8; ++i_) q.prof[22 + i_] = va[i_];
             }
 #endif
-            info.pri_res = ra[0];
-            info.dua_res = cinv * va[0];
+            info.pri_res = uni_pin(ra[0]);
+            info.dua_res = uni_pin(cinv * va[0]);
             if (can_check || iter == c.max_iter) {
                 double eps_pri = c.eps_abs + c.eps_rel * dmax(ra[1], ra[2]);
-                double eps_dua = c.eps_abs + c.eps_rel * cinv * dmax(va[1], dmax(va[2], va[3]));
+                double eps_dua = c.eps_abs + eps_rel_cinv * dmax(va[1], dmax(va[2], va[3]));
                 if (info.pri_res < eps_pri && info.dua_res < eps_dua) { info.status = DEKF_SOLVE_OK; done = true; }
             }
             DEKF_PROF_MARK(q, 10);
@@ -1791,7 +1792,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
                 double du = va[4] / (dmax(va[5], dmax(va[6], va[7])) + 1e-10);
                 double rho_new = dmin(dmax(q.rho * sqrt(pr / (du + 1e-10)), RHO_MIN), RHO_MAX);
                 if (rho_new > q.rho * c.adaptive_rho_tolerance || rho_new < q.rho / c.adaptive_rho_tolerance) {
-                    q.rho = rho_new;
+                    q.rho = uni_pin(rho_new);
                     info.rho_updates++;
                     DEKF_SYNC();
                     if constexpr (R3) {  // the factorisation's temporaries take the LDS the row state rests in: over to the slab and back
@@ -1841,7 +1842,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     if constexpr (POLISH) if (c.polish && ok && finite && info.status == DEKF_SOLVE_OK) {
         const double pri0 = info.pri_res, dua0 = info.dua_res, rho_keep = q.rho;
         DEKF_SYNC();
-        q.rho = dmin(dmax(1.0 / (c.delta * RHO_EQ_OVER_RHO_INEQ), RHO_MIN), RHO_MAX);  // rho of an equality row: 1 / delta
+        q.rho = uni_pin(dmin(dmax(1.0 / (c.delta * RHO_EQ_OVER_RHO_INEQ), RHO_MIN), RHO_MAX));  // rho of an equality row: 1 / delta
         q.zlo = true;
         if constexpr (R3) {
             q.cold = true;

@@ -368,6 +368,49 @@ inline void wtiles(int ntiles, F f) {
 }
 #endif
 
+// A load of data that is read once per solve (window records, the solve's input snapshot): with the non-temporal hint the line
+// is marked for early eviction in L2 instead of pushing out the workgroup's slab lines, which are written once per factorisation
+// and read back a few times per solve — without the hint every one of them went to HBM and came back.
+#if DEKF_DEVICE_BUILD
+template <class P>
+DEKF_FN double ld_stream(P p, int i) {
+#ifdef DEKF_NT_ALL
+    return __builtin_nontemporal_load(&p[i]);
+#else
+    return p[i];
+#endif
+}
+template <class P>
+DEKF_FN double ld_stream_resid(P p, int i) { return __builtin_nontemporal_load(&p[i]); }
+#else
+template <class P>
+inline double ld_stream(P p, int i) { return p[i]; }
+template <class P>
+inline double ld_stream_resid(P p, int i) { return p[i]; }
+#endif
+
+// A wave-uniform double pinned into an SGPR pair (two v_readfirstlane).  The f64 pipeline is vector-only, so a uniform value that
+// is COMPUTED (dt^2 / 2, 1000 rho, 1 - alpha, the cost scaling c, ...) lives in a VGPR pair, and the compiler hoists it to the
+// top of the kernel and keeps it there: at 168 VGPRs (three workgroups per CU) a dozen of them were most of what the register
+// allocator spilled — each spill slot a 512-byte wave access to scratch that no longer fits L2 at that residency.  From an SGPR
+// pair a VALU instruction takes the value as a scalar operand.  The value is unchanged; the host build is the identity.
+#if DEKF_DEVICE_BUILD
+DEKF_FN double uni(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return __hiloint2double(hi, lo);
+}
+// (Pinning the read-back to the definition with inline assembly — so that the compiler cannot sink it to the uses and keep the
+// VGPR pair alive — was tried both ways and does not work: hand-written v_readfirstlane inside the statement gave wrong results and
+// erratic timing (inline assembly gets no hazard handling), an empty statement with "+s" constraints behind the intrinsic ends in
+// "illegal VGPR to SGPR copy" wherever the compiler has already decided to keep that value's chain on the vector side.)
+DEKF_FN double uni_pin(double v) { return uni(v); }
+#else
+inline double uni(double v) { return v; }
+inline double uni_pin(double v) { return v; }
+#endif
+
 // 1/x and 1/sqrt(x) to double precision without the IEEE division / square-root sequences (about 25 and 65
 // instructions on gfx950): hardware estimate (v_rcp_f64 / v_rsq_f64) plus two Newton steps.  Last-bit
 // differences against 1.0 / x and 1.0 / sqrt(x) are possible; the host build uses those.
@@ -394,7 +437,7 @@ inline double rsqrt_fast(double x) { return 1.0 / std::sqrt(x); }
 // different instantiations of the same expression (measured: the three-workgroup and the two-workgroup solve kernels drifted
 // apart by an ulp per iteration when their row loops were restructured).
 DEKF_FN double lin2(double a, double x, double b, double y) { return fma(a, x, b * y); }
-DEKF_FN double relax(double alpha, double v, double w) { return fma(alpha, v, (1.0 - alpha) * w); }
+DEKF_FN double relax(double alpha, double v, double w) { return fma(alpha, v, uni(1.0 - alpha) * w); }
 DEKF_FN double dmax(double a, double b) { return a > b ? a : b; }
 DEKF_FN double dmin(double a, double b) { return a < b ? a : b; }
 

@@ -27,8 +27,22 @@ def _ptr_where(a, dtype):
     return C.c_void_p(a.data_ptr()), (capi.DEKF_DEVICE if a.is_cuda else capi.DEKF_HOST)
 
 
+def _torch_runtime_first():
+    """PyTorch-ROCm ships its own copy of the HIP runtime (torch/lib/libamdhip64.so).  If libdekf.so has already brought up the
+    system's copy when torch initialises its own, torch finds no device ("No HIP GPUs are available": seen on the GPU box when a tool
+    created an estimator first and uploaded tensors afterwards).  Loaded the other way round, libdekf.so binds to the runtime that is
+    already in the process.  So whoever is going to hand torch tensors to this class gets torch's runtime initialised first; without
+    torch installed this is a no-op (numpy arguments and the C / C++ callers never need it)."""
+    try:
+        import torch
+        torch.cuda.is_available()
+    except Exception:  # noqa: BLE001
+        pass
+
+
 class BatchedEstimator:
     def __init__(self, params: DekfParams, batch: int, device: int = 0, stream=None):
+        _torch_runtime_first()
         self.lib = capi.load()
         self.params = params.copy()
         self.batch = batch
@@ -184,6 +198,7 @@ class BatchedEstimator:
 
 
 def new_unique_id() -> bytes:
+    _torch_runtime_first()
     buf = C.create_string_buffer(capi.DEKF_UNIQUE_ID_BYTES)
     capi.check(capi.load().dekf_comm_unique_id(buf))
     return buf.raw

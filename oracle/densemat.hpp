@@ -188,6 +188,66 @@ inline Mat inverse(const Mat& A) {
     return Ai;
 }
 
+// TEST KNOB for the one inverse whose conditioning limits parity: the 21/24/33/36-dim saddle matrix of marginalizeQP
+// (MheSrb.cpp:588,640), diagonal entries from 1e-11 to 1e14 with leg_odom_type 1.  How far do two equally legitimate fp64
+// evaluations of the reference's formula lie apart?  (tests/test_foot_states.py measures it and ties the device's allowance to it.)
+//   0  as above: Eigen's PartialPivLU in double — what every parity test compares with
+//   1  the same elimination in long double (x87 80-bit: 11 more mantissa bits), result rounded to double
+//   2  the same double elimination on the symmetrically REVERSED matrix P A P (another, equally valid, pivot sequence)
+//   3  as 0, but the SPD inverses M^-1, Q^-1, R^-1 that S is built from go through the pivoted LU instead of the Cholesky solve
+//      (est_oracle.hpp: marginalize): S itself then differs in its last bits, as it does in any other implementation
+//   4  3 and 2 together
+inline int& marg_inverse_variant() { static int v = 0; return v; }
+inline Mat lu_inverse_long(const Mat& A) {
+    const int n = A.r;
+    std::vector<long double> LU((size_t)n * n), X((size_t)n * n), y(n);
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) LU[(size_t)i * n + j] = A(i, j);
+    std::vector<int> piv(n);
+    for (int i = 0; i < n; ++i) piv[i] = i;
+    for (int k = 0; k < n; ++k) {
+        int p = k;
+        long double best = fabsl(LU[(size_t)k * n + k]);
+        for (int i = k + 1; i < n; ++i)
+            if (fabsl(LU[(size_t)i * n + k]) > best) { best = fabsl(LU[(size_t)i * n + k]); p = i; }
+        if (p != k) {
+            for (int j = 0; j < n; ++j) std::swap(LU[(size_t)k * n + j], LU[(size_t)p * n + j]);
+            std::swap(piv[k], piv[p]);
+        }
+        for (int i = k + 1; i < n; ++i) {
+            LU[(size_t)i * n + k] /= LU[(size_t)k * n + k];
+            const long double l = LU[(size_t)i * n + k];
+            for (int j = k + 1; j < n; ++j) LU[(size_t)i * n + j] -= l * LU[(size_t)k * n + j];
+        }
+    }
+    Mat Ai(n, n);
+    for (int col = 0; col < n; ++col) {
+        for (int i = 0; i < n; ++i) {
+            long double s = (piv[i] == col) ? 1.0L : 0.0L;
+            for (int j = 0; j < i; ++j) s -= LU[(size_t)i * n + j] * y[j];
+            y[i] = s;
+        }
+        for (int i = n - 1; i >= 0; --i) {
+            long double s = y[i];
+            for (int j = i + 1; j < n; ++j) s -= LU[(size_t)i * n + j] * X[(size_t)j * n + col];
+            X[(size_t)i * n + col] = s / LU[(size_t)i * n + i];
+        }
+    }
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Ai(i, j) = (double)X[(size_t)i * n + j];
+    return Ai;
+}
+inline Mat inverse_marg(const Mat& A) {
+    const int v = marg_inverse_variant(), n = A.r;
+    if (v == 1) return lu_inverse_long(A);
+    if (v == 2 || v == 4) {
+        Mat R(n, n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) R(i, j) = A(n - 1 - i, n - 1 - j);
+        Mat Ri = inverse(R), Ai(n, n);
+        for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) Ai(i, j) = Ri(n - 1 - i, n - 1 - j);
+        return Ai;
+    }
+    return inverse(A);
+}
+
 // SPD inverse by Cholesky solve against I: what the reference's
 // SimplicialLLT::solve(I) computes (MheSrb.cpp:524-525,555-559,610-614).
 inline Mat spd_inverse(const Mat& A) {

@@ -203,14 +203,18 @@ class QpBook {
                 n_p = -(M_p * cost[prior].b);
                 cost.erase(prior);
             }
-            Mat M_inv = spd_inverse(M_p);
+            // (test knob, densemat.hpp: variants >= 3 take the three SPD inverses that feed S through the pivoted LU instead of the
+            // Cholesky solve — S then differs from the reference's in its last bits, which is what any other implementation's does)
+            const bool alt_in = marg_inverse_variant() >= 3;
+            auto spd_inv = [&](const Mat& X) { return alt_in ? inverse(X) : spd_inverse(X); };
+            Mat M_inv = spd_inv(M_p);
             const Mat& R_meas = cost[meas].Q;
             const Mat& H_meas = con[meas].dep[kx];
             const Vec& y_meas = con[meas].lb;
             const Mat& Q_dyn = cost[dyn].Q;
             const Mat& A_dyn = con[dyn].dep[kx];
             Vec b_dyn = -con[dyn].lb;
-            Mat R_meas_inv = spd_inverse(R_meas);
+            Mat R_meas_inv = spd_inv(R_meas);
             int na;          // rows of the stacked [dyn; cam] block
             Mat A_m, Q_m_inv;
             Vec b_m;
@@ -228,12 +232,12 @@ class QpBook {
                 b_m = Vec(na, 0.0);
                 set_segment(b_m, 0, b_dyn);
                 set_segment(b_m, ns, b_cam);
-                Q_m_inv = spd_inverse(Q_m);
+                Q_m_inv = spd_inv(Q_m);
             } else {
                 na = ns;
                 A_m = A_dyn;
                 b_m = b_dyn;
-                Q_m_inv = spd_inverse(Q_dyn);
+                Q_m_inv = spd_inv(Q_dyn);
             }
             int dim = na + nm;
             Mat S(dim, dim);
@@ -251,7 +255,7 @@ class QpBook {
             if (na > ns)
                 for (int i = 0; i < nc; ++i) B(ns + i, i) = -1.0;
             Mat C = B.T();
-            Mat S_inv = inverse(S);
+            Mat S_inv = inverse_marg(S);  // = inverse(S) unless a test turned the knob (densemat.hpp)
             Vec u(dim, 0.0);
             set_segment(u, 0, -b_m + A_m * (M_inv * n_p));
             set_segment(u, na, y_meas + H_meas * (M_inv * n_p));

@@ -106,6 +106,8 @@ void orc_ekf_vo_correct(void* h, const double* q, const double* q_vo, const doub
 }
 
 // ---------------------------------------------------------------- estimator
+// test knob (densemat.hpp: marg_inverse_variant): 0 the reference's evaluation, 1 long double, 2 reversed pivot order; process-wide
+void orc_set_marg_inverse_variant(int v) { marg_inverse_variant() = v; }
 void* orc_est_create(const dekf_params* p) { return new EstOracle(*p); }
 void orc_est_destroy(void* h) { delete (EstOracle*)h; }
 void orc_est_set_imu(void* h, double t, const double* accel, const double* gyro) {

@@ -7,19 +7,20 @@
 set -e
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/traffic
+rm -rf $OUT          # (a second run in one call used to pick up the first run's counter file)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 $R/bench.py --steps 6 --warmup 24 --no-cpu-baseline > $OUT/$c.log 2>&1
 done
 python3 - "$OUT" "$R" <<'PY'
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 out, root = sys.argv[1], sys.argv[2]
 sys.path.insert(0, root)
 import bench
 vals = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True)[0]
+    f = sorted(glob.glob(f"{out}/{c}/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1]
     rows = [r for r in csv.DictReader(open(f)) if "k_mhe_solve" in r["Kernel_Name"] and r["Counter_Name"] == c]
     last = rows[-6:]                      # the timed, steady-state launches
     vals[c] = sum(float(r["Counter_Value"]) for r in last) / len(last)
