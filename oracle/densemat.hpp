@@ -194,9 +194,10 @@ inline Mat inverse(const Mat& A) {
 //   0  as above: Eigen's PartialPivLU in double — what every parity test compares with
 //   1  the same elimination in long double (x87 80-bit: 11 more mantissa bits), result rounded to double
 //   2  the same double elimination on the symmetrically REVERSED matrix P A P (another, equally valid, pivot sequence)
-//   3  as 0, but the SPD inverses M^-1, Q^-1, R^-1 that S is built from go through the pivoted LU instead of the Cholesky solve
+//   3  as 0, but the SPD inverses M^-1, Q^-1, R^-1 that S is built from run their Cholesky solve in the reversed elimination order
 //      (est_oracle.hpp: marginalize): S itself then differs in its last bits, as it does in any other implementation
 //   4  3 and 2 together
+//   5  as 0 on S with every entry moved by one unit in the last place (a fixed symmetric pattern)
 inline int& marg_inverse_variant() { static int v = 0; return v; }
 inline Mat lu_inverse_long(const Mat& A) {
     const int n = A.r;
@@ -238,6 +239,19 @@ inline Mat lu_inverse_long(const Mat& A) {
 inline Mat inverse_marg(const Mat& A) {
     const int v = marg_inverse_variant(), n = A.r;
     if (v == 1) return lu_inverse_long(A);
+    if (v == 5) {
+        // every entry of S moved by one unit in the last place, up or down by a fixed symmetric pattern: what another order of the
+        // sums that BUILD S (or a fused multiply-add in one of them) does to it
+        Mat P = A;
+        for (int i = 0; i < n; ++i)
+            for (int j = i; j < n; ++j) {
+                const unsigned h = (unsigned)(i * 2654435761u) ^ (unsigned)(j * 40503u + 0x9e3779b9u);
+                const double f = ((h >> 7) & 1u) ? 1.0 + 0x1p-52 : 1.0 - 0x1p-53;
+                P(i, j) = A(i, j) * f;
+                P(j, i) = A(j, i) * f;
+            }
+        return inverse(P);
+    }
     if (v == 2 || v == 4) {
         Mat R(n, n);
         for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) R(i, j) = A(n - 1 - i, n - 1 - j);

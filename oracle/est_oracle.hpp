@@ -203,10 +203,23 @@ class QpBook {
                 n_p = -(M_p * cost[prior].b);
                 cost.erase(prior);
             }
-            // (test knob, densemat.hpp: variants >= 3 take the three SPD inverses that feed S through the pivoted LU instead of the
-            // Cholesky solve — S then differs from the reference's in its last bits, which is what any other implementation's does)
+            // (test knob, densemat.hpp: variants >= 3 take the three SPD inverses that feed S in another elimination order — S then
+            // differs from the reference's in its last bits, which is what any other implementation's does)
             const bool alt_in = marg_inverse_variant() >= 3;
-            auto spd_inv = [&](const Mat& X) { return alt_in ? inverse(X) : spd_inverse(X); };
+            auto spd_inv = [&](const Mat& X) {
+                if (!alt_in) return spd_inverse(X);
+                // the same Cholesky solve in the opposite elimination order, on the symmetrised matrix (one triangle must stay the
+                // only source: fed from both triangles of M — e.g. through a pivoted LU — the recursion amplifies their rounding
+                // asymmetry and diverges within three swing phases)
+                const int n = X.r;
+                Mat Rv(n, n);
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) Rv(i, j) = X(n - 1 - (i > j ? i : j), n - 1 - (i > j ? j : i));  // lower triangle of X, reversed
+                Mat Ri = spd_inverse(Rv), Xi(n, n);
+                for (int i = 0; i < n; ++i)
+                    for (int j = 0; j < n; ++j) Xi(i, j) = Ri(n - 1 - i, n - 1 - j);
+                return Xi;
+            };
             Mat M_inv = spd_inv(M_p);
             const Mat& R_meas = cost[meas].Q;
             const Mat& H_meas = con[meas].dep[kx];

@@ -270,6 +270,25 @@ class Pipe:
         return q
 
 
+class marg_inverse_variant:
+    """TEST KNOB of the oracle (oracle/densemat.hpp: marg_inverse_variant), as a context manager: how the saddle matrix of
+    marginalizeQP (MheSrb.cpp:588,640) is inverted — 0 the reference's evaluation (what every parity test compares with),
+    1 long double, 2 reversed pivot order, 5 on S moved by one unit in the last place.  Process-wide: no oracle threads of
+    another variant may run meanwhile."""
+
+    def __init__(self, v):
+        self.v = int(v)
+
+    def __enter__(self):
+        L = lib()
+        L.orc_set_marg_inverse_variant.argtypes = [C.c_int]
+        L.orc_set_marg_inverse_variant.restype = None
+        L.orc_set_marg_inverse_variant(self.v)
+
+    def __exit__(self, *a):
+        lib().orc_set_marg_inverse_variant(0)
+
+
 def run_streams(params, s, nthreads=1, want_iters=False):
     """Run the whole log through the oracle; returns x[K,B,ns], v_b[K,B,3], quat[K,B,4], secs."""
     K, B = s["imu_t"].shape
