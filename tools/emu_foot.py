@@ -28,5 +28,6 @@ for k in range(W, W + steps):
 est.sync(); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(json.dumps({"lib": os.environ.get("DEKF_LIB", "product"), "fixed_iters": iters, "ms_per_step": 1e3 * dt / steps,
-                  "steps_per_s_at_this_iteration_count": B * steps / dt, "mean_iters": float(est.solver_info()["iters"].mean())}))
+                  "steps_per_s_at_this_iteration_count": B * steps / dt, "mean_iters": float(est.solver_info()["iters"].mean()),
+                  "solve_workgroups": est.launch_info()["solve_workgroups"]}))
 est.close()
