@@ -26,10 +26,13 @@ else
     run() { "$@" & pids+=($!); while [ "$(jobs -rp | wc -l)" -ge "$JOBS" ]; do sleep 0.2; done; }
     # heaviest sets first (foot-state kernels, then the generic ones)
     # DEKF_NO_MLICM: the kernel sets compiled with LLVM's machine-level loop-invariant code motion off (default: the fixed-horizon Go1
-    # and Cassie sets, 1 and 2).  That pass hoists constant materialisations and address arithmetic to the top of a kernel, where
-    # they stay live across the whole solve: at the 168 VGPRs of the three-workgroup kernels the register allocator answered with
-    # 43 spilled VGPRs (5 without the pass), i.e. scratch traffic beyond L2.  "all" / "none" for A/B builds.
-    NO_MLICM=${DEKF_NO_MLICM:-"1 2"}
+    # and Cassie sets, 1 and 2, and the one-leg set 4).  That pass hoists constant materialisations and address arithmetic to the top
+    # of a kernel, where they stay live across the whole solve: at the 168 VGPRs of the three-workgroup kernels the register
+    # allocator answered with 43 spilled VGPRs (5 without the pass), i.e. scratch traffic beyond L2; the
+    # rows-in-registers kernel of set 4 (k_mhe_solve_rr_1, 256 VGPRs) spills 40 VGPRs inside its iteration loops with the pass and
+    # none without.  Not for every set: hipcc 7.2 dies on some of the others without the pass ("Illegal instruction detected").
+    # "all" / "none" for A/B builds.
+    NO_MLICM=${DEKF_NO_MLICM:-"1 2 4"}
     for m in 512 256 128 64 32 16 8 4 1 2 1024; do
         X=""
         case " $NO_MLICM " in *" $m "*|*" all "*) X="-mllvm -disable-machine-licm";; esac

@@ -33,6 +33,9 @@ DEKF_DECL_K(k_mhe_solve_r3_4_n20)
 DEKF_DECL_K(k_mhe_solve_r3_2_n20)
 #endif
 DEKF_DECL_SOLVE(1)
+#ifndef DEKF_NO_RR
+DEKF_DECL_K(k_mhe_solve_rr_1)
+#endif
 DEKF_DECL_SOLVE(2)
 DEKF_DECL_SOLVE(3)
 DEKF_DECL_SOLVE(4)
@@ -305,6 +308,34 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             h->solve_grid_full = (int)(sf < batch ? sf : batch);
             // only where the batch really fills more slots than the two-workgroup kernel offers: below that the row state
             // would travel through the slab for no residency gained
+            if (pcf > per_cu && h->solve_grid_full > h->solve_grid) {
+                h->solve_kernel_full = full;
+                h->solve_name_full = full_name;
+            }
+        }
+    }
+#endif
+#ifndef DEKF_NO_RR
+    // One-legged robots with long windows (PogoX: N = 100): the generic placement keeps 103 KB of iterates in LDS, one workgroup per
+    // CU.  Full windows run the kernel that keeps the row state in registers (mhe_admm_core.h: admm_chunk_rr) — 77 KB, two per CU —
+    // when the batch fills more slots than the generic kernel offers.
+    if (!h->solve_kernel_full && !c.ft && c.L == 1 && (cap == 0 || cap > per_cu)) {
+        const SolveFn full = c.polish ? k_mhe_solve_rr_1_pol : k_mhe_solve_rr_1;
+        const char* const full_name = c.polish ? "k_mhe_solve_rr_1_pol" : "k_mhe_solve_rr_1";
+        hipFuncAttributes fa;
+        size_t static_lds = 512;
+        if (hipFuncGetAttributes(&fa, (const void*)full) == hipSuccess) static_lds = fa.sharedSizeBytes;
+        if (lay.rr_fits(c.L, static_lds)) {
+            h->lds_solve_full = lay.rr_lds_bytes();
+            if (h->lds_solve_full > 64 * 1024)
+                (void)hipFuncSetAttribute((const void*)full, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_solve_full);
+            int pcf = 1;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&pcf, (const void*)full, DEKF_SOLVE_THREADS, h->lds_solve_full) != hipSuccess || pcf < 1)
+                pcf = 1;
+            if (pcf > 2) pcf = 2;  // (rr_fits has decided that two fit; the kernel is compiled for two wavefronts per SIMD)
+            if (cap > 0 && pcf > cap) pcf = cap;
+            const long sf = (long)pcf * prop.multiProcessorCount;
+            h->solve_grid_full = (int)(sf < batch ? sf : batch);
             if (pcf > per_cu && h->solve_grid_full > h->solve_grid) {
                 h->solve_kernel_full = full;
                 h->solve_name_full = full_name;

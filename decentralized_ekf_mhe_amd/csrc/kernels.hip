@@ -180,6 +180,9 @@ DEKF_SOLVE_KERNEL_IF(0, k_mhe_solve_r3_4_n20, DEKF_R3_WAVES, 4, true, true, 20, 
 DEKF_SOLVE_KERNEL_IF(1, k_mhe_solve_lg_2_n20, 2, 2, true, false, 20)
 DEKF_SOLVE_KERNEL_IF(1, k_mhe_solve_r3_2_n20, DEKF_R3_WAVES, 2, true, true, 20, 0, true)
 DEKF_SOLVE_KERNELS(2, 1)
+// one leg, long windows (PogoX, N = 100): full windows with the row state in registers at a run-time horizon, factor in the slab,
+// TWO workgroups per CU instead of the one that the generic placement's 103 KB of iterates allow (mhe_admm_core.h: admm_chunk_rr)
+DEKF_SOLVE_KERNEL_IF(2, k_mhe_solve_rr_1, 2, 1, false, false, 0, 0, true)
 DEKF_SOLVE_KERNELS(3, 2)
 DEKF_SOLVE_KERNELS(4, 3)
 DEKF_SOLVE_KERNELS(5, 4)

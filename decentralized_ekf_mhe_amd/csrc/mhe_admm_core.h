@@ -489,7 +489,10 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
     const int lane = DEKF_LANE() & 63, row = lane >> 4, li = lane & 15;
     const int i = li < 9 ? li : 8;
     const bool act = li < 9, leg = row < 2, top = (row & 1) == 0;
-    dptr xs = q.xs, xd = q.xd, x = q.x;
+    // the x blocks: inside the full variable vector (stride SV per step), or compact (rows in registers: [K][9] in LDS); D is
+    // always indexed inside the full scaling vector
+    constexpr int XST = Q::R3 ? 9 : SV;
+    dptr xs = q.xs, xd = q.xd, x = Q::R3 ? q.xb : q.x;
     struct Ops { double w[9], rhs; };
     // ---------------- forward: step s = 1..M
     cdptr fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
@@ -540,14 +543,14 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
         double s9[9];
 #pragma unroll
         for (int t = 0; t < 9; ++t) s9[t] = q.Sinv[M * 81 + 9 * i + t];
-        const double dm = q.D[M * SV + i], xm = x[M * SV + i];
+        const double dm = q.D[M * SV + i], xm = x[M * XST + i];
         const double src = all_rows_from_row1(v);                 // f^_{M+1} everywhere
         const double res = chain_matvec_dpp(src, w, row == 0 ? v : 0.0);
         if (row == 3 && act) xd[9 * (M + 1) + i] = res;            // -g_{M+1}
         const double um = -chain_matvec_dpp(res, s9, 0.0);         // row 0: S_M^-1 (f_M - W^_M f^_{M+1})
         if (row == 0 && act) {
             xd[9 * M + i] = dm * um;
-            x[M * SV + i] = relax(alpha, um, xm);
+            x[M * XST + i] = relax(alpha, um, xm);
         }
         v = row1_from_row0(um);                                    // rows 0 and 1 start from u_M
     }
@@ -556,9 +559,9 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
         struct Bops { double w[9], ng, dsc, xo; };
         const bool own = leg && act;
         dptr xdp = own ? xd + 9 * M + i : dummy;
-        dptr xp = own ? x + M * SV + i : dummy;
+        dptr xp = own ? x + M * XST + i : dummy;
         cdptr Dp = q.D + (own ? M * SV + i : 0);     // (D may sit in HBM: no LDS dummy here, idle lanes re-read D[0])
-        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -SV : SV) : 0;
+        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0, dstep = own ? (top ? -SV : SV) : 0;
         cdptr Wp = q.Wk + (top ? M : M - 1) * 81 + i;  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
         const int wstep = top ? -81 : 81;
         auto bload = [&](int s, Bops& o) {
@@ -567,7 +570,7 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
             o.ng = xdp[sl * xdstep];
-            o.dsc = Dp[sl * xstep];
+            o.dsc = Dp[sl * dstep];
             o.xo = xp[sl * xstep];
         };
         Bops r[RING];
@@ -1417,6 +1420,8 @@ struct RowRegsT {
 // iteration left them when a chunk merely continues after a termination check.  Neither t nor rho E D ever go to the slab, and
 // the three-workgroup kernels run no separate restart phase.  Writes w (and gb) to LDS: a workgroup barrier follows.
 template <int KIND, class Q>
+DEKF_FN void row_regs_fill(Q& q, double sigma, RowRegsT<KIND>& t, cdptr sp);
+template <int KIND, class Q>
 DEKF_FN void row_regs_load(Q& q, int lane, double sigma, RowRegsT<KIND>& t) {
     constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
@@ -1445,20 +1450,30 @@ DEKF_FN void row_regs_load(Q& q, int lane, double sigma, RowRegsT<KIND>& t) {
         }
     }
     t.valid = true;
+    row_regs_fill<KIND>(q, sigma, t, sp);
+}
+// the block is chosen (t.valid, k, r0, sv0, vel, meas, vo, xo; sp: its slack-block inverse when it is a Meas block): constants, state
+// and the restart
+template <int KIND, class Q>
+DEKF_FN void row_regs_fill(Q& q, double sigma, RowRegsT<KIND>& t, cdptr sp) {
+    constexpr int L = Q::LEGS;
+    const int K = q.K, nmeas = K * L;
     const bool vo = t.vo;
+    // slack-block inverses: entry-major in the slab of the three-workgroup kernels, block-major for RR (solve_factor 3a)
+    constexpr bool EM = Q::FACTOR_LDS;
     if constexpr (KIND == 1) {
-        const DynPairMat S(q.Sw + t.k, t.vel, K);
+        const DynPairMat S(EM ? q.Sw + t.k : q.Sw + t.k * SWS, t.vel, EM ? K : 1);
 #pragma unroll
         for (int i = 0; i < 6; ++i) t.a[i] = S.a[i];
 #pragma unroll
         for (int i = 0; i < 9; ++i) t.b[i] = S.b[i];
     } else if (KIND == 2 && !t.meas) {
-        const VoOrBiasMat S(q.Sc + t.k, q.Sw + t.k + 21 * K, vo, K);
+        const VoOrBiasMat S(EM ? q.Sc + t.k : q.Sc + 6 * t.k, EM ? q.Sw + t.k + 21 * K : q.Sw + t.k * SWS + 21, vo, EM ? K : 1);
 #pragma unroll
         for (int i = 0; i < 6; ++i) t.a[i] = S.p[i];
     } else {
 #pragma unroll
-        for (int i = 0; i < 6; ++i) t.a[i] = sp[i * nmeas];
+        for (int i = 0; i < 6; ++i) t.a[i] = sp[i * (EM ? nmeas : 1)];
     }
     // State: zero before the first chunk (the cold start); afterwards the slack x and y from where the previous chunk left them
     // in LDS; z of an equality row IS its bound after one iteration (the projection returns it), only the VO rows keep theirs.
@@ -1743,6 +1758,215 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
         else worker(std::integral_constant<int, 2>{});
     }
 #undef DEKF_R3_T
+    DEKF_PROF_MARK(q, 9);
+    DEKF_SYNC();
+    q.cold = false;
+    DEKF_PROF_MARK(q, 15);
+}
+#endif
+
+#if DEKF_DEVICE_BUILD
+// ---------------------------------------------------------------- rows in registers at a RUN-TIME horizon, two workgroups per CU (RR)
+// PogoX (1 leg, N = 100) keeps 103 KB of iterates in LDS in the generic placement: ONE workgroup per CU, whose solve wavefront works
+// through 101 dependent steps per iteration while three SIMDs idle.  Measured with emulation builds before this was written
+// (profiles/r04_pogox_factor_in_lds_emulation.txt): the factor stream from the slab costs 15 %, a second resident workgroup is worth
+// 1.75 x.  So the three-workgroup kernels' split — a row block's state in the registers of the lane that owns it for a whole chunk
+// of iterations, LDS only for what crosses lanes, wave-specialised loops with matched barriers — at a run-time horizon:
+//   LDS    R | D | E | x blocks | xd | w (= stash of the slack x between chunks) | xs | gb | scratch       77 KB at N = 100: two per CU
+//   slab   factor (S^-1, W), slack-block inverses (entry-major), scaled bounds, stash of y and of the VO rows' z between chunks
+//   regs   per owned block: t, slack x, y, scaled bound [, z]  (12 / 15 doubles); a lane owns up to three blocks
+// What a block needs beyond that in an iteration is re-read or rebuilt: its slack-block inverse from the slab (L2), E, D (and with
+// them rho E D and E D, the same products as at the load: same bits) and R_k from LDS.
+// Tiles of 64 blocks by kind (0 the first 64 Meas leg blocks, 1 Dyn position / velocity halves on lane pairs, 2 VO blocks, bias
+// blocks and the Meas blocks beyond 64 on the generic projection path); the three worker wavefronts take them as (kind, tile)
+// slots fixed at compile time, three each — valid for at most 1 + 4 + 4 tiles (SolveLayout::rr_fits):
+//   worker 1: (0,0) (1,1) (2,0)     worker 2: (1,2) (2,1) (2,3)     worker 3: (1,0) (1,3) (2,2)
+// The arithmetic is row_regs_iter's, called on a RowRegsT assembled from the kept state and the re-read constants.
+template <int KIND>
+struct RowStT {
+    bool valid, vel, vo, meas;
+    int k, r0, sv0;
+    double t[3], xs[3], y[3], lo[3];
+    double z[KIND == 2 ? 3 : 1];
+};
+template <int KIND, class Q>
+DEKF_FN void rr_load(Q& q, int j, int lane, double sigma, RowStT<KIND>& st) {
+    constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
+    const int K = q.K, K1 = K - 1, nmeas = K * L, e = 64 * j + lane;
+    RowRegsT<KIND> t;
+    t.valid = false; t.k = 0; t.r0 = 0; t.sv0 = 0; t.vel = false; t.meas = false; t.vo = false; t.xo = 0;
+    cdptr sp = q.Sv;
+    if constexpr (KIND == 0) {
+        if (e < nmeas && e < 64) {
+            const int k = e / L, leg = e - k * L;
+            t.valid = true; t.k = k; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg; t.xo = 3;
+            sp = q.Sv + 6 * e;
+        }
+    } else if constexpr (KIND == 1) {
+        const int k = e >> 1;
+        if (k < K1) { t.valid = true; t.k = k; t.vel = e & 1; t.r0 = q.ix.rd(k, t.vel ? 3 : 0); t.sv0 = k * SV + 9 + NM + (t.vel ? 3 : 0); }
+    } else {
+        if (e < 2 * K1) {
+            t.valid = true; t.vo = e < K1;
+            const int k = t.vo ? e : e - K1;
+            t.k = k; t.xo = t.vo ? 0 : 6; t.r0 = t.vo ? q.ix.rv(k, 0) : q.ix.rd(k, 6); t.sv0 = k * SV + (t.vo ? 18 + NM : 9 + NM + 6);
+        } else {  // the Meas blocks beyond the first 64, on the generic projection path (bit-identical for an equality block)
+            const int m = 64 + e - 2 * K1;
+            if (m < nmeas) {
+                const int k = m / L, leg = m - k * L;
+                t.valid = true; t.meas = true; t.k = k; t.xo = 3; t.r0 = q.ix.rm(k, 3 * leg); t.sv0 = k * SV + 9 + 3 * leg;
+                sp = q.Sv + 6 * m;
+            }
+        }
+    }
+    st.valid = t.valid; st.vel = t.vel; st.vo = t.vo; st.meas = t.meas; st.k = t.k; st.r0 = t.r0; st.sv0 = t.sv0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { st.t[a] = 0.0; st.xs[a] = 0.0; st.y[a] = 0.0; st.lo[a] = 0.0; }
+    st.z[0] = 0.0;
+    if (!t.valid) return;
+    row_regs_fill<KIND>(q, sigma, t, sp);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { st.t[a] = t.t[a]; st.xs[a] = t.xs[a]; st.y[a] = t.y[a]; st.lo[a] = t.lo[a]; }
+    if constexpr (KIND == 2) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) st.z[a] = t.z[a];
+    }
+}
+// the slack-block inverse of the block, from the slab (entry-major: solve_factor 3a), and what else row_regs_iter wants in registers
+template <int KIND, class Q>
+DEKF_FN void rr_assemble(const Q& q, const RowStT<KIND>& st, RowRegsT<KIND>& t) {
+    constexpr int L = Q::LEGS;
+    const int K = q.K, nmeas = K * L;
+    // (block indices opaque per iteration: hoisted out of the iteration loop, the address arithmetic of up to four blocks — a dozen
+    // pointers each — stays live across the x-column tiles and the barriers and pushes the kept state into scratch)
+    int k_ = st.k, r0_ = st.r0, sv0_ = st.sv0;
+    asm volatile("" : "+v"(k_), "+v"(r0_), "+v"(sv0_));
+    t.valid = st.valid; t.k = k_; t.r0 = r0_; t.sv0 = sv0_; t.vel = st.vel; t.vo = st.vo; t.meas = st.meas;
+    t.xo = (KIND == 0 || st.meas) ? 3 : (st.vo ? 0 : 6);
+    if constexpr (KIND == 1) {
+        const DynPairMat S(q.Sw + k_ * SWS, st.vel);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t.a[i] = S.a[i];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.b[i] = S.b[i];
+        cdptr R = q.R + 9 * k_;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) t.rk[i] = R[i];
+    } else if constexpr (KIND == 2) {
+        // (one code path for the three kinds of block on this tile: the six entries come from Sc, from the diagonal tail of Sw, or from Sv)
+        if (st.meas) {
+            cdptr sp = q.Sv + 2 * r0_;  // Meas block (k, leg): block index = its first row / 3, six entries each
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t.a[i] = sp[i];
+        } else {
+            const VoOrBiasMat S(q.Sc + 6 * k_, q.Sw + k_ * SWS + 21, st.vo);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) t.a[i] = S.p[i];
+        }
+        // upper bounds: a bias block is an equality (hi = lo); a VO block is an equality or the box -+1e30 E, whose upper end is
+        // exactly -lo — so the array of upper bounds need not be read back (solve_window_t writes hi = ub E next to lo = lb E)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t.b[a] = st.lo[a] < -1e20 ? -st.lo[a] : st.lo[a];
+    } else {
+        cdptr sp = q.Sv + 2 * r0_;  // Meas block (k, leg): block index k L + leg = its first row / 3, six entries each
+#pragma unroll
+        for (int i = 0; i < 6; ++i) t.a[i] = sp[i];
+    }
+    const double rho_eq = uni(RHO_EQ_OVER_RHO_INEQ * q.rho);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double d = q.D[sv0_ + a];
+        t.e[a] = q.E[r0_ + a];
+        t.lo[a] = st.lo[a];
+        // (row_regs_fill's expressions: rho E D = (rv E) D, E D = D E)
+        double rv = rho_eq;
+        if constexpr (KIND == 2) rv = q.rho_of(st.lo[a], t.b[a]);
+        t.cf[a] = rv * t.e[a] * d;
+        t.c2[a] = d * t.e[a];
+        t.t[a] = st.t[a]; t.xs[a] = st.xs[a]; t.y[a] = st.y[a];
+    }
+    if constexpr (KIND == 2) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) t.z[a] = st.z[a];
+    }
+}
+template <int KIND, class Q>
+DEKF_FN void rr_iter(Q& q, RowStT<KIND>& st, double alpha, double sigma, bool first_cold) {
+    if (!st.valid) return;
+    RowRegsT<KIND> t;
+    rr_assemble<KIND>(q, st, t);
+    row_regs_iter<KIND>(q, t, alpha, sigma, first_cold);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) { st.t[a] = t.t[a]; st.xs[a] = t.xs[a]; st.y[a] = t.y[a]; }
+    if constexpr (KIND == 2) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) st.z[a] = t.z[a];
+    }
+}
+template <int KIND, class Q>
+DEKF_FN void rr_store(Q& q, const RowStT<KIND>& st) {
+    if (!st.valid) return;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const int r = st.r0 + a;
+        q.sx[r] = st.xs[a];
+        q.sy[r] = st.y[a];
+        if constexpr (KIND == 2) { if (st.vo) q.sz[r - q.ix.rvb] = st.z[a]; }
+    }
+}
+template <class Q>
+DEKF_FN void admm_chunk_rr(Q& q, int iters, double alpha, double sigma) {
+    const int w = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), lane = DEKF_LANE() & 63;
+    const int K = q.K, ntx = (3 * K + 63) >> 6;
+    if (w == 0) {
+        DEKF_SYNC();  // B0: w, gb of the (re)start complete
+        DEKF_PROF_MARK(q, 14);
+        for (int it = 0; it < iters; ++it) {
+            DEKF_SYNC();  // B1: xs complete
+            __builtin_amdgcn_s_setprio(3);
+            sweeps_one_wave_rt(q, alpha);
+            __builtin_amdgcn_s_setprio(0);
+            DEKF_SYNC();  // B2: xd complete
+            DEKF_SYNC();  // B3: w, gb complete
+        }
+    } else {
+        const bool cold = q.cold, pol = q.polishing();
+        // this worker's x-column tiles: flat tile f = kind * ntx + j, every third one
+        auto xcols = [&] {
+            for (int f = w - 1; f < 3 * ntx; f += 3) {
+                const int kind = f / ntx, j = f - kind * ntx;
+                xcols_tile_r3(q, kind, 64 * j + lane, sigma);
+            }
+        };
+#define DEKF_RR_LOOP(ITERS_BODY, STORE_BODY)                      \
+        DEKF_SYNC(); /* B0 */                                      \
+        for (int it = 0; it < iters; ++it) {                       \
+            xcols();                                               \
+            DEKF_SYNC(); /* B1 */                                  \
+            DEKF_SYNC(); /* B2 */                                  \
+            const bool fc = cold && it == 0 && !pol;               \
+            ITERS_BODY                                             \
+            DEKF_SYNC(); /* B3 */                                  \
+        }                                                          \
+        STORE_BODY
+        if (w == 1) {
+            RowStT<0> s0; RowStT<1> s1; RowStT<2> s2;
+            rr_load<0>(q, 0, lane, sigma, s0); rr_load<1>(q, 1, lane, sigma, s1); rr_load<2>(q, 0, lane, sigma, s2);
+            DEKF_RR_LOOP(rr_iter<1>(q, s1, alpha, sigma, fc); rr_iter<2>(q, s2, alpha, sigma, fc); rr_iter<0>(q, s0, alpha, sigma, fc);,
+                         rr_store<0>(q, s0); rr_store<1>(q, s1); rr_store<2>(q, s2);)
+        } else if (w == 2) {
+            RowStT<1> s0; RowStT<2> s1, s2;
+            rr_load<1>(q, 2, lane, sigma, s0); rr_load<2>(q, 1, lane, sigma, s1); rr_load<2>(q, 3, lane, sigma, s2);
+            DEKF_RR_LOOP(rr_iter<1>(q, s0, alpha, sigma, fc); rr_iter<2>(q, s1, alpha, sigma, fc); rr_iter<2>(q, s2, alpha, sigma, fc);,
+                         rr_store<1>(q, s0); rr_store<2>(q, s1); rr_store<2>(q, s2);)
+        } else {
+            RowStT<1> s0, s1; RowStT<2> s2;
+            rr_load<1>(q, 0, lane, sigma, s0); rr_load<1>(q, 3, lane, sigma, s1); rr_load<2>(q, 2, lane, sigma, s2);
+            DEKF_RR_LOOP(rr_iter<1>(q, s0, alpha, sigma, fc); rr_iter<1>(q, s1, alpha, sigma, fc); rr_iter<2>(q, s2, alpha, sigma, fc);,
+                         rr_store<1>(q, s0); rr_store<1>(q, s1); rr_store<2>(q, s2);)
+        }
+#undef DEKF_RR_LOOP
+    }
     DEKF_PROF_MARK(q, 9);
     DEKF_SYNC();
     q.cold = false;

@@ -122,6 +122,20 @@ struct SolveLayout {
         const size_t granule = 1536, need = (r3_lds_bytes() + static_lds + granule - 1) / granule * granule;
         return ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && DEKF_R3_WAVES * need <= 160 * 1024;
     }
+    // Rows in registers at a run-time horizon with the factor in the slab (RR, mhe_admm_core.h: admm_chunk_rr):
+    //   R | D | E | xb | xd | at (= the stash of the slack x between chunks) | xs | gb | tmp
+    // The stash of y and of the VO rows' z between chunks, the scaled bounds, the slack-block inverses and the factor live in the slab;
+    // the Ruiz passes' temporaries Dn | En overlay xb .. gb (dead during the scaling), the P column norms go to the slab.
+    DEKF_HD int rr_doubles() const { return 9 * K + n_pad + m_pad + ns * K + (2 * ns * K + m_pad + 3 * K) + solve_tmp_len(ns); }
+    DEKF_HD size_t rr_lds_bytes() const { return (size_t)rr_doubles() * 8; }
+    DEKF_HD bool rr_fits(int L, size_t static_lds = 512) const {
+        const size_t granule = 1536, need = (rr_lds_bytes() + static_lds + granule - 1) / granule * granule;
+        // row tiles (admm_chunk_rr): the first 64 Meas blocks | up to four tiles of Dyn lane pairs | up to four of VO + bias blocks
+        // + the remaining Meas blocks
+        const int over = K * L > 64 ? K * L - 64 : 0;
+        return ns == 9 && K >= 4 && (K & 1) == 0 && 2 * (K - 1) <= 256 && 2 * (K - 1) + over <= 256 &&
+               n_pad + m_pad <= 3 * ns * K + m_pad + 3 * K && 2 * need <= 160 * 1024;
+    }
     // Factor in the HBM slab (one workgroup per CU anyway): whatever LDS the iterates leave free takes the per-row constants
     // that every phase reads (D, E, scaled bounds, R) — they are what made a PogoX iteration fetch 53 KB more from beyond L2.
     DEKF_HD int gg_consts() const { return n_pad + 2 * m_pad + 3 * K + 9 * K; }
@@ -941,7 +955,10 @@ DEKF_FN bool solve_factor(Q& q) {
     // Three-workgroup kernels keep the slack-block inverses in the HBM slab: there they are stored ENTRY-major ([entry][block]) so
     // that the lanes of a wavefront, which own consecutive blocks, write and read consecutive doubles (block-major, a wave's store
     // of one entry touched up to 64 different 32-byte sectors: 288 such stores per solve were most of the kernel's write traffic)
-    constexpr bool ST = Q::R3;
+    // (RR — rows in registers with the factor in the slab — keeps them block-major: a lane re-reads its block's inverse in every
+    // iteration, and a contiguous block is one base address with immediate offsets and wide loads instead of 6 to 15 separate
+    // 64-bit addresses)
+    constexpr bool ST = Q::R3 && Q::FACTOR_LDS;
     const int stv = ST ? K * L : 1, stw = ST ? K : 1;
     auto block3 = [&](cdptr q6, int r0, int sv0, dptr Si_out, dptr W_out, int sst) {
         double gv[3], rr[3], S6[6], Si[6];
@@ -1579,8 +1596,35 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
         auto take = [&](int len) { dptr r = DEKF_SPAN(p, len); p += len; return r; };
         auto gs = [&](int off, int len) { return DEKF_SPAN(gw + off, len); };
         const int b2K = NH * NS2;
-        if constexpr (R3) {
-            static_assert(!R3 || (FACTOR_LDS && PA_LDS && NFIX != 0 && FT == 0), "R3: fixed horizon, 9 states, factor in LDS");
+        if constexpr (R3 && !FACTOR_LDS) {
+            // RR: rows in registers, run-time horizon, factor in the slab, two workgroups per CU (SolveLayout::rr_doubles)
+            static_assert(!PA_LDS && NFIX == 0 && FT == 0, "RR: run-time horizon, 9 states, factor and factor-time product in the slab");
+            q.R = take(9 * NH);
+            q.D = take(lay.n_pad);
+            q.E = take(lay.m_pad);
+            q.xb = take(NS * NH);
+            double* const rb = p;
+            q.PA = gs(g.PA, b2K);
+            q.xd = DEKF_SPAN(rb, NS * NH);
+            q.at = DEKF_SPAN(rb + NS * NH, lay.m_pad);
+            q.xs = DEKF_SPAN(rb + NS * NH + lay.m_pad, NS * NH);
+            q.gb = DEKF_SPAN(rb + 2 * NS * NH + lay.m_pad, 3 * NH);
+            q.sx = q.at;
+            p += 2 * NS * NH + lay.m_pad + 3 * NH;
+            q.tmp = take(TM::LEN);
+            q.Sinv = gs(g.Sinv, b2K);
+            q.Wk = gs(g.Wk, b2K);
+            q.Sf = nullptr; q.Wf = nullptr;
+            q.x = gs(g.x, lay.n_pad);  // (the P column norms of the Ruiz passes)
+            q.sy = gs(g.y, lay.m_pad); q.sz = gs(g.z, lay.m_pad);
+            q.y = nullptr; q.z = nullptr; q.zt = nullptr; q.cf = nullptr; q.xt = nullptr;
+            q.lo = gs(g.lo, lay.m_pad); q.hi = gs(g.hi, lay.m_pad);
+            q.cold = true;
+            q.Sv = gs(g.Sv, NH * 6 * L); q.Sw = gs(g.Sw, NH * SWS); q.Sc = gs(g.Sc, NH * 6);
+            q.Wm = gs(g.Wm, NH * 6 * L); q.Wd = gs(g.Wd, NH * 24); q.Wc = gs(g.Wc, NH * 6);
+        }
+        if constexpr (R3 && FACTOR_LDS) {
+            static_assert(!R3 || !FACTOR_LDS || (PA_LDS && NFIX != 0 && FT == 0), "R3: fixed horizon, 9 states, factor in LDS");
             q.R = take(9 * NH);
             q.D = take(lay.n_pad);
             q.E = take(lay.m_pad);
@@ -1699,7 +1743,17 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
         for (int i = 0; i < DEKF_PROF_SLOTS; ++i) q.prof[i] = 0.0;
 #endif
     wfor(K * 9, [&](int e) { q.R[e] = ld_stream(q.rec(e / 9), Rec::R + e % 9); });
-    if constexpr (R3) {
+    if constexpr (R3 && !FACTOR_LDS) {
+        // RR: D and E in LDS for the whole solve; the passes' temporaries Dn | En overlay xb .. gb (dead until the cold start), the P
+        // column norms pc live in the slab (q.x)
+        double* const ob = raw_of(q.xb);
+        q.xt = DEKF_SPAN(ob, lay.n_pad);                 // Dn
+        q.zt = DEKF_SPAN(ob + lay.n_pad, lay.m_pad);     // En
+        if (c.scaling > 0) solve_scale(q);
+        else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
+        q.zt = nullptr; q.xt = nullptr;
+        wfor(K * NS, [&](int e) { q.xb[e] = 0.0; });
+    } else if constexpr (R3) {
         // D and E stay in LDS for the whole solve; the Ruiz passes' temporaries pc, En, Dn sit behind the staged P blocks inside
         // S^-1 | W, which are not live before the first factorisation.
         constexpr int PSL = NFIX * (6 * L + 27) + NS * (NS + 1) / 2;
@@ -1756,7 +1810,8 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
             int nxt = c.max_iter;
             if (c.check_termination > 0) { const int e = (iter / c.check_termination + 1) * c.check_termination; nxt = e < nxt ? e : nxt; }
             if (c.adaptive_rho && c.adaptive_rho_interval > 0) { const int e = (iter / c.adaptive_rho_interval + 1) * c.adaptive_rho_interval; nxt = e < nxt ? e : nxt; }
-            admm_chunk_r3<NFIX>(q, nxt - iter, alpha, sigma);
+            if constexpr (FACTOR_LDS) admm_chunk_r3<NFIX>(q, nxt - iter, alpha, sigma);
+            else admm_chunk_rr(q, nxt - iter, alpha, sigma);
             iter = nxt;
             DEKF_PROF_MARK(q, 9);
         } else
@@ -1795,7 +1850,8 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
                     q.rho = uni_pin(rho_new);
                     info.rho_updates++;
                     DEKF_SYNC();
-                    if constexpr (R3) {  // the factorisation's temporaries take the LDS the row state rests in: over to the slab and back
+                    if constexpr (R3 && FACTOR_LDS) {  // the factorisation's temporaries take the LDS the row state rests in: over to the slab and back
+                        // (RR: the factor-time product lives in the slab, nothing of the factorisation touches the stash)
                         const int mp = lay.m_pad, nz = 3 * NH;
                         wfor(2 * mp + nz, [&](int e) {
                             if (e < mp) q.x[e] = q.sx[e];
@@ -1804,7 +1860,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
                         });
                     }
                     ok = solve_factor(q);
-                    if constexpr (R3) {
+                    if constexpr (R3 && FACTOR_LDS) {
                         const int mp = lay.m_pad, nz = 3 * NH;
                         wfor(2 * mp + nz, [&](int e) {
                             if (e < mp) q.sx[e] = q.x[e];
@@ -1864,7 +1920,8 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
         if (okp) {
 #if DEKF_DEVICE_BUILD
             if constexpr (R3) {
-                admm_chunk_r3<NFIX>(q, npol, 1.0, q.sigma());
+                if constexpr (FACTOR_LDS) admm_chunk_r3<NFIX>(q, npol, 1.0, q.sigma());
+                else admm_chunk_rr(q, npol, 1.0, q.sigma());
             } else
 #endif
             {

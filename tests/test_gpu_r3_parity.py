@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as O
-from decentralized_ekf_mhe_amd import cassie_params, go1_params
+from decentralized_ekf_mhe_amd import cassie_params, go1_params, pogox_params
 from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_device
 from decentralized_ekf_mhe_amd.streams import make_streams
 from test_gpu_parity import ATOL, RTOL, _params, block_err
@@ -26,16 +26,16 @@ def _tile(s, reps):
             for k, v in s.items()}
 
 
-def run_tiled(p, s, K, reps=REPS, want_polish=False):
+def run_tiled(p, s, K, reps=REPS, want_polish=False, family="_r3_", min_batch=512):
     """the distinct logs of `s` tiled `reps` times over one batch; every tick read back.  Returns per-tick arrays of the FIRST
     tile after checking that every other tile carries the same bits."""
     D = s["imu_t"].shape[1]
     B = D * reps
-    assert B > 512
+    assert B > min_batch
     est = BatchedEstimator(p, B)
     name_full, name_fill = est.solve_kernel_name(True), est.solve_kernel_name(False)
-    assert "_r3_" in name_full, name_full
-    assert "_r3_" not in name_fill, name_fill
+    assert family in name_full, name_full
+    assert family not in name_fill, name_fill
     sd = streams_to_device(_tile(s, reps))
     xs, qs, vbs, its, sts, pols, pris = [], [], [], [], [], [], []
     for k in range(K):
@@ -139,3 +139,34 @@ def test_r3_polish_matches_oracle(maker, kernel):
     scale = max(1.0, np.abs(x_ref).max())
     assert np.abs(g["x"][full][both] - x_ref[full][both]).max() <= 1e-8 * scale
     assert np.all(g["pri_res"][full][both] <= 1e-9)
+
+
+def test_rr_pogox_every_tick_matches_oracle():
+    """PogoX (1 leg, N = 100): full windows run k_mhe_solve_rr_1 (row state in registers at a run-time horizon, two workgroups per
+    CU) once the batch exceeds the 256 slots of the generic kernel, which still runs the 99 window-fill ticks.  8 distinct logs
+    tiled to 320 instances, 135 ticks, every tick against the oracle."""
+    p = _params(pogox_params)
+    D, K = 8, 135
+    s = make_streams(p, D, K)
+    x_ref, vb_ref, q_ref, _, it_ref = O.run_streams(p, s, nthreads=16, want_iters=True)
+    g = run_tiled(p, s, K, reps=40, family="_rr_", min_batch=256)
+    assert g["kernel"] == "k_mhe_solve_rr_1"
+    check_every_tick(g, x_ref, vb_ref, q_ref, it_ref, p.N)
+
+
+def test_rr_pogox_polish_matches_oracle():
+    """osqp.polish on k_mhe_solve_rr_1_pol: the polishing iterations run through admm_chunk_rr (cold start with z on the bounds,
+    sigma = delta, rho = 1 / delta, alpha = 1).  Rules of tests/test_polish.py."""
+    from test_polish import _oracle_run, _status_agrees, _tol_units
+    p = _params(pogox_params, polish=1)
+    D, K = 4, 118
+    s = make_streams(p, D, K)
+    x_ref, st_ref, res_ref = _oracle_run(p, s, K)
+    g = run_tiled(p, s, K, reps=72, family="_rr_", min_batch=256)
+    assert g["kernel"] == "k_mhe_solve_rr_1_pol"
+    assert (g["status"][1:] == 1).all()
+    full = slice(p.N, None)
+    pol, ref = g["polish_status"][full], st_ref[full]
+    assert _status_agrees(pol, ref)
+    assert (pol == ref).mean() >= 0.85, (pol == ref).mean()
+    assert _tol_units(g["x"][1:], x_ref[1:]) <= 1.0

@@ -159,7 +159,7 @@ def main():
     ok &= case("go1 N=20 (BASELINE configs[1] shape), 256 x 400 ticks tiled x 4 (B = 1024)", go1_params, 256, 400, th, reps=4)
     ok &= case("go1 N=20, KF mode", go1_params, 64, 200, th, est_type=1)
     ok &= case("cassie N=20, 128 x 200 ticks tiled x 7 (B = 896)", cassie_params, 128, 200, th, reps=7)
-    ok &= case("pogox N=100", pogox_params, 32, 260, th)
+    ok &= case("pogox N=100, 32 x 260 ticks tiled x 9 (B = 288: full windows on k_mhe_solve_rr_1)", pogox_params, 32, 260, th, reps=9)
     ok &= case("go1 N=5", go1_params, 64, 120, th, N=5)
     ok &= case("go1 N=20, foot positions as states (leg_odom_type 1)", go1_params, 32, 120, th, leg_odom_type=1)
     sys.exit(0 if ok else 1)
