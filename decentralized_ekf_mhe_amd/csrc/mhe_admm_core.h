@@ -482,7 +482,9 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha, int lane_in = -1) {
 template <class Q>
 DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
-    constexpr int RING = Q::FACTOR_LDS ? 4 : DEKF_GG_RING;
+    // (RR — rows in registers, two workgroups per CU — has the registers for eight sets and the latency to hide: 171 k -> 177 k
+    // steps/s on PogoX against six; ten spill)
+    constexpr int RING = Q::FACTOR_LDS ? 4 : (Q::R3 ? 8 : DEKF_GG_RING);
     const int K = q.K, M = mid_block(K), NOUT = K - 1 - M;  // K even: K - 2 - M == M, both forward legs M steps
     // (the lane id stays opaque here: taken from q.lane0, i.e. loop-invariant, the run-time ring of operand sets and the hoisted
     // addresses together spill 63 VGPRs of the 256 and PogoX drops from 102 k to 80 k steps/s)
@@ -1782,6 +1784,8 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
 // slots fixed at compile time, three each — valid for at most 1 + 4 + 4 tiles (SolveLayout::rr_fits):
 //   worker 1: (0,0) (1,1) (2,0)     worker 2: (1,2) (2,1) (2,3)     worker 3: (1,0) (1,3) (2,2)
 // The arithmetic is row_regs_iter's, called on a RowRegsT assembled from the kept state and the re-read constants.
+// (Requesting the first block's inverse while the solve wavefront still works — before barrier B2 — was measured: 175.8 k against
+// 177.3 k steps/s; not kept.)
 template <int KIND>
 struct RowStT {
     bool valid, vel, vo, meas;
@@ -2045,8 +2049,12 @@ DEKF_FN void phase_sweeps_rows(Q& q, double alpha, double sigma) {
 // the branch-free gathers.  The P blocks come from the window records in HBM (requested first, they
 // arrive while the LDS part is being computed).  Replaces two wfor sweeps over rows / variables with
 // per-item kind decoding (50 k cycles per check on Go1, 3 checks per solve).
+// rv != nullptr: additionally the scaled KKT residual VECTORS of the current point, for the refinement steps of OSQP's polishing
+// (polish.c: rhs - K sol):  rxb[k NS + j] = -(q + P x + A'y) on the x blocks, rxs[r] the same on the slack variable of row r,
+// ry[r] = z_r - (A x)_r, i.e. b - A x on a row held at its bound
+struct ResidVec { dptr rxb, rxs, ry; };
 template <class Q>
-DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
+DEKF_FN void residual_norms(Q& q, dptr ra, dptr va, const ResidVec* rv = nullptr) {
     constexpr int L = Q::LEGS, NM = 3 * L, FT = Q::FOOT, NS = Q::NS, SV = 2 * NS + 3 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     const double dt = q.c.dt, hdt2 = q.c.hdt2, cc = q.cc;
@@ -2087,6 +2095,7 @@ DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
             acc[5] = dmax(acc[5], fabs(Ax));
             const double Px = cc * d * ps[j], Aty = -e * d * YR(r);
             const double dr = Px + Aty, di = rcp_fast(d);
+            if (rv) { rv->ry[r] = -pr; rv->rxs[r] = -dr; }
             acc[6] = dmax(acc[6], fabs(dr) * di);
             acc[8] = dmax(acc[8], fabs(Aty) * di);
             acc[9] = dmax(acc[9], fabs(Px) * di);
@@ -2198,6 +2207,7 @@ DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
                 Px *= cc * d;
             }
             const double Aty = d * g, dr = qv + Px + Aty, di = rcp_fast(d);
+            if (rv) rv->rxb[NS * k + j] = -dr;
             acc[6] = dmax(acc[6], fabs(dr) * di);
             acc[7] = dmax(acc[7], fabs(qv) * di);
             acc[8] = dmax(acc[8], fabs(Aty) * di);
@@ -2234,6 +2244,7 @@ DEKF_FN void residual_norms(Q& q, dptr ra, dptr va) {
                 Px *= cc * d;
             }
             const double Aty = d * g, dr = qv + Px + Aty, di = rcp_fast(d);
+            if (rv) rv->rxb[NS * k + j] = -dr;
             acc[6] = dmax(acc[6], fabs(dr) * di);
             acc[7] = dmax(acc[7], fabs(qv) * di);
             acc[8] = dmax(acc[8], fabs(Aty) * di);

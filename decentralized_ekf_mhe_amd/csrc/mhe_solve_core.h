@@ -218,6 +218,7 @@ struct SolveCtx {
     // the regularisation of the x block in the linear system: settings sigma; delta while polishing
     DEKF_FN double sigma() const { if constexpr (POLISH) return zlo ? sigma_pol : c.sigma; else return c.sigma; }
     DEKF_FN bool polishing() const { if constexpr (POLISH) return zlo; else return false; }
+    dptr pol;  // POLISH: slab scratch of the refinement steps (Gws::pol): saved point | saved bounds | KKT residual vectors
     dptr Pst;  // unscaled P blocks staged by solve_scale (aliases Sinv | Wk until the first factorisation)
     bool staged;  // Pst valid
     dptr prof;         // diagnostic build only
@@ -1567,6 +1568,127 @@ DEKF_FN bool solve_factor(Q& q) {
 
 #include "mhe_admm_core.h"
 
+// ---------------------------------------------------------------- osqp.polish: refinement against explicit residuals
+// OSQP refines the polished point as polish.c does: r = rhs - K s with the UNREGULARISED matrix, K_reg ds = r, s += ds.  The
+// correction is solved by the machinery that is there: one ADMM step with sigma = delta, 1 / rho = delta on the active rows and
+// alpha = 1 solves  [P + delta I, A'; A, -delta I] [xt; nu] = [delta x - q; z - delta y]  — so with the state loaded as
+// x := r_x / delta, q := 0, y := 0 and the rows held at z := r_y instead of at their bounds it returns xt = dx and y+ = dy.
+// (Rounds 3's form iterated  K_reg s+ = rhs + delta [x; -y]  on the full point: the same recursion in exact arithmetic, but its
+// error floor is relative to |s|, not to |ds| — the dual residual stopped at 1e-8 of the problem's scale where OSQP reaches 1e-13,
+// and the device rejected polished points OSQP accepts.)
+// Layout of q.pol: pv_xb [K NS] | pv_xs [m] | pv_y [m] | pv_lo [m] | pr_xb [K NS] | pr_xs [m] | pr_y [m]   (m = m_pad)
+template <class Q>
+struct PolishScratch {
+    dptr pv_xb, pv_xs, pv_y, pv_lo, pr_xb, pr_xs, pr_y;
+    DEKF_FN PolishScratch(const Q& q, int m_pad, int NH) {
+        constexpr int NS = Q::NS;
+        double* p = raw_of(q.pol);
+        pv_xb = DEKF_SPAN(p, NS * NH); p += NS * NH;
+        pv_xs = DEKF_SPAN(p, m_pad); p += m_pad;
+        pv_y = DEKF_SPAN(p, m_pad); p += m_pad;
+        pv_lo = DEKF_SPAN(p, m_pad); p += m_pad;
+        pr_xb = DEKF_SPAN(p, NS * NH); p += NS * NH;
+        pr_xs = DEKF_SPAN(p, m_pad); p += m_pad;
+        pr_y = DEKF_SPAN(p, m_pad);
+    }
+};
+// a VO row without bounds: not in OSQP's active set; here a free row (rho = RHO_MIN) whose multiplier stays exactly 0
+// (a VO row is either an equality or the box -+1e30 E: its ORIGINAL lower bound tells which)
+template <class Q>
+DEKF_FN bool polish_free_row(const Q& q, int r, double lo_orig) {
+    return r >= q.ix.rvb && lo_orig < -q.c.inf_thr;
+}
+// one step of the iteration kernels with sigma = delta, alpha = 1 from whatever the state arrays hold (a function, not a lambda: a
+// lambda that is called twice is not inlined, and then the whole solve context lives in scratch memory — 1.7 KB per lane)
+template <int NFIX, class Q>
+DEKF_FN void polish_step(Q& q) {
+#if DEKF_DEVICE_BUILD
+    if constexpr (Q::R3) {
+        if constexpr (Q::FACTOR_LDS) admm_chunk_r3<NFIX>(q, 1, 1.0, q.sigma());
+        else admm_chunk_rr(q, 1, 1.0, q.sigma());
+    } else
+#endif
+    {
+        phase_xcols(q, q.sigma());
+        phase_sweeps_rows(q, 1.0, q.sigma());
+    }
+}
+// save the polished point and the bounds; load the correction's right-hand side as the state (see above)
+template <class Q>
+DEKF_FN void polish_swap_in(Q& q, const PolishScratch<Q>& ps, double delta) {
+    constexpr int NS = Q::NS;
+    const int K = q.K, m = q.m;
+    const double dinv = 1.0 / delta;
+    wfor_nosync(m + K * NS, [&](int e) {
+        if (e >= m) {
+            const int i = e - m, k = i / NS, j = i - NS * k;
+            if constexpr (Q::R3) { ps.pv_xb[i] = q.xb[i]; q.xb[i] = ps.pr_xb[i] * dinv; }
+            else { const int xi = q.ix.x(k, j); ps.pv_xb[i] = q.x[xi]; q.x[xi] = ps.pr_xb[i] * dinv; }
+            return;
+        }
+        const int r = e;
+        const double lo_r = q.lo[r];
+        const bool vo = r >= q.ix.rvb, fr = polish_free_row(q, r, lo_r);
+        ps.pv_lo[r] = lo_r;
+        if constexpr (Q::R3) {
+            ps.pv_xs[r] = q.sx[r];
+            ps.pv_y[r] = fr ? q.sz[r - q.ix.rvb] : q.sy[r];   // (a free row: y = 0 throughout, its z = A x is what has to be carried)
+            q.sx[r] = ps.pr_xs[r] * dinv;
+            q.sy[r] = 0.0;
+            if (vo) q.sz[r - q.ix.rvb] = fr ? 0.0 : ps.pr_y[r];
+        } else {
+            int k, kind, o;
+            q.dec_row(r, k, kind, o);
+            const int sv = q.row_slack(k, kind, o);
+            ps.pv_xs[r] = q.x[sv];
+            ps.pv_y[r] = fr ? q.z[r] : q.y[r];
+            q.x[sv] = ps.pr_xs[r] * dinv;
+            q.y[r] = 0.0;
+            q.z[r] = fr ? 0.0 : ps.pr_y[r];
+        }
+        if (!fr) {
+            q.lo[r] = ps.pr_y[r];
+            if (vo) q.hi[r - q.ix.rvb] = ps.pr_y[r];
+        }
+    });
+    DEKF_SYNC();
+}
+// s := saved + correction; bounds (and z of the rows held at them) back
+template <class Q>
+DEKF_FN void polish_accumulate(Q& q, const PolishScratch<Q>& ps) {
+    constexpr int NS = Q::NS;
+    const int K = q.K, m = q.m;
+    wfor_nosync(m + K * NS, [&](int e) {
+        if (e >= m) {
+            const int i = e - m, k = i / NS, j = i - NS * k;
+            if constexpr (Q::R3) q.xb[i] = ps.pv_xb[i] + q.xb[i];
+            else { const int xi = q.ix.x(k, j); q.x[xi] = ps.pv_xb[i] + q.x[xi]; }
+            return;
+        }
+        const int r = e;
+        const double lo_r = ps.pv_lo[r];
+        const bool vo = r >= q.ix.rvb;
+        const bool fr = polish_free_row(q, r, lo_r);  // (free rows were left alone by polish_swap_in)
+        if constexpr (Q::R3) {
+            q.sx[r] = ps.pv_xs[r] + q.sx[r];
+            if (fr) { q.sz[r - q.ix.rvb] = ps.pv_y[r] + q.sz[r - q.ix.rvb]; q.sy[r] = 0.0; }
+            else { q.sy[r] = ps.pv_y[r] + q.sy[r]; if (vo) q.sz[r - q.ix.rvb] = lo_r; }
+        } else {
+            int k, kind, o;
+            q.dec_row(r, k, kind, o);
+            const int sv = q.row_slack(k, kind, o);
+            q.x[sv] = ps.pv_xs[r] + q.x[sv];
+            if (fr) { q.z[r] = ps.pv_y[r] + q.z[r]; q.y[r] = 0.0; }
+            else { q.y[r] = ps.pv_y[r] + q.y[r]; q.z[r] = lo_r; }
+        }
+        if (!fr) {
+            q.lo[r] = lo_r;
+            if (vo) q.hi[r - q.ix.rvb] = lo_r;
+        }
+    });
+    DEKF_SYNC();
+}
+
 struct SolveInfo {
     int iters, status, rho_updates;
     double pri_res, dua_res, rho;
@@ -1714,6 +1836,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
             if constexpr (FT) q.Wf = DEKF_SPAN(wb + NH * 6 * L + NH * 30, NH * 6 * L);
         }
     }
+    q.pol = DEKF_SPAN(raw_of(gws) + g.pol, 2 * NH * NS + 5 * lay.m_pad);
     q.n = (K - 1) * IdxT<L, FT>::SV + NS + IdxT<L, FT>::nm;
     q.m = (K - 1) * IdxT<L, FT>::SC + IdxT<L, FT>::nm;
     {
@@ -1916,21 +2039,22 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
         if constexpr (!R3) {
             if (okp) phase_rows<true>(q, 1.0, q.sigma());
         }
-        const int npol = 1 + (c.polish_refine_iter > 0 ? c.polish_refine_iter : 0);
+        const int nref = c.polish_refine_iter > 0 ? c.polish_refine_iter : 0;
         if (okp) {
-#if DEKF_DEVICE_BUILD
-            if constexpr (R3) {
-                if constexpr (FACTOR_LDS) admm_chunk_r3<NFIX>(q, npol, 1.0, q.sigma());
-                else admm_chunk_rr(q, npol, 1.0, q.sigma());
-            } else
-#endif
-            {
-                for (int it = 0; it < npol; ++it) {
-                    phase_xcols(q, q.sigma());
-                    phase_sweeps_rows(q, 1.0, q.sigma());
-                }
-            }
+            polish_step<NFIX>(q);  // K_reg s = rhs from the cold start
             double ra[6], va[8];
+            const PolishScratch<decltype(q)> ps(q, lay.m_pad, NH);
+            const ResidVec rvec{ps.pr_xb, ps.pr_xs, ps.pr_y};
+            for (int it = 0; it < nref; ++it) {
+                residual_norms(q, ra, va, &rvec);  // r = rhs - K s (the norms are not used here)
+                DEKF_SYNC();
+                polish_swap_in(q, ps, c.delta);
+                wfor(NS, [&](int j) { q.tmp[TM::QSL + j] = 0.0; });
+                if constexpr (!R3) phase_rows<true>(q, 1.0, q.sigma());
+                polish_step<NFIX>(q);  // K_reg ds = r
+                polish_accumulate(q, ps);
+                wfor(NS, [&](int j) { q.tmp[TM::QSL + j] = q.cc * q.D[ix.x(0, j)] * q.np[j]; });
+            }
             residual_norms(q, ra, va);
             const double prp = ra[0], dup = cinv * va[0];
             const bool good = (prp < pri0 && dup < dua0) || (prp < pri0 && dua0 < 1e-10) || (dup < dua0 && pri0 < 1e-10);

@@ -43,11 +43,11 @@ def _oracle_run(p, s, K):
 
 
 def _status_agrees(dev, ref):
-    """The device refines through the condensed system (x-block system of the ADMM step with sigma = delta, rho = 1 / delta), OSQP
-    through the full quasi-definite KKT matrix with explicit residuals: both land on the same x (1e-12), but the condensed form's
-    dual residual stops at ~1e-8 of the problem's scale where the full form reaches 1e-16.  When the ADMM iterate is already below
-    that floor the device keeps the iterate (-1) where OSQP's acceptance test takes the polished point (+1): the one allowed
-    disagreement.  The x of the two then differ by the error of an eps = 1e-6 iterate, inside the tolerance."""
+    """Since round 4 the device refines the polished point as OSQP's polish.c does — against explicit residuals of the unregularised
+    KKT matrix, the correction solved by one step of the iteration kernels (mhe_solve_core.h: polish_swap_in / polish_accumulate) —
+    so its residuals reach the oracle's level and the acceptance test decides alike.  (Round 3 iterated the regularised system on
+    the full point: same x, but a dual-residual floor of ~1e-8 of the problem's scale, and the device kept the iterate at ticks where
+    OSQP takes the polished point.)  The one disagreement still tolerated, in at most 1 % of instance-ticks: exactly that one."""
     return bool(np.all((dev == ref) | ((dev == -1) & (ref == 1))))
 
 
@@ -134,7 +134,7 @@ def test_hostsim_polish_matches_oracle(maker, N, K, refine, ft):
         both = (o["polish_status"] == 1) & (st_ref[k] == 1)
         if both.any():  # the same polished point
             assert np.abs(o["x"][both] - x_ref[k][both]).max() <= 1e-8 * max(1.0, np.abs(x_ref[k]).max()), k
-    assert same >= 0.85 * B * (K - 1), same
+    assert same >= 0.99 * B * (K - 1), same
     # (without refinement steps the delta-regularised solve is never better than the iterate: all rejected, on both sides)
     assert (st_ref[1:] == 1).any() == (refine > 0)
 
@@ -177,7 +177,7 @@ def test_gpu_polish_matches_oracle(maker, N, K, ft):
             assert np.all(info["pri_res"][both] <= 1e-9), (k, info["pri_res"][both])
     assert worst <= 1.0, worst
     assert polished <= 1e-8, polished
-    assert same >= 0.85 * B * (K - 1), same
+    assert same >= 0.99 * B * (K - 1), same
     name = est.lib.dekf_solve_kernel_name(est.h, 1).decode()
     assert name.endswith("_pol") and "_r3_" not in name, name
     assert (st_ref[1:] == 1).any()

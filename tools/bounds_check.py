@@ -49,6 +49,7 @@ CASES = [  # (kernel set = library suffix, name, params maker, batch, ticks, ove
     ("go1", "go1 N=20, two workgroups per CU for full windows too", "go1", 600, 45, dict(solve_workgroups_per_cu=2)),
     ("cassie", "cassie N=20 (k_mhe_solve_lg_2_n20, k_mhe_solve_r3_2_n20)", "cassie", 900, 60, {}),
     ("legs1", "pogox N=100 (factor streamed from the slab)", "pogox", 64, 130, {}),
+    ("legs1", "pogox N=100, 320 instances: full windows on k_mhe_solve_rr_1 (row state in registers, two workgroups per CU)", "pogox", 320, 128, {}),
     ("legs4", "go1 N=5", "go1", 64, 30, dict(N=5)),
     ("legs4", "go1 N=7 (odd horizon: two-wavefront solve form)", "go1", 64, 30, dict(N=7)),
     ("legs3", "three legs, six joints, N=12", "go1", 64, 40, dict(num_legs=3, joints_per_leg=6, N=12)),
@@ -61,6 +62,7 @@ CASES = [  # (kernel set = library suffix, name, params maker, batch, ticks, ove
     ("go1", "go1 N=20 with osqp.polish (k_mhe_solve_ll_4_n20_pol, k_mhe_solve_r3_4_n20_pol)", "go1", 800, 50, dict(polish=1)),
     ("cassie", "cassie N=20 with osqp.polish (k_mhe_solve_lg_2_n20_pol, k_mhe_solve_r3_2_n20_pol)", "cassie", 800, 45, dict(polish=1)),
     ("legs1", "pogox N=100 with osqp.polish (factor streamed from the slab)", "pogox", 64, 110, dict(polish=1)),
+    ("legs1", "pogox N=100 with osqp.polish, 320 instances (k_mhe_solve_rr_1_pol)", "pogox", 320, 112, dict(polish=1)),
     ("foot4", "go1 leg_odom_type 1 with osqp.polish", "go1", 128, 30, dict(leg_odom_type=1, polish=1)),
 ]
 MAKERS = {"go1": go1_params, "cassie": cassie_params, "pogox": pogox_params}
