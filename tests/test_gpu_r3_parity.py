@@ -170,3 +170,29 @@ def test_rr_pogox_polish_matches_oracle():
     assert _status_agrees(pol, ref)
     assert (pol == ref).mean() >= 0.99, (pol == ref).mean()
     assert _tol_units(g["x"][1:], x_ref[1:]) <= 1.0
+
+
+def test_rr_other_window_length_and_caps():
+    """the rows-in-registers kernel at another run-time horizon (N = 90: three tiles of Dyn lane pairs instead of four, other fill
+    of the last tiles; shorter windows fit the generic placement twice per CU and keep it) and with an iteration cap below
+    convergence; a cap on the resident workgroups (solve_workgroups_per_cu = 1) must fall back to the generic kernel and give the
+    same estimates to rounding"""
+    p = _params(pogox_params, N=90, max_qp_iter=60)
+    D, K = 8, 116
+    s = make_streams(p, D, K)
+    x_ref, vb_ref, q_ref, _, it_ref = O.run_streams(p, s, nthreads=16, want_iters=True)
+    g = run_tiled(p, s, K, reps=36, family="_rr_", min_batch=256)
+    assert np.abs(g["quat"] - q_ref).max() < 1e-9
+    assert np.array_equal(g["iters"][1:], it_ref[1:]) and g["iters"][p.N:].max() == 60
+    assert block_err(g["x"][1:], x_ref[1:]) <= 1.0
+    q1 = p.copy()
+    q1.solve_workgroups_per_cu = 1
+    est = BatchedEstimator(q1, D * 36)
+    assert "_rr_" not in est.solve_kernel_name(True)
+    sd = streams_to_device(_tile(s, 36))
+    for k in range(K):
+        est.push_stream_step(sd, k)
+        est.step(k)
+    o = est.get()
+    est.close()
+    assert block_err(o["x"][:D], g["x"][-1]) <= 0.01
