@@ -25,14 +25,15 @@ else
     pids=()
     run() { "$@" & pids+=($!); while [ "$(jobs -rp | wc -l)" -ge "$JOBS" ]; do sleep 0.2; done; }
     # heaviest sets first (foot-state kernels, then the generic ones)
-    # DEKF_NO_MLICM: the kernel sets compiled with LLVM's machine-level loop-invariant code motion off (default: the fixed-horizon Go1
-    # and Cassie sets, 1 and 2, and the one-leg set 4).  That pass hoists constant materialisations and address arithmetic to the top
-    # of a kernel, where they stay live across the whole solve: at the 168 VGPRs of the three-workgroup kernels the register
-    # allocator answered with 43 spilled VGPRs (5 without the pass), i.e. scratch traffic beyond L2; the
-    # rows-in-registers kernel of set 4 (k_mhe_solve_rr_1, 256 VGPRs) spills 40 VGPRs inside its iteration loops with the pass and
-    # none without.  Not for every set: hipcc 7.2 dies on some of the others without the pass ("Illegal instruction detected").
-    # "all" / "none" for A/B builds.
-    NO_MLICM=${DEKF_NO_MLICM:-"1 2 4"}
+    # DEKF_NO_MLICM: the kernel sets compiled with LLVM's machine-level loop-invariant code motion off (default: every set of solve
+    # kernels; the set of the small kernels, 1024, keeps the pass).  That pass hoists constant materialisations and address
+    # arithmetic to the top of a kernel, where they stay live across the whole solve: at the 168 VGPRs of the three-workgroup
+    # kernels the register allocator answered with 43 spilled VGPRs (7 without the pass), i.e. scratch traffic beyond L2 (DESIGN.md
+    # section 6); the rows-in-registers kernel of set 4 (k_mhe_solve_rr_1, 256 VGPRs) spills 40 VGPRs inside its iteration loops with
+    # the pass and none without; the foot-state kernels need 205 instead of 256 VGPRs and run 2 % faster.  Mid-round, hipcc 7.2 died
+    # on two sets without the pass ("Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base"; it compiles all of them
+    # now): if that comes back, name the sets that build here ("1 2 4" are the ones with measured gains).  "none" for A/B builds.
+    NO_MLICM=${DEKF_NO_MLICM:-"1 2 4 8 16 32 64 128 256 512"}
     for m in 512 256 128 64 32 16 8 4 1 2 1024; do
         X=""
         case " $NO_MLICM " in *" $m "*|*" all "*) X="-mllvm -disable-machine-licm";; esac
