@@ -155,6 +155,8 @@ def main():
         ok &= case("cassie N=20, 32 x 5000 ticks, tiled x 25 (B = 800)", cassie_params, 32, 5000, th, reps=25)
         ok &= case("go1 N=20 with osqp.polish, 32 x 1500 ticks, tiled x 25 (B = 800)", go1_params, 32, 1500, th, reps=25, polish=1)
         ok &= case("cassie N=20 with osqp.polish, 32 x 1500 ticks, tiled x 25 (B = 800)", cassie_params, 32, 1500, th, reps=25, polish=1)
+        ok &= case("pogox N=100, 16 x 1500 ticks, tiled x 18 (B = 288: k_mhe_solve_rr_1)", pogox_params, 16, 1500, th, reps=18)
+        ok &= case("pogox N=100 with osqp.polish, 16 x 600 ticks, tiled x 18 (B = 288: k_mhe_solve_rr_1_pol)", pogox_params, 16, 600, th, reps=18, polish=1)
         sys.exit(0 if ok else 1)
     ok &= case("go1 N=20 (BASELINE configs[1] shape), 256 x 400 ticks tiled x 4 (B = 1024)", go1_params, 256, 400, th, reps=4)
     ok &= case("go1 N=20, KF mode", go1_params, 64, 200, th, est_type=1)
