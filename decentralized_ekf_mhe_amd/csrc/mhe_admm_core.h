@@ -693,9 +693,10 @@ DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
         }
     };
     if (smax > 0) {
-        // ring of three operand sets, two steps of prefetch in flight: the factor of these shapes streams from the HBM slab
+        // ring of operand sets, RING - 1 steps of prefetch in flight: the factor of these shapes streams from the HBM slab
         // (two sets, one step ahead, left a memory round trip exposed in every step: 1.1-1.3 k cycles per step measured)
-        constexpr int RING = 3;
+        // (round 4: four sets — with machine LICM off the kernel has the registers, 207 -> 255 VGPRs: 275 k -> 279 k steps/s on Go1)
+        constexpr int RING = 4;
         Ops r[RING];
 #pragma unroll
         for (int u = 0; u < RING - 1; ++u)
@@ -817,6 +818,9 @@ DEKF_FN void phase_sweeps_generic(Q& q, double alpha) {
 #else
     sweep_legs_generic<false>(q, alpha);
 #endif
+    // (Measured and not kept, round 4: the three waiting wavefronts requesting their rows of S_k^-1 — and the meeting block's operands —
+    // while wavefront 0 works through the forward legs, so that this phase reads LDS only: 272 k against 279 k steps/s on Go1 with
+    // foot states.  The requests compete with the legs' own operand stream, which is the critical path.)
     DEKF_SYNC();
     DEKF_PROF_MARK(q, 3);
     // g_k = S_k^-1 f_k is outside both recursions: one entry per lane, next to the meeting block
