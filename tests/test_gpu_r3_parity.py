@@ -196,3 +196,21 @@ def test_rr_other_window_length_and_caps():
     o = est.get()
     est.close()
     assert block_err(o["x"][:D], g["x"][-1]) <= 0.01
+
+
+def test_rr_pogox_flight_vo_dropout_and_late_vo():
+    """inputs the hopping logs do not produce, through the rows-in-registers kernel at every tick: the leg in the air for 120 ticks
+    (longer than the window: every Meas weight at the swing value), on the ground for 60, a camera that drops out for 50 ticks, and a
+    slow, late camera (3.75 Hz, 60 ms) on half of the robots"""
+    p = _params(pogox_params)
+    D, K = 8, 150
+    s = make_streams(p, D, K, vo_rate=30.0)
+    slow = make_streams(p, D, K, vo_rate=3.75, vo_latency=0.06)
+    for key in ("vo_mask", "vo_t_pre", "vo_t_now", "vo_dp", "vo_t_pose", "vo_q"):
+        s[key][:, 4:] = slow[key][:, 4:]
+    s["contact"][10:130, 0:2] = 0.0
+    s["contact"][40:100, 2:4] = 1.0
+    s["vo_mask"][60:110, 1::2] = 0
+    x_ref, vb_ref, q_ref, _, it_ref = O.run_streams(p, s, nthreads=16, want_iters=True)
+    g = run_tiled(p, s, K, reps=36, family="_rr_", min_batch=256)
+    check_every_tick(g, x_ref, vb_ref, q_ref, it_ref, p.N, iters_equal=0.97)

@@ -1,7 +1,8 @@
 """The device cores under AddressSanitizer + UBSan (CPU build only: GPU ASan is not available on
 this pool).  A stand-alone driver links tests/hostsim/hostsim.cpp with -fsanitize=address,undefined
 and steps Go1, a 2-leg/5-joint robot, a long-horizon 1-leg robot and two leg_odom_type = 1 shapes (foot positions as states)
-through window fill, marginalisation and VO updates; any out-of-bounds index in the kernels' LDS/HBM carving aborts it."""
+through window fill, marginalisation and VO updates, two of them with osqp.polish on; any out-of-bounds index in the kernels'
+LDS/HBM carving aborts it."""
 import os
 import subprocess
 import sys
@@ -11,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 DRIVER = r'''
 #include "hostsim.cpp"
 #include <cstdio>
-static int run(int L, int nj, int N, int steps, int ft = 0, int form = 0) {
-    dekf_params p; default_params(&p); p.ekf_rate = 200; p.num_legs = L; p.joints_per_leg = nj; p.N = N; p.leg_odom_type = ft; p.arrival_cost_form = form;
+static int run(int L, int nj, int N, int steps, int ft = 0, int form = 0, int polish = 0) {
+    dekf_params p; default_params(&p); p.ekf_rate = 200; p.num_legs = L; p.joints_per_leg = nj; p.N = N; p.leg_odom_type = ft; p.arrival_cost_form = form; p.polish = polish;
     const int ns = 9 + 3 * L * ft;
     int B = 2;
     void* h = hs_create(&p, B);
@@ -46,8 +47,10 @@ static int run(int L, int nj, int N, int steps, int ft = 0, int form = 0) {
 // marginalisation with swinging feet and VO updates, with BOTH forms of the arrival cost: 0 = the reference's covariance form
 // (the default: pivoted generic inverse in the enlarged AsmScratch), 1 = information form (marginalize_info); and a 2-leg shape
 int main() {
+    // ... and osqp.polish (a second factorisation, the refinement steps' residual vectors, the save / load / accumulate of the polished
+    // point in the slab scratch: mhe_solve_core.h polish_swap_in / polish_accumulate) on a 9-state and a 21-state shape
     return run(4, 3, 20, 60) | run(2, 5, 8, 30) | run(1, 3, 40, 70) | run(4, 3, 20, 34, 1, 0) | run(4, 3, 20, 34, 1, 1) |
-           run(2, 5, 6, 24, 1, 0) | run(2, 5, 6, 24, 1, 1);
+           run(2, 5, 6, 24, 1, 0) | run(2, 5, 6, 24, 1, 1) | run(4, 3, 20, 44, 0, 0, 1) | run(2, 5, 6, 24, 1, 0, 1);
 }
 '''
 
