@@ -457,3 +457,27 @@ def test_pipelined_allgather_returns_each_steps_own_v_b():
         ref.step(k)
         assert np.array_equal(got[k], ref.get()["v_b"]), k
     ref.close()
+
+
+def test_pipelined_steps_with_the_rows_in_registers_kernel():
+    """solve_pipeline = 1 with PogoX at 300 instances (full windows on k_mhe_solve_rr_1: the stash of y / z and the polishing
+    scratch live in the per-parity slab set): bit-identical to the in-order run"""
+    p = _params(pogox_params)
+    B, K = 300, 118
+    sd = streams_to_device(make_streams(p, B, K))
+    outs = []
+    for pipe in (0, 1):
+        q = p.copy()
+        q.solve_pipeline = pipe
+        est = BatchedEstimator(q, B)
+        assert est.solve_kernel_name(True) == "k_mhe_solve_rr_1"
+        for k in range(K):
+            est.push_stream_step(sd, k)
+            est.step(k)
+        outs.append((est.get(), est.solver_info()))
+        est.close()
+    (a, ia), (b, ib) = outs
+    assert (a["status"] == 1).all()
+    for key in ("x", "v_b", "quat", "status"):
+        assert np.array_equal(a[key], b[key]), key
+    assert np.array_equal(ia["iters"], ib["iters"]) and np.array_equal(ia["pri_res"], ib["pri_res"])
