@@ -20,7 +20,7 @@ struct AsmScratch {
         const int ns = 9 + (ft ? 3 * L : 0), na = ns + 3, dim = na + 3 * L;
         return ns * ns /*Minv*/ + 2 * na * ns /*Am, AmMi*/ + dim * dim /*S*/ + 2 * dim /*pivot row, column*/ +
                dim /*u*/ + dim /*Yu*/ + ns /*M^-1 n*/ + 3 * L * ns /*H M^-1*/ + 16 +
-               (ft ? dim * dim + dim : 0) /*augmented half of the pivoted inverse (foot-position states)*/;
+               (ft && !DEKF_DEVICE_BUILD ? dim * dim + dim : 0) /*augmented half of the pivoted inverse in LDS: foot-position states, lane-sequential build only — the device inverts in registers*/;
     }
 };
 
@@ -357,6 +357,74 @@ DEKF_FN bool gj_columns_plain(double (&a)[N], int lane) {
     return ok;
 }
 
+// In-place inverse WITH ROW PIVOTING of the N x N matrix S (row-major in LDS, leading dimension N, N <= 64): lane j < N takes
+// column j into registers, the wavefront runs Gauss-Jordan with the pivot rule and the arithmetic of winverse(.., pivoting = true)
+// — first largest |entry| of the pivot column at or below the diagonal, row swap, d = 1 / pivot (IEEE), row p scaled by d, every other
+// row i minus s_ip times the scaled row — and writes S^-1 back.  Bit-identical to the augmented [S | I] form in LDS: the in-place
+// scheme keeps the one column of the growing inverse that is no longer a unit vector where the eliminated column of S was (all other
+// entries of [S | I] it leaves out are exact 0 / 1 / never read again), and a row swap moves a register in EVERY lane, i.e. in the
+// columns of S and of the inverse alike.  What the swaps leave behind is a column permutation of the result, B = (P S)^-1 = S^-1 P':
+// lane j carries the original index of the row that sits at position j (`lab`, exchanged between the two lanes of a swap), which is
+// the column of S^-1 its registers hold at the end — the write-back applies it for free.
+// The register array rotates by one row per pivot (gj_columns): the candidate rows p .. N-1 are a[0 .. N-1-p], the pivot row is a[0]
+// after the swap, all register indices are static.  Replaces 41 rounds of LDS read-modify-write per pivot (with two run-time integer
+// divisions per element) for the reference form of the foot-state arrival cost (MheSrb.cpp:588,640: Eigen inverse() = LU with
+// partial pivoting).
+template <int N>
+DEKF_FN bool inverse_pivoted_regs(double* S, int lane) {
+    static_assert(N <= WAVE, "one column per lane");
+    const int j = lane < N ? lane : N - 1;  // lanes beyond the matrix mirror the last column (never broadcast, never stored)
+    double a[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = S[N * i + j];
+    int lab = lane;
+    bool ok = true;
+    for (int p = 0; p < N; ++p) {
+        // pivot search in column p (lane p) over rows p .. N-1
+        double best = fabs(a[0]);
+        int bi = 0;
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            const double v = fabs(a[i]);
+            const bool take = i < N - p && v > best;
+            best = take ? v : best;
+            bi = take ? i : bi;
+        }
+        bi = __builtin_amdgcn_readlane(bi, p);
+        if (readlane_f64(best, p) == 0.0) { ok = false; break; }  // wave-uniform
+        // rows at positions p and p + bi change places (registers 0 and bi of every lane; their labels between the two lanes)
+        {
+            const double r0 = a[0];
+            double pr = r0;
+#pragma unroll
+            for (int i = 1; i < N; ++i) {
+                const bool hit = i == bi;
+                pr = hit ? a[i] : pr;
+                a[i] = hit ? r0 : a[i];
+            }
+            a[0] = pr;
+            const int lp = __builtin_amdgcn_readlane(lab, p), lq = __builtin_amdgcn_readlane(lab, p + bi);
+            lab = lane == p ? lq : (lane == p + bi ? lp : lab);
+        }
+        const double d = 1.0 / readlane_f64(a[0], p);
+        const bool is_p = lane == p;
+        const double rd = (is_p ? 1.0 : a[0]) * d;
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            const double ci = readlane_f64(a[i], p);
+            a[i - 1] = fma(-ci, rd, is_p ? 0.0 : a[i]);
+        }
+        a[N - 1] = rd;
+    }
+    wave_sync();  // every lane has read its column before any lane overwrites S
+    if (ok && lane < N) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) S[N * i + lab] = a[i];
+    }
+    wave_sync();
+    return ok;
+}
+
 // column j (0..5) of the 6x6 process covariance G C G' of a step with rotation R (the matrix step_gains inverts)
 DEKF_FN void cov6_column(const DevCfg& c, const double* R, int j, double (&col)[6]) {
     const double dt = c.dt;
@@ -659,26 +727,17 @@ DEKF_FN bool marginalize_info(const DevCfg& c, const DevState& s, int b, const d
     return ok;
 }
 
-// marginalizeQP(step): fold window step `step` into (Mp, np)   (MheSrb.cpp:475-713)
-DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int step, double* sm) {
-    const double* r = s.rec + ((size_t)b * c.wcap + (step % c.wcap)) * c.rec;
-    const int nm = c.nm, L = c.L, ns = c.ns, ft = c.ft;
+// marginalizeQP(step) in the generic form (any state dimension): rows [Dyn (ns) | VO (3, when flagged) | Meas (nm)]   (MheSrb.cpp:475-713)
+// LT / VT: 0 / -1 = leg count and VO flag read at run time (the lane-sequential build, type 0 beyond four legs); LT = 1..4, VT = 0 / 1:
+// the foot-state shapes of the device build with every dimension a compile-time constant — the same statements in the same order
+// (bit-identical results), but the element -> (row, column) divisions become multiplications and the dot products unroll.
+template <int LT, int VT>
+DEKF_FN bool marginalize_generic(const DevCfg& c, const DevState& s, int b, const double* r, double* sm) {
+    const int L = LT > 0 ? LT : c.L, ft = LT > 0 ? 1 : c.ft;
+    const int nm = 3 * L, ns = 9 + (ft ? 3 * L : 0);
     double* Mp = s.Mp + (size_t)ns * ns * b;
     double* np = s.np_ + (size_t)ns * b;
-    const bool vo = r[Rec::VOF] != 0.0;
-#if DEKF_DEVICE_BUILD
-    if (!ft) {
-        switch (L) {  // wave-uniform
-            case 1: return vo ? marginalize_regs<1, true>(c, s, b, r, sm) : marginalize_regs<1, false>(c, s, b, r, sm);
-            case 2: return vo ? marginalize_regs<2, true>(c, s, b, r, sm) : marginalize_regs<2, false>(c, s, b, r, sm);
-            case 3: return vo ? marginalize_regs<3, true>(c, s, b, r, sm) : marginalize_regs<3, false>(c, s, b, r, sm);
-            case 4: return vo ? marginalize_regs<4, true>(c, s, b, r, sm) : marginalize_regs<4, false>(c, s, b, r, sm);
-            default: break;
-        }
-    }
-#endif
-    if (ft && c.marg_info) return marginalize_info(c, s, b, r, sm);
-    // generic form (any state dimension): rows [Dyn (ns) | VO (3, when flagged) | Meas (nm)]
+    const bool vo = VT >= 0 ? VT != 0 : r[Rec::VOF] != 0.0;
     const int na = vo ? ns + 3 : ns;
     const int dim = na + nm;
     double* Minv = sm;                      // ns x ns
@@ -788,8 +847,17 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
     // (measured: an instance turns indefinite after 130 ticks of a 5 Hz gait).  The reference inverts this matrix with
     // Eigen's inverse() = LU with partial pivoting (MheSrb.cpp:588,640); Gauss-Jordan with the same row-pivot rule visits
     // the same pivots.
-    if (ft) ok = winverse(S, dim, HMi + nm * ns, true) && ok;
-    else ok = winverse_definite(S, dim, wsc) && ok;
+    if (ft) {
+#if DEKF_DEVICE_BUILD
+        // (device: the same elimination with one column per lane in registers, bit-identical — inverse_pivoted_regs; dim = 9 + 6 L [+ 3])
+        if constexpr (LT > 0) ok = inverse_pivoted_regs<9 + 6 * LT + 3 * (VT > 0 ? 1 : 0)>(S, DEKF_LANE()) && ok;
+        else ok = false;
+#else
+        ok = winverse(S, dim, HMi + nm * ns, true) && ok;
+#endif
+    } else {
+        ok = winverse_definite(S, dim, wsc) && ok;
+    }
     wfor(dim, [&](int i) {
         double sacc = 0;
         for (int t = 0; t < dim; ++t) sacc += S[i * dim + t] * u[t];
@@ -814,6 +882,38 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
         }
     });
     return ok;
+}
+
+// marginalizeQP(step): fold window step `step` into (Mp, np)   (MheSrb.cpp:475-713)
+DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int step, double* sm) {
+    const double* r = s.rec + ((size_t)b * c.wcap + (step % c.wcap)) * c.rec;
+    const int L = c.L, ft = c.ft;
+    const bool vo = r[Rec::VOF] != 0.0;
+#if DEKF_DEVICE_BUILD
+    if (!ft) {
+        switch (L) {  // wave-uniform
+            case 1: return vo ? marginalize_regs<1, true>(c, s, b, r, sm) : marginalize_regs<1, false>(c, s, b, r, sm);
+            case 2: return vo ? marginalize_regs<2, true>(c, s, b, r, sm) : marginalize_regs<2, false>(c, s, b, r, sm);
+            case 3: return vo ? marginalize_regs<3, true>(c, s, b, r, sm) : marginalize_regs<3, false>(c, s, b, r, sm);
+            case 4: return vo ? marginalize_regs<4, true>(c, s, b, r, sm) : marginalize_regs<4, false>(c, s, b, r, sm);
+            default: break;
+        }
+    }
+#endif
+    if (ft && c.marg_info) return marginalize_info(c, s, b, r, sm);
+#if DEKF_DEVICE_BUILD
+    if (ft) {
+        switch (L) {  // wave-uniform
+            case 1: return vo ? marginalize_generic<1, 1>(c, s, b, r, sm) : marginalize_generic<1, 0>(c, s, b, r, sm);
+            case 2: return vo ? marginalize_generic<2, 1>(c, s, b, r, sm) : marginalize_generic<2, 0>(c, s, b, r, sm);
+            case 3: return vo ? marginalize_generic<3, 1>(c, s, b, r, sm) : marginalize_generic<3, 0>(c, s, b, r, sm);
+            case 4: return vo ? marginalize_generic<4, 1>(c, s, b, r, sm) : marginalize_generic<4, 0>(c, s, b, r, sm);
+            default: return false;  // (dekf_create refuses more than four legs)
+        }
+    }
+#endif
+    (void)vo;
+    return marginalize_generic<0, -1>(c, s, b, r, sm);
 }
 
 // everything update(T) does before initQP/solveQP; T >= 1
