@@ -357,6 +357,43 @@ DEKF_FN bool gj_columns_plain(double (&a)[N], int lane) {
     return ok;
 }
 
+// M^-1 for the generic marginalisation, in registers: lane j < N takes column j of the arrival information from HBM (through the
+// LOWER triangle, see marginalize_generic), the wavefront runs the Gauss-Jordan sweep of winverse_definite — natural pivot order,
+// d = 1 / pivot, pivot row r_j d, pivot column -c_i d, elsewhere a_ij - c_i r_j d, the very expressions — and leaves M^-1 in LDS.
+// Bit-identical to the LDS form (every entry sees the same operations in the same order); 21 loads in flight per lane instead of
+// seven dependent rounds of them, no LDS round trip per pivot.
+template <int N>
+DEKF_FN bool inverse_definite_regs(const double* Mp, double* Minv, int lane) {
+    static_assert(N <= WAVE, "one column per lane");
+    const int j = lane < N ? lane : N - 1;
+    double a[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) a[i] = i >= j ? Mp[N * i + j] : Mp[N * j + i];
+    bool ok = true;
+    for (int p = 0; p < N; ++p) {
+        const double piv = readlane_f64(a[0], p);
+        if (!(fabs(piv) > 0.0) || !(fabs(piv) < 1e300)) { ok = false; break; }  // wave-uniform
+        const double d = 1.0 / piv;
+        const bool is_p = lane == p;
+        const double rp = a[0];
+        const double newrow = is_p ? d : rp * d;
+#pragma unroll
+        for (int i = 1; i < N; ++i) {
+            const double ci = readlane_f64(a[i], p);
+            const double pc = -ci * d;
+            const double el = a[i] - ci * rp * d;
+            a[i - 1] = is_p ? pc : el;
+        }
+        a[N - 1] = newrow;
+    }
+    if (lane < N) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) Minv[N * i + lane] = a[i];
+    }
+    wave_sync();
+    return ok;
+}
+
 // In-place inverse WITH ROW PIVOTING of the N x N matrix S (row-major in LDS, leading dimension N, N <= 64): lane j < N takes
 // column j into registers, the wavefront runs Gauss-Jordan with the pivot rule and the arithmetic of winverse(.., pivoting = true)
 // — first largest |entry| of the pivot column at or below the diagonal, row swap, d = 1 / pivot (IEEE), row p scaled by d, every other
@@ -393,7 +430,7 @@ DEKF_FN bool inverse_pivoted_regs(double* S, int lane) {
         bi = __builtin_amdgcn_readlane(bi, p);
         if (readlane_f64(best, p) == 0.0) { ok = false; break; }  // wave-uniform
         // rows at positions p and p + bi change places (registers 0 and bi of every lane; their labels between the two lanes)
-        {
+        if (bi != 0) {  // wave-uniform
             const double r0 = a[0];
             double pr = r0;
 #pragma unroll
@@ -751,18 +788,34 @@ DEKF_FN bool marginalize_generic(const DevCfg& c, const DevState& s, int b, cons
     double* HMi = Min + ns;                 // nm x ns: A_meas M^-1
     const double* R = r + Rec::R;
     const double dt = c.dt;
-    wfor(ns * ns + na * ns, [&](int e) {
-        // M enters through its LOWER triangle, as in the reference: M^-1 comes from Eigen's SimplicialLLT (default UpLo = Lower,
-        // MheSrb.cpp:524-525), while the QP takes the upper one (OSQP reads triu(P)).  M+ = -B' S^-1 B is symmetric only up to
-        // rounding, and with foot-position states that rounding is amplified at every swing phase (measured: 1e-13 -> 1e-1
-        // over three phases when both triangles feed the inverse)
-        if (e < ns * ns) { const int i = e / ns, j = e - ns * i; Minv[e] = i >= j ? Mp[e] : Mp[ns * j + i]; }
-        else {
-            int q = e - ns * ns, i = q / ns, j = q - ns * i;
+#if DEKF_DEVICE_BUILD
+    constexpr bool REGS = LT > 0;  // M^-1 in registers (same arithmetic: inverse_definite_regs)
+#else
+    constexpr bool REGS = false;
+#endif
+    // M enters through its LOWER triangle, as in the reference: M^-1 comes from Eigen's SimplicialLLT (default UpLo = Lower,
+    // MheSrb.cpp:524-525), while the QP takes the upper one (OSQP reads triu(P)).  M+ = -B' S^-1 B is symmetric only up to
+    // rounding, and with foot-position states that rounding is amplified at every swing phase (measured: 1e-13 -> 1e-1
+    // over three phases when both triangles feed the inverse)
+    bool ok;
+    if constexpr (REGS) {
+#if DEKF_DEVICE_BUILD
+        wfor(na * ns, [&](int q) {
+            const int i = q / ns, j = q - ns * i;
             Am[q] = i < ns ? adyn_entry(R, dt, i, j) : ((i - ns) == j ? 1.0 : 0.0);
-        }
-    });
-    bool ok = winverse_definite(Minv, ns, wsc);
+        });
+        ok = inverse_definite_regs<9 + 3 * (LT > 0 ? LT : 1)>(Mp, Minv, DEKF_LANE());
+#endif
+    } else {
+        wfor(ns * ns + na * ns, [&](int e) {
+            if (e < ns * ns) { const int i = e / ns, j = e - ns * i; Minv[e] = i >= j ? Mp[e] : Mp[ns * j + i]; }
+            else {
+                int q = e - ns * ns, i = q / ns, j = q - ns * i;
+                Am[q] = i < ns ? adyn_entry(R, dt, i, j) : ((i - ns) == j ? 1.0 : 0.0);
+            }
+        });
+        ok = winverse_definite(Minv, ns, wsc);
+    }
     wmatmul<false, false>(AmMi, ns, Am, ns, Minv, ns, na, ns, ns);
     wfor(nm * ns + ns, [&](int e) {
         if (e >= nm * ns) {
@@ -791,6 +844,9 @@ DEKF_FN bool marginalize_generic(const DevCfg& c, const DevState& s, int b, cons
         S[e] = v;
     });
     // minus the inverse gains on the diagonal blocks: one lane per block
+    // (measured and not kept: the 6 x 6 process gain spread over six lanes with the operations of inv_spd_unrolled — the compiler
+    // contracts the fully unrolled serial form differently somewhere, outputs move by 1e-8 against the lane-per-block form below;
+    // the block is 12 k of the 250 k cycles of a marginalisation)
     wfor(2 * L + 2, [&](int blk) {
         if (blk < L) {
             double qi[6];
