@@ -821,13 +821,25 @@ DEKF_FN bool factor_blocks_generic(Q& q) {
                 // C couples the base states among themselves (9 x 9) and every foot with itself (3 x 3): row / column j of C is
                 // exactly zero outside [t0, t1) (solve_factor 3b-3c writes those zeros), so only that range is summed — in the
                 // same three accumulators, i.e. bit-identical to the full sum: 5.6 products per entry instead of 21
-                const int t0 = j < 9 ? 0 : 9 + 3 * ((j - 9) / 3), t1 = j < 9 ? 9 : t0 + 3;
-                if (top) {  // W_{k-1} C_{k-1}'
-                    cdptr cr = C + NS * j;
-                    for (int t = t0; t < t1; t += 3) { s0 += wr[t] * cr[t]; s1 += wr[t + 1] * cr[t + 1]; s2 += wr[t + 2] * cr[t + 2]; }
-                } else {    // What_k C_k
-                    cdptr cc = C + j;
-                    for (int t = t0; t < t1; t += 3) { s0 += wr[t] * cc[NS * t]; s1 += wr[t + 1] * cc[NS * (t + 1)]; s2 += wr[t + 2] * cc[NS * (t + 2)]; }
+                // (branch-free: the first group of three for every entry, the second and third — base columns only — computed from clamped
+                // indices and selected; with run-time loop bounds every group waited for its own LDS reads, 7.4 k cycles per block)
+                const bool base = j < 9;
+                const int t0 = base ? 0 : 9 + 3 * ((j - 9) / 3), tb = base ? 3 : t0, tc = base ? 6 : t0;
+                double w[9], cv[9];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int t = (u == 0 ? t0 : (u == 1 ? tb : tc));
+#pragma unroll
+                    for (int v = 0; v < 3; ++v) {
+                        w[3 * u + v] = wr[t + v];
+                        cv[3 * u + v] = top ? C[NS * j + t + v] : C[NS * (t + v) + j];
+                    }
+                }
+                s0 += w[0] * cv[0]; s1 += w[1] * cv[1]; s2 += w[2] * cv[2];
+#pragma unroll
+                for (int u = 1; u < 3; ++u) {
+                    const double n0 = s0 + w[3 * u] * cv[3 * u], n1 = s1 + w[3 * u + 1] * cv[3 * u + 1], n2 = s2 + w[3 * u + 2] * cv[3 * u + 2];
+                    s0 = base ? n0 : s0; s1 = base ? n1 : s1; s2 = base ? n2 : s2;
                 }
                 ts[p] -= s0 + (s1 + s2);
             }
