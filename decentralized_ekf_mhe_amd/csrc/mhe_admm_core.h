@@ -507,21 +507,28 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
     const bool gown = !leg && act;
     dptr gst = gown ? xd + (top ? 0 : 9 * (K - 1)) + i : dummy;  // where rows 2, 3 put -g of step 1
     const int gstep = gown ? rstep : 0;
-    auto fload = [&](int s, Ops& o) {
-        cdptr W = fm + (s - 1) * fstep;
+    // (the operands of step s sit s - 1 lane-dependent strides behind those of step 1, and the loads are issued in the order of the
+    // steps: running pointers, one addition per array and step — as s * stride every address cost a quarter-rate 32-bit multiply
+    // on the wavefront whose issue slots are the iteration's critical path, nine of them per pair of steps)
+    cdptr fmr = fm, frr = fr;
+    auto fload = [&](int, Ops& o) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) o.w[t] = W[t];
-        o.rhs = fr[(s - 1) * frstep];
+        for (int t = 0; t < 9; ++t) o.w[t] = fmr[t];
+        o.rhs = frr[0];
+        fmr = fmr + fstep;
+        frr = frr + frstep;
     };
     double v = xs[(top ? 0 : 9 * (K - 1)) + i];  // f_0 = b_0 / f^_{K-1} = b_{K-1}
     {
         Ops r[RING];
+        dptr gsr = gst;
         auto fstepf = [&](const Ops& c, Ops& n, int s, int ahead) {
             if (s + ahead <= M) fload(s + ahead, n);
             const double src = rows23_from_rows01(v);
             const double res = chain_matvec_dpp(src, c.w, c.rhs);
             v = res;
-            gst[(s - 1) * gstep] = res;
+            gsr[0] = res;
+            gsr = gsr + gstep;
         };
 #pragma unroll
         for (int u = 0; u < RING - 1; ++u)
@@ -566,27 +573,35 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
         const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0, dstep = own ? (top ? -SV : SV) : 0;
         cdptr Wp = q.Wk + (top ? M : M - 1) * 81 + i;  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
         const int wstep = top ? -81 : 81;
+        cdptr Wr = Wp, Dr = Dp;
+        dptr xdr = xdp, xr = xp;       // operands of the step being loaded
+        dptr xdw = xdp, xw = xp;       // results of the step being computed
         auto bload = [&](int s, Bops& o) {
-            const int sl = s <= M ? s : (top ? M : s);  // row 0 has one step less: its last load repeats block 0
-            cdptr W = Wp + sl * wstep;
+            const bool adv = s <= M || !top;  // row 0 has one step less: its last load repeats block 0
+            Wr = Wr + (adv ? wstep : 0);
+            xdr = xdr + (adv ? xdstep : 0);
+            Dr = Dr + (adv ? dstep : 0);
+            xr = xr + (adv ? xstep : 0);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) o.w[t] = W[9 * t];
-            o.ng = xdp[sl * xdstep];
-            o.dsc = Dp[sl * dstep];
-            o.xo = xp[sl * xstep];
+            for (int t = 0; t < 9; ++t) o.w[t] = Wr[9 * t];
+            o.ng = xdr[0];
+            o.dsc = Dr[0];
+            o.xo = xr[0];
         };
         Bops r[RING];
         auto bstepf = [&](const Bops& c, Bops& n, int s, int ahead) {
             if (s + ahead <= NOUT) bload(s + ahead, n);
             const double res = chain_matvec_dpp(v, c.w, -c.ng);
             v = res;
-            if (s <= M) {
-                xdp[s * xdstep] = c.dsc * res;
-                xp[s * xstep] = relax(alpha, res, c.xo);
-            } else if (!top && own) {  // the bottom leg is one block longer
-                xdp[s * xdstep] = c.dsc * res;
-                xp[s * xstep] = relax(alpha, res, c.xo);
-            }
+            xdw = xdw + xdstep;
+            xw = xw + xstep;
+            // every lane stores in every step, the ones with nothing to store into their dummy word (lanes that own no component
+            // point there anyway; the top leg's lanes in the one step the bottom leg is longer): an address select instead of
+            // two guarded copies of the stores with their exec-mask bookkeeping
+            const bool real = s <= M || !top;
+            dptr dxd = real ? xdw : dummy, dx = real ? xw : dummy;
+            dxd[0] = c.dsc * res;
+            dx[0] = relax(alpha, res, c.xo);
         };
 #pragma unroll
         for (int u = 0; u < RING - 1; ++u)
