@@ -107,11 +107,12 @@ struct Idx {
 struct Gws {
     // D (n) | E (m) | lo (m) | hi (m) | rho (m) | Sv (K*6L) | Sw (K*25) | Sc (K*6) | Sf (K*6L ft) |
     // Wm (K*6L) | Wd (K*24) | Wc (K*6) | Wf (K*6L ft) | PA (K*NS^2) | Sinv (K*NS^2) | Wk (K*NS^2) |
+    // WT (K*81, 9-state kernels that stream the factor from here: the W blocks once more, transposed, for the outward legs) |
     // x (n) | z (m) | y (m) | zt (m) | cf (m): the row-phase state between chunks of iterations, three-workgroup placement only |
     // pol (2 K NS + 5 m): osqp.polish — the polished point and the bounds while a refinement step solves for a correction, and
     // the KKT residual vectors that step starts from (mhe_solve_core.h: polish_swap_in / polish_accumulate)
     int n_pad, m_pad, K;
-    int D, E, lo, hi, rho, Sv, Sw, Sc, Sf, Wm, Wd, Wc, Wf, PA, Sinv, Wk, x, z, y, zt, cf, pol, total;
+    int D, E, lo, hi, rho, Sv, Sw, Sc, Sf, Wm, Wd, Wc, Wf, PA, Sinv, Wk, WT, x, z, y, zt, cf, pol, total;
     DEKF_HD void init(int N, int L, int ft = 0) {
         K = N;
         const int nm = 3 * L, ns = 9 + (ft ? nm : 0), b2 = ns * ns;
@@ -134,6 +135,7 @@ struct Gws {
         PA = o; o += K * b2;
         Sinv = o; o += K * b2;
         Wk = o; o += K * b2;
+        WT = o; o += ft ? 0 : K * b2;
         x = o; o += n_pad;
         z = o; o += m_pad;
         y = o; o += m_pad;

@@ -571,7 +571,10 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
         dptr xp = own ? x + M * XST + i : dummy;
         cdptr Dp = q.D + (own ? M * SV + i : 0);     // (D may sit in HBM: no LDS dummy here, idle lanes re-read D[0])
         const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0, dstep = own ? (top ? -SV : SV) : 0;
-        cdptr Wp = q.Wk + (top ? M : M - 1) * 81 + i;  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
+        // (with the factor in the slab the column comes as a ROW of the transposed copy the factorisation leaves next to W: 72
+        // contiguous bytes per lane, five loads instead of nine on the wavefront whose issue slots are the critical path)
+        constexpr bool WTB = !Q::FACTOR_LDS;
+        cdptr Wp = (WTB ? q.WT : q.Wk) + (top ? M : M - 1) * 81 + (WTB ? 9 * i : i);  // row 0: W_{M-s}', row 1: W^_{M+s-1}'
         const int wstep = top ? -81 : 81;
         cdptr Wr = Wp, Dr = Dp;
         dptr xdr = xdp, xr = xp;       // operands of the step being loaded
@@ -583,7 +586,7 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
             Dr = Dr + (adv ? dstep : 0);
             xr = xr + (adv ? xstep : 0);
 #pragma unroll
-            for (int t = 0; t < 9; ++t) o.w[t] = Wr[9 * t];
+            for (int t = 0; t < 9; ++t) o.w[t] = WTB ? Wr[t] : Wr[9 * t];
             o.ng = xdr[0];
             o.dsc = Dr[0];
             o.xo = xr[0];

@@ -205,6 +205,7 @@ struct SolveCtx {
     dptr Sf;  // FOOT: inverses of the slack blocks of the foot-position Dyn rows, [K][L][6]
     // factor-time temporaries
     dptr Wm, Wd, Wc, PA;
+    dptr WT;   // 9-state kernels with the factor in the slab: the W blocks once more, transposed (what the outward legs read); else null
     dptr Wf;  // FOOT: effective row weights of the foot-position Dyn rows
     cdptr Mp, np;
     cdptr vo;  // [wcap][4] VO flag + bound per ring slot, from the solve's input snapshot
@@ -1436,6 +1437,10 @@ DEKF_FN bool solve_factor(Q& q) {
         if (ccol) {
 #pragma unroll
             for (int t = 0; t < 9; ++t) q.Wk[kw * 81 + 9 * cidx + t] = a[t];
+            if constexpr (!W_DIRECT) {  // (the factor streams from the slab: a transposed copy for the outward legs, sweeps_one_wave_rt)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) q.WT[kw * 81 + 9 * t + cidx] = a[t];
+            }
             if constexpr (!W_DIRECT) {
 #pragma unroll
                 for (int t = 0; t < 9; ++t) two[9 * cidx + t] = a[t];
@@ -1516,6 +1521,7 @@ DEKF_FN bool solve_factor(Q& q) {
                     wave_sync();  // every read of W^_m is done
                     for (int pp = lane, n = 0; pp < 81; pp += WAVE, ++n) {
                         q.Wk[mid * 81 + pp] = P12[pp];
+                        if constexpr (!W_DIRECT) q.WT[mid * 81 + 9 * (pp % 9) + pp / 9] = P12[pp];
                         q.Sinv[(mid + 1) * 81 + pp] = p22[n];
                     }
                     wave_sync();
@@ -1723,6 +1729,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     g.init(NH, L, FT);
     SolveCtx<L, NFIX, FACTOR_LDS, FT, R3, POLISH> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
     q.xb = nullptr;
+    q.WT = nullptr;
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time.  Every array is handed out with its
         // extent (DEKF_SPAN: a plain pointer in the product builds, a checked one in the -DDEKF_BOUNDS build, wave.h)
         double* p = raw_of(lds);
@@ -1747,6 +1754,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
             p += 2 * NS * NH + lay.m_pad + 3 * NH;
             q.tmp = take(TM::LEN);
             q.Sinv = gs(g.Sinv, b2K);
+            q.WT = gs(g.WT, b2K);
             q.Wk = gs(g.Wk, b2K);
             q.Sf = nullptr; q.Wf = nullptr;
             q.x = gs(g.x, lay.n_pad);  // (the P column norms of the Ruiz passes)
@@ -1821,6 +1829,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
             q.Sv = gs(g.Sv, NH * 6 * L); q.Sw = gs(g.Sw, NH * SWS); q.Sc = gs(g.Sc, NH * 6);
             if constexpr (FT) q.Sf = gs(g.Sf, NH * 6 * L);
             q.Sinv = gs(g.Sinv, b2K); q.Wk = gs(g.Wk, b2K); q.R = gs(g.rho, lay.m_pad);  // rho slot is unused: R (9K <= m_pad)
+            if constexpr (!FT) q.WT = gs(g.WT, b2K);
             if (lay.gg_consts_in_lds()) {  // (run-time placement: these five become generic pointers in this instantiation)
                 q.D = take(lay.n_pad);
                 q.E = take(lay.m_pad);
