@@ -44,6 +44,7 @@ struct DevCfg {
     // an instruction literal; as kernel arguments they arrive in SGPRs: dt^2 / 2, the clamped initial rho, OSQP's "infinite bound"
     // threshold OSQP_INFTY * MIN_SCALING (rho_of)
     double hdt2, rho0c, inf_thr;
+    int gws_wt;  // the solver slabs carry the transposed W blocks (Gws::WT): 9-state shapes whose factor streams from the slab
     // estimator constants (DecentralEst.cpp:39-51, 236-253)
     double C_p[3], C_accel[3], C_accel_bias[3], C_gyro[3];
     double C_enc_pos[DEKF_MAX_JOINTS], C_enc_vel[DEKF_MAX_JOINTS];
@@ -107,13 +108,15 @@ struct Idx {
 struct Gws {
     // D (n) | E (m) | lo (m) | hi (m) | rho (m) | Sv (K*6L) | Sw (K*25) | Sc (K*6) | Sf (K*6L ft) |
     // Wm (K*6L) | Wd (K*24) | Wc (K*6) | Wf (K*6L ft) | PA (K*NS^2) | Sinv (K*NS^2) | Wk (K*NS^2) |
-    // WT (K*81, 9-state kernels that stream the factor from here: the W blocks once more, transposed, for the outward legs) |
     // x (n) | z (m) | y (m) | zt (m) | cf (m): the row-phase state between chunks of iterations, three-workgroup placement only |
     // pol (2 K NS + 5 m): osqp.polish — the polished point and the bounds while a refinement step solves for a correction, and
-    // the KKT residual vectors that step starts from (mhe_solve_core.h: polish_swap_in / polish_accumulate)
+    // the KKT residual vectors that step starts from (mhe_solve_core.h: polish_swap_in / polish_accumulate) |
+    // WT (K*81, LAST and only with `wt`: 9-state shapes whose factor streams from here keep the W blocks once more, transposed, for the
+    // outward legs.  Behind everything else, so that the offsets — and, for the LDS-resident shapes, the slab stride — are what they were
+    // without it: inserted in the middle it moved Go1's slabs to another stride and the dominant kernel's fetch traffic by 12 %)
     int n_pad, m_pad, K;
     int D, E, lo, hi, rho, Sv, Sw, Sc, Sf, Wm, Wd, Wc, Wf, PA, Sinv, Wk, WT, x, z, y, zt, cf, pol, total;
-    DEKF_HD void init(int N, int L, int ft = 0) {
+    DEKF_HD void init(int N, int L, int ft = 0, int wt = 0) {
         K = N;
         const int nm = 3 * L, ns = 9 + (ft ? nm : 0), b2 = ns * ns;
         n_pad = N * (2 * ns + nm + 3);
@@ -135,13 +138,13 @@ struct Gws {
         PA = o; o += K * b2;
         Sinv = o; o += K * b2;
         Wk = o; o += K * b2;
-        WT = o; o += ft ? 0 : K * b2;
         x = o; o += n_pad;
         z = o; o += m_pad;
         y = o; o += m_pad;
         zt = o; o += m_pad;
         cf = o; o += m_pad;
         pol = o; o += 2 * K * ns + 5 * m_pad;
+        WT = o; o += wt && !ft ? K * b2 : 0;
         total = o;
     }
 };

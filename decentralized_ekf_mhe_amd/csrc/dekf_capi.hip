@@ -238,6 +238,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     SolveLayout lay;
     lay.init(c.N, c.L, c.ft);
     h->lds_solve = lay.lds_bytes();
+    h->c.gws_wt = !c.ft && !lay.factor_in_lds();  // the factor streams from the slab: the outward legs read a transposed copy of W (Gws::WT)
 #ifdef DEKF_PROFILE
     // diagnostic build only: DEKF_DEBUG_LDS_PAD=<bytes> inflates the request (e.g. to force one workgroup per CU)
     if (const char* pad = getenv("DEKF_DEBUG_LDS_PAD")) h->lds_solve += (size_t)atol(pad);
@@ -271,6 +272,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             }
             // the _gg kernels carve D, E, bounds and R behind the iterates when SolveLayout::gg_consts_in_lds() says so
             if (p == 2) h->lds_solve = (size_t)(lay.vec + (lay.gg_consts_in_lds() ? lay.gg_consts() : 0)) * sizeof(double);
+            if (p == 2) h->c.gws_wt = !c.ft;
         }
 #endif
     }
@@ -345,7 +347,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
 #endif
     const int solve_slots = h->solve_kernel_full && h->solve_grid_full > h->solve_grid ? h->solve_grid_full : h->solve_grid;
     Gws g;
-    g.init(c.N, c.L, c.ft);
+    g.init(c.N, c.L, c.ft, h->c.gws_wt);
     h->gws_len = g.total;
     h->pipelined = c.est_type == 0 && p->solve_pipeline == 1;
     bool ok = true;

@@ -81,6 +81,7 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     c.marg_info = p.leg_odom_type == 1 && p.arrival_cost_form == 1;
     c.dt = 1.0 / (double)p.rate;
     c.hdt2 = 0.5 * c.dt * c.dt;
+    c.gws_wt = 0;  // (dekf_create sets it once the placement of the factor is known)
     c.inf_thr = OSQP_INFTY * MIN_SCALING;
     auto sq = [](double v) { return v * v; };
     for (int i = 0; i < 3; ++i) {
@@ -142,7 +143,7 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
     s.wp = D(12 * B); s.wpt = D(4 * B); s.wp_count = I(B);
     s.p_vo = D(3 * B); s.vo_ins_idx = I(B); s.vo_ins_dtime = I(B);
     Gws g;
-    g.init(c.N, c.L, c.ft);
+    g.init(c.N, c.L, c.ft, c.gws_wt);
     const size_t cp = (size_t)copies;
     s.gws = D(cp * solve_slots * g.total);
     s.kf_x = D(ns * B); s.kf_C = D(ns * ns * B);
@@ -154,7 +155,7 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
 inline DevState second_set(const DevCfg& c, const DevState& s, int solve_slots) {
     const size_t B = (size_t)c.B, ns = (size_t)c.ns;
     Gws g;
-    g.init(c.N, c.L, c.ft);
+    g.init(c.N, c.L, c.ft, c.gws_wt);
     DevState t = s;
     t.snap += (size_t)c.snap_len * B;
     t.gws += (size_t)solve_slots * g.total;

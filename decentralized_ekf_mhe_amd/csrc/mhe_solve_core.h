@@ -1726,7 +1726,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     SolveLayout lay;
     lay.init(NH, L, FT);
     Gws g;
-    g.init(NH, L, FT);
+    g.init(NH, L, FT, !FACTOR_LDS && !FT);  // (WT sits behind everything else: a kernel that does not use it sees the layout without it)
     SolveCtx<L, NFIX, FACTOR_LDS, FT, R3, POLISH> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
     q.xb = nullptr;
     q.WT = nullptr;
