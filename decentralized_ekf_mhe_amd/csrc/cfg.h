@@ -112,8 +112,9 @@ struct Gws {
     // pol (2 K NS + 5 m): osqp.polish — the polished point and the bounds while a refinement step solves for a correction, and
     // the KKT residual vectors that step starts from (mhe_solve_core.h: polish_swap_in / polish_accumulate) |
     // WT (K*81, LAST and only with `wt`: 9-state shapes whose factor streams from here keep the W blocks once more, transposed, for the
-    // outward legs.  Behind everything else, so that the offsets — and, for the LDS-resident shapes, the slab stride — are what they were
-    // without it: inserted in the middle it moved Go1's slabs to another stride and the dominant kernel's fetch traffic by 12 %)
+    // outward legs.  Behind everything else, so that every other offset — and, for the LDS-resident shapes, the slab itself — is what it was
+    // without it: inserted behind Wk it moved the regions after it by 13.6 KB and the dominant Go1 kernel's fetch traffic up by 12 %;
+    // padding the END of the slab does nothing of the kind, profiles/r04_slab_pad_sweep.txt)
     int n_pad, m_pad, K;
     int D, E, lo, hi, rho, Sv, Sw, Sc, Sf, Wm, Wd, Wc, Wf, PA, Sinv, Wk, WT, x, z, y, zt, cf, pol, total;
     DEKF_HD void init(int N, int L, int ft = 0, int wt = 0) {
