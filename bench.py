@@ -39,9 +39,9 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 # SURVEY.md §8(d) contract figure: algorithmic bytes per estimator-step, Go1, N = 20
 B_ALG_GO1 = 5736
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
-FP64_VECTOR_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector peak (the path computes in fp64, DESIGN.md §3)
+FP64_VECTOR_TFLOPS = 78.6  # MI355X_MICROARCH.md: fp64 vector peak (the path computes in fp64, DESIGN.md §2)
 # dependent-issue floor of one 9x9 chain step: nine v_fmac_f64_dpp, each occupying its SIMD for 16 cycles
-# (quarter-rate DPP f64), back to back on one wavefront (DESIGN.md §4.4, tools/probes/dpp_chain_probe.hip)
+# (quarter-rate DPP f64), back to back on one wavefront (DESIGN.md §4, tools/probes/dpp_chain_probe.hip)
 CHAIN_STEP_FLOOR_CYCLES = 9 * 16
 TRAFFIC_FILE = os.path.join("profiles", "traffic_k_mhe_solve.json")  # refreshed by tools/final_profiles.sh for the kernel of this round
 
@@ -78,7 +78,7 @@ def csrc_sha1():
 
 def algorithmic_flops(L, N, iters, factorizations, checks, scaling_passes=10):
     """fp64 operations (FMA = 2) one estimator-step needs in the STRUCTURED algorithm as it is implemented (slack
-    blocks eliminated, block-tridiagonal 9x9 system in the window states; DESIGN.md §4.3) — what roofline.flop_frac
+    blocks eliminated, block-tridiagonal 9x9 system in the window states; DESIGN.md §3) — what roofline.flop_frac
     prices against the fp64 vector peak.  Counted per phase:
       solve    two-sided block substitution: (K-1) forward + K (g = S^-1 f) + (K-1) outward 9x9 mat-vecs
       rows     per 3-row block: A_x x (3..30), two slack-block applies (18 / 36 each), 17 per row of updates, w (9)
@@ -304,7 +304,7 @@ def run_bench(args, env, rank, world):
         li = est.launch_info()
         cycles_per_solve = avg_solve_s * li["clock_hz"] / max(1.0, float(np.ceil(B / max(li["solve_workgroups"], 1))))
         # dependent mat-vec steps of one block-tridiagonal solve: (N - 2) / 2 forward + 1 joint middle + (N - 2) / 2 outward
-        # on each side of the two-sided solve, the two sides in lock step (DESIGN.md section 4.4)
+        # on each side of the two-sided solve, the two sides in lock step (DESIGN.md §4)
         chain_floor = mean_iters * (int(p.N) - 1) * CHAIN_STEP_FLOOR_CYCLES
         kernel = est.solve_kernel_name(True)
         traffic, traffic_src = measured_traffic(kernel, B) if (world == 1 and env.real) else (None, None)

@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(64, DEKF_ASM_WAVES) k_mhe_assemble(DevCfg c, D
 // per SIMD) caps VGPR+AGPR at 256 so that TWO workgroups stay resident per CU — LDS allows exactly
 // two, and at 260 registers the kernel silently dropped to one (2x slower).
 // DEKF_SOLVE_MIN_WAVES: wavefronts per SIMD the generic instantiations are compiled for (2 -> 256 VGPRs; the
-// residency experiment in DESIGN.md §8 builds them with 3 -> 168 VGPRs)
+// residency experiment in EXPERIMENTS.md II §4.4 builds them with 3 -> 168 VGPRs)
 #ifndef DEKF_SOLVE_MIN_WAVES
 #define DEKF_SOLVE_MIN_WAVES 2
 #endif

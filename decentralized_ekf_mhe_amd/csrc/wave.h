@@ -370,7 +370,7 @@ inline void wtiles(int ntiles, F f) {
 
 // A load of data that is read once per solve (window records, the solve's input snapshot): with the non-temporal hint the line
 // is marked for early eviction in L2 instead of pushing out the workgroup's slab lines, which are written once per factorisation
-// and read back a few times per solve — without the hint every one of them went to HBM and came back.
+// and read back a few times per solve — without the hint every one of them went to HBM and came back (EXPERIMENTS.md II §6).
 #if DEKF_DEVICE_BUILD
 template <class P>
 DEKF_FN double ld_stream(P p, int i) {

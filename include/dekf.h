@@ -118,7 +118,7 @@ typedef struct dekf_params {
                                      * EKF tick and the term construction of step T + 1 (and then its solve) start while the last
                                      * workgroups of step T's solve are still running; getters wait for the newest solve in stream
                                      * order, so results are bit-identical.  Measured on MI355X, Go1: +7 % at B = 768, +1 % at 4096,
-                                     * +2 % at 8192: it hides the 0.1 ms of EKF + assemble + launch gaps, the
+                                     * +2 % at 8192 (EXPERIMENTS.md II §7): it hides the 0.1 ms of EKF + assemble + launch gaps, the
                                      * partial last round of a launch costs nothing to begin with. */
     int solve_workgroups_per_cu;    /* 0: as many as the CU holds (3 for full Go1 / Cassie windows when the batch exceeds the 512
                                      * slots of the two-workgroup kernels); 1 or 2: cap — 2 keeps the two-workgroup solve kernels
