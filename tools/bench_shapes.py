@@ -2,7 +2,13 @@
 """Throughput of the other BASELINE.json configurations (they are parity cases, not the bench line):
 Cassie (2 legs, 5 joints) B=4096 N=20, PogoX (1 leg) B=1024 N=100, Go1 at the 8-GPU per-rank batch 8192,
 and the Kalman-filter alternative (est_type 1).
-Same loop as bench.py (device-resident synthetic logs, steady state), one JSON line per shape."""
+Same loop as bench.py (device-resident synthetic logs, steady state), one JSON line per shape; an MHE shape's line carries the
+same `roofline` block as bench.py's: SURVEY.md section 8(d)'s algorithmic bytes per estimator-step x the instances one launch of
+the solve kernel processes / that kernel's average launch time (HIP events on the handle's stream, dekf_timing_read), against the
+8 TB/s of HBM; `traffic` is quoted from profiles/traffic_<kernel>.json (tools/collect_traffic.sh <shape>) when that file was
+collected for the same kernel, batch and revision of csrc/.
+    python tools/bench_shapes.py                 every shape
+    python tools/bench_shapes.py pogox [steps]   one shape (the form tools/collect_traffic.sh and collect_sq.sh put behind rocprofv3)"""
 import json
 import os
 import sys
@@ -18,6 +24,28 @@ from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_dev
 from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
 
 
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md
+
+
+def alg_bytes_per_step(p):
+    """SURVEY.md section 8(d): inputs + outputs + EKF state and arrival cost read and written + the window ring (fp32 I/O model);
+    Go1 N = 20: 5 736, Cassie: 4 160, PogoX: 11 596"""
+    L, nj, N = int(p.num_legs), int(p.joints_per_leg), int(p.N)
+    return (80 + 16 * L * (1 + nj)) + 68 + 880 + (N + 1) * 4 * (17 + 9 * L)
+
+
+def measured_traffic(kernel, batch):
+    import bench
+    f = os.path.join(ROOT, "profiles", f"traffic_{kernel}.json")
+    try:
+        d = json.load(open(f))
+    except Exception:
+        return None, f"profiles/traffic_{kernel}.json absent"
+    if d.get("kernel") != kernel or int(d.get("batch", -1)) != int(batch) or d.get("csrc_sha1") != bench.csrc_sha1():
+        return None, f"profiles/traffic_{kernel}.json is for {d.get('kernel')} at batch {d.get('batch')}, csrc {d.get('csrc_sha1')}"
+    return d.get("hbm_bytes_per_launch"), f"profiles/traffic_{kernel}.json"
+
+
 def run(name, maker, B, steps, **kw):
     p = maker()
     p.ekf_rate = p.rate
@@ -31,6 +59,7 @@ def run(name, maker, B, steps, **kw):
         est.push_stream_step(sd, k)
         est.step(k)
     est.sync()
+    est.timing_enable(True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(W, W + steps):
@@ -39,16 +68,45 @@ def run(name, maker, B, steps, **kw):
     est.sync()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    tim = est.timing_read()
+    est.timing_enable(False)
     info = est.solver_info()
     o = est.get()
+    kernel = est.solve_kernel_name(True)
+    li = est.launch_info()
     est.close()
-    print(json.dumps({"shape": name, "legs": p.num_legs, "N": p.N, "batch": B, "steps": steps,
+    roof = None
+    if kernel and tim["solve"][1] > 0 and int(p.leg_odom_type) == 0:
+        avg_s = tim["solve"][0] / tim["solve"][1] * 1e-3
+        b_alg = alg_bytes_per_step(p)
+        traffic, src = measured_traffic(kernel, B)
+        roof = {"bound": "hbm", "achieved": b_alg * B / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": b_alg * B / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "kernel": kernel,
+                "avg_launch_ms": avg_s * 1e3, "launches": tim["solve"][1], "alg_bytes_per_step": b_alg, "units_per_launch": B,
+                "solve_workgroups": li["solve_workgroups"]}
+    elif kernel and tim["solve"][1] > 0:
+        # SURVEY 8(d) prices leg_odom_type 0 only; the foot-state variant carries 3 L more states per window step: no contract figure
+        roof = {"kernel": kernel, "avg_launch_ms": tim["solve"][0] / tim["solve"][1], "launches": tim["solve"][1],
+                "alg_bytes_per_step": None, "note": "SURVEY.md 8(d) has no byte figure for leg_odom_type 1"}
+    print(json.dumps({"shape": name, "roofline": roof, "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items()}, "legs": p.num_legs, "N": p.N, "batch": B, "steps": steps,
                       "estimator_steps_per_s": B * steps / dt, "ms_per_step": 1e3 * dt / steps,
                       "mean_iters": float(info["iters"].mean()), "solved_frac": float((o["status"] == 1).mean()),
                       "polish_accepted_frac": float((info["polish_status"] == 1).mean())}), flush=True)
 
 
+SHAPES = {  # the single-shape form (profilers put `python3 tools/bench_shapes.py <shape>` behind `--`)
+    "go1": ("go1 N=20 (bench line shape)", go1_params, 4096, 30, {}),
+    "go1_8192": ("go1 N=20, per-rank batch of the 8-GPU config", go1_params, 8192, 20, {}),
+    "cassie": ("cassie N=20", cassie_params, 4096, 30, {}),
+    "pogox": ("pogox N=100", pogox_params, 1024, 12, {}),
+    "go1foot": ("go1 with foot-position states (leg_odom_type 1, 21-dim blocks)", go1_params, 4096, 8, dict(leg_odom_type=1)),
+}
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        nm, maker, B, steps, kw = SHAPES[sys.argv[1]]
+        run(nm, maker, B, int(sys.argv[2]) if len(sys.argv) > 2 else steps, **kw)
+        sys.exit(0)
     run("go1 N=20 (bench line shape)", go1_params, 4096, 100)
     run("go1 N=20, per-rank batch of the 8-GPU config", go1_params, 8192, 60)
     run("cassie N=20", cassie_params, 4096, 100)
