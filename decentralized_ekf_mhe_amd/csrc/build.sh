@@ -34,15 +34,37 @@ else
     # on two sets without the pass ("Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base"; it compiles all of them
     # now): if that comes back, name the sets that build here ("1 2 4" are the ones with measured gains).  "none" for A/B builds.
     NO_MLICM=${DEKF_NO_MLICM:-"1 2 4 8 16 32 64 128 256 512"}
+    # Every unit is compiled with -Rpass-analysis=kernel-resource-usage: the compiler's own account of each kernel (VGPRs, spills,
+    # scratch, occupancy) goes to resource_usage.txt next to the library, and tests/test_resource_usage.py fails when a benchmark
+    # kernel leaves its design point (three workgroups per CU at <= 16 spilled VGPRs, the rows-in-registers kernel spill-free).
+    # A set whose compile dies WITH the hidden flag is retried without it (and named): the build survives a compiler that rejects
+    # the flag, and the test then says what that cost.
+    unit() {  # unit <mask> <flags...>
+        local m=$1; shift
+        if ! $HIPCC $FLAGS "$@" -Rpass-analysis=kernel-resource-usage -c -DDEKF_KSET=$m -DDEKF_KSET_ONLY -o "$T/k_$m.o" kernels.hip $EXTRA 2> "$T/ru_$m.txt"; then
+            case " $* " in *" -disable-machine-licm "*)
+                echo "build.sh: kernel set $m failed with -mllvm -disable-machine-licm, retrying without it" >&2
+                $HIPCC $FLAGS -Rpass-analysis=kernel-resource-usage -c -DDEKF_KSET=$m -DDEKF_KSET_ONLY -o "$T/k_$m.o" kernels.hip $EXTRA 2> "$T/ru_$m.txt" \
+                    && echo "set $m: compiled WITHOUT -disable-machine-licm (retry)" >> "$T/ru_notes.txt" && return 0;;
+            esac
+            grep -v "remark:" "$T/ru_$m.txt" >&2
+            return 1
+        fi
+    }
+    EXTRA="$*"
     for m in 512 256 128 64 32 16 8 4 1 2 1024; do
         X=""
         case " $NO_MLICM " in *" $m "*|*" all "*) X="-mllvm -disable-machine-licm";; esac
-        run $HIPCC $FLAGS $X -c -DDEKF_KSET=$m -DDEKF_KSET_ONLY -o "$T/k_$m.o" kernels.hip "$@"
+        run unit $m $X
     done
     run $HIPCC $FLAGS -c -o "$T/capi.o" dekf_capi.hip "$@"
     rc=0
     for p in "${pids[@]}"; do wait "$p" || rc=1; done
     [ $rc -eq 0 ] || { echo "build failed"; exit 1; }
     $HIPCC --offload-arch=gfx950 -fPIC -shared -o "$OUT" "$T"/*.o -ldl
+    # (warnings of the units, if any, to the terminal; the remarks to the file)
+    cat "$T"/ru_*.txt | grep -v "remark:\|^ *[0-9]* | \|^ *| " >&2 || true
+    { echo "# compiler resource remarks of $(basename "$OUT"), $(date -u +%Y-%m-%dT%H:%MZ), flags: $FLAGS $EXTRA; no-machine-LICM sets: $NO_MLICM";
+      cat "$T"/ru_notes.txt 2>/dev/null || true; cat "$T"/ru_*.txt | grep "remark:" | sed 's/^.*remark: *//; s/ *\[-Rpass-analysis=kernel-resource-usage\]//'; } > "${OUT%.so}_resource_usage.txt"
 fi
 echo "built $(pwd)/$OUT"

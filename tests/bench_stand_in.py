@@ -13,10 +13,11 @@ class StandInEstimator:
     def __init__(self, p, B, rank, world, comm_fails=False):
         self.B, self.rank, self.world, self.k = B, rank, world, -1
         self.comm_fails, self.comm, self.timing = comm_fails, None, False
-        self.timed_steps, self.gathers = 0, 0
+        self.timed_steps, self.gathers, self.layout_checked = 0, 0, 0
+        self.slow_rank_delay_s = 0.0  # tests: the LAST rank sleeps this long per timed step, so that the MAX over ranks is what the line reports
 
-    def vb(self):
-        inst = np.arange(self.B)[:, None] + self.rank * self.B
+    def vb(self, rank=None):
+        inst = np.arange(self.B)[:, None] + (self.rank if rank is None else rank) * self.B
         return inst * 1000.0 + self.k + np.arange(3)[None, :] * 0.25
 
     def push_stream_step(self, sd, k):
@@ -26,6 +27,9 @@ class StandInEstimator:
         assert k == self.k + 1
         self.k = k
         self.timed_steps += self.timing
+        if self.timing and self.slow_rank_delay_s and self.rank == self.world - 1:
+            import time
+            time.sleep(self.slow_rank_delay_s)
 
     def sync(self):
         pass
@@ -40,6 +44,11 @@ class StandInEstimator:
         assert self.comm == "up"
         dist.all_gather_into_tensor(out.view(self.world * self.B, 3), torch.from_numpy(self.vb()))
         self.gathers += 1
+        # the fleet's estimates as every rank must hold them: [world][B][3], rank r's shard at out[r]
+        assert tuple(out.shape) == (self.world, self.B, 3)
+        for r in range(self.world):
+            assert np.array_equal(out[r].numpy(), self.vb(r)), (self.rank, r, self.k)
+        self.layout_checked += 1
 
     def get_into(self, v_b=None):
         v_b.copy_(torch.from_numpy(self.vb()))

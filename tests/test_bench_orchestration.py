@@ -1,4 +1,4 @@
-"""bench.py's rank choreography (`run_bench`, `agree_on_gather`) on two gloo ranks, on CPU.
+"""bench.py's rank choreography (`run_bench`, `agree_on_gather`) on two, four and eight gloo ranks, on CPU.
 
 The 8-GPU runs are the driver's to launch, so the code path `bench.py --gpus N` takes for N > 1 — unique-id
 broadcast, the MIN-reduced pre-flight that decides which all-gather runs, the per-step exchange, the barrier-bracketed
@@ -13,6 +13,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -31,18 +32,26 @@ def _free_port():
     return port
 
 
-def _worker(rank, world, port, out_dir, preflight_fails_on):
+def _worker(rank, world, port, out_dir, preflight_fails_on, slow_s=0.0):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     made = []
     env = make_env(rank, rank, world, preflight_fails_on=preflight_fails_on, made=made)
     args = argparse.Namespace(gpus=world, steps=7, warmup=5, batch=6, no_cpu_baseline=True, no_allgather=False)
+    if slow_s:
+        make0 = env.make_estimator
+
+        def make_slow(p, B):
+            e = make0(p, B)
+            e.slow_rank_delay_s = slow_s
+            return e
+        env.make_estimator = make_slow
     line = bench.run_bench(args, env, rank, world)
     est = made[0]
     assert est.k == 50 + 7 - 1 and est.timed_steps == 7          # 45 fill + 5 warm-up + exactly 7 timed steps
     if preflight_fails_on is None:
-        assert est.comm == "up" and est.gathers == 57
+        assert est.comm == "up" and est.gathers == 57 and est.layout_checked == 57
     else:
         assert est.comm is None and est.gathers == 0                 # nobody entered the collective init
     assert (line is None) == (rank != 0)
@@ -53,9 +62,8 @@ def _worker(rank, world, port, out_dir, preflight_fails_on):
     dist.destroy_process_group()
 
 
-def _run(tmp_path, preflight_fails_on):
-    world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), preflight_fails_on), nprocs=world, join=True)
+def _run(tmp_path, preflight_fails_on, world=2, slow_s=0.0):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), preflight_fails_on, slow_s), nprocs=world, join=True)
     with open(tmp_path / "line.json") as fh:
         return json.load(fh)
 
@@ -74,6 +82,24 @@ def test_two_ranks_own_communicator(tmp_path):
 def test_preflight_failure_on_one_rank_moves_every_rank_to_the_fallback(tmp_path):
     d = _run(tmp_path, 1)
     assert d["config"]["allgather"] == "torch.distributed.all_gather_into_tensor"
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_four_and_eight_ranks_layout_timing_and_preflight(tmp_path, world):
+    """the 8-GPU configuration (BASELINE.json configs[3]) is the driver's to launch; its choreography runs here on gloo ranks:
+    every rank ends up with the fleet's v_b as [world][B][3] (checked inside the stand-in at every step, on every rank), the line
+    reports the MAX over ranks of the timed region (the last rank is made slow), value is the whole job's"""
+    slow = 0.02
+    d = _run(tmp_path, None, world=world, slow_s=slow)
+    assert d["n_gpus"] == world and d["config"]["global_batch"] == 6 * world and d["config"]["allgather"].startswith("dekf_allgather_vb")
+    assert d["ms_per_step"] >= 1e3 * slow                       # the slow rank's time, not rank 0's
+    assert abs(d["value"] - world * 6 * 7 / (d["ms_per_step"] * 7e-3)) / d["value"] < 1e-9
+    assert d["scaling"] == "weak" and "cpu_baseline" not in d
+
+
+def test_preflight_failure_on_the_last_of_eight_ranks_moves_all_to_the_fallback(tmp_path):
+    d = _run(tmp_path, 7, world=8)
+    assert d["n_gpus"] == 8 and d["config"]["allgather"] == "torch.distributed.all_gather_into_tensor"
 
 
 def test_flop_model_is_consistent():
