@@ -32,8 +32,10 @@ else
     # section 6); the rows-in-registers kernel of set 4 (k_mhe_solve_rr_1, 256 VGPRs) spills 40 VGPRs inside its iteration loops with
     # the pass and none without; the foot-state kernels need 205 instead of 256 VGPRs and run 2 % faster.  Mid-round, hipcc 7.2 died
     # on two sets without the pass ("Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base"; it compiles all of them
-    # now): if that comes back, name the sets that build here ("1 2 4" are the ones with measured gains).  "none" for A/B builds.
-    NO_MLICM=${DEKF_NO_MLICM:-"1 2 4 8 16 32 64 128 256 512"}
+    # now): a set that dies with the flag is retried without it below, and tests/test_resource_usage.py then says what that cost.
+    # Default: the sets with MEASURED gains — 1, 2 (three-workgroup kernels), 4 (rows in registers), 64..512 (foot-state kernels); the
+    # generic 2-4-leg sets (8, 16, 32: 179-207 VGPRs, no spills either way) keep the pass.  "none" for A/B builds, "all" for every set.
+    NO_MLICM=${DEKF_NO_MLICM:-"1 2 4 64 128 256 512"}
     # Every unit is compiled with -Rpass-analysis=kernel-resource-usage: the compiler's own account of each kernel (VGPRs, spills,
     # scratch, occupancy) goes to resource_usage.txt next to the library, and tests/test_resource_usage.py fails when a benchmark
     # kernel leaves its design point (three workgroups per CU at <= 16 spilled VGPRs, the rows-in-registers kernel spill-free).

@@ -1450,7 +1450,7 @@ DEKF_FN void row_regs_load(Q& q, int lane, double sigma, RowRegsT<KIND>& t) {
     constexpr int L = Q::LEGS, NM = 3 * L, SV = 21 + NM;
     const int K = q.K, K1 = K - 1, nmeas = K * L;
     t.valid = false; t.k = 0; t.r0 = 0; t.sv0 = 0; t.vel = false; t.meas = false; t.vo = false; t.xo = 0;
-    cdptr sp = q.Sv;  // (the slack-block inverses are stored entry-major in the slab: solve_factor 3a)
+    cdptr sp = q.Sv;  // (the slack-block inverses of the three-workgroup kernels are stored entry-major in the slab: solve_factor 3a)
     if constexpr (KIND == 0) {
         if (lane >= nmeas || lane >= 64) return;
         const int k = lane / L, leg = lane - k * L;
@@ -1797,7 +1797,7 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
 // 1.75 x.  So the three-workgroup kernels' split — a row block's state in the registers of the lane that owns it for a whole chunk
 // of iterations, LDS only for what crosses lanes, wave-specialised loops with matched barriers — at a run-time horizon:
 //   LDS    R | D | E | x blocks | xd | w (= stash of the slack x between chunks) | xs | gb | scratch       77 KB at N = 100: two per CU
-//   slab   factor (S^-1, W), slack-block inverses (entry-major), scaled bounds, stash of y and of the VO rows' z between chunks
+//   slab   factor (S^-1, W), slack-block inverses (BLOCK-major here: one base address and wide loads per block), scaled bounds, stash of y and of the VO rows' z between chunks
 //   regs   per owned block: t, slack x, y, scaled bound [, z]  (12 / 15 doubles); a lane owns up to three blocks
 // What a block needs beyond that in an iteration is re-read or rebuilt: its slack-block inverse from the slab (L2), E, D (and with
 // them rho E D and E D, the same products as at the load: same bits) and R_k from LDS.
@@ -1858,7 +1858,7 @@ DEKF_FN void rr_load(Q& q, int j, int lane, double sigma, RowStT<KIND>& st) {
         for (int a = 0; a < 3; ++a) st.z[a] = t.z[a];
     }
 }
-// the slack-block inverse of the block, from the slab (entry-major: solve_factor 3a), and what else row_regs_iter wants in registers
+// the slack-block inverse of the block, from the slab (block-major for RR: solve_factor 3a), and what else row_regs_iter wants in registers
 template <int KIND, class Q>
 DEKF_FN void rr_assemble(const Q& q, const RowStT<KIND>& st, RowRegsT<KIND>& t) {
     constexpr int L = Q::LEGS;
@@ -2017,7 +2017,7 @@ DEKF_FN void phase_sweeps_rows(Q& q, double alpha, double sigma) {
 #endif
             // With at most three tiles (one Meas tile: 2 legs) the three waiting wavefronts take them all and
             // prefetch while the solve runs; with four (Go1) the solve wavefront does the first Meas tile behind
-            // its solve, unprefetched (folding the fourth tile into another wavefront was slower: DESIGN.md §7).
+            // its solve, unprefetched (folding the fourth tile into another wavefront was slower: EXPERIMENTS.md II §7).
             constexpr bool spare = ((NF * L + 63) >> 6) + 2 * ((2 * (NF - 1) + 63) >> 6) <= 3;
             const int tile = spare ? w - 1 : w;
             if (w == 0) {

@@ -368,18 +368,14 @@ inline void wtiles(int ntiles, F f) {
 }
 #endif
 
-// A load of data that is read once per solve (window records, the solve's input snapshot): with the non-temporal hint the line
-// is marked for early eviction in L2 instead of pushing out the workgroup's slab lines, which are written once per factorisation
-// and read back a few times per solve — without the hint every one of them went to HBM and came back (EXPERIMENTS.md II §6).
+// Loads of data that is read once per solve (window records, the solve's input snapshot).  Only the RESIDUAL CHECKS' reads carry the
+// non-temporal hint (ld_stream_resid): the line is then marked for early eviction in L2 instead of pushing out the workgroup's slab
+// lines, which are written once per factorisation and read back a few times per solve — measured -6 % HBM-side traffic at the same
+// solve time.  The same hint on EVERY record read (staging included) was measured too: -3 % more traffic, +1.3 % solve time, not kept
+// (EXPERIMENTS.md II §6) — so ld_stream is a plain load; the name marks the once-per-solve reads.
 #if DEKF_DEVICE_BUILD
 template <class P>
-DEKF_FN double ld_stream(P p, int i) {
-#ifdef DEKF_NT_ALL
-    return __builtin_nontemporal_load(&p[i]);
-#else
-    return p[i];
-#endif
-}
+DEKF_FN double ld_stream(P p, int i) { return p[i]; }
 template <class P>
 DEKF_FN double ld_stream_resid(P p, int i) { return __builtin_nontemporal_load(&p[i]); }
 #else

@@ -6,6 +6,8 @@ in public members (x_MHE_, v_MHE_b_, p_vo_accmulate_, ...) as ``get()``.  All ar
 happens in csrc/libdekf.so on the GPU; arguments are numpy arrays (host) or torch CUDA
 tensors (HBM, zero-copy)."""
 import ctypes as C
+import os
+import sys
 
 import numpy as np
 
@@ -31,13 +33,18 @@ def _torch_runtime_first():
     """PyTorch-ROCm ships its own copy of the HIP runtime (torch/lib/libamdhip64.so).  If libdekf.so has already brought up the
     system's copy when torch initialises its own, torch finds no device ("No HIP GPUs are available": seen on the GPU box when a tool
     created an estimator first and uploaded tensors afterwards).  Loaded the other way round, libdekf.so binds to the runtime that is
-    already in the process.  So whoever is going to hand torch tensors to this class gets torch's runtime initialised first; without
-    torch installed this is a no-op (numpy arguments and the C / C++ callers never need it)."""
+    already in the process.  So a process that HAS imported torch — i.e. one that may hand tensors to this class — gets torch's
+    runtime initialised before libdekf.so touches a device.  A process that has not imported torch (numpy arguments, the C / C++
+    callers) is left alone: no torch import, no second HIP runtime in the address space, no seconds of start-up.  A caller that
+    imports torch only AFTER creating an estimator sets DEKF_TORCH_RUNTIME_FIRST=1 (or imports torch first)."""
+    if "torch" not in sys.modules and os.environ.get("DEKF_TORCH_RUNTIME_FIRST", "0") != "1":
+        return
     try:
         import torch
         torch.cuda.is_available()
-    except Exception:  # noqa: BLE001
-        pass
+    except Exception as e:  # noqa: BLE001
+        print(f"decentralized_ekf_mhe_amd: torch is imported but its HIP runtime did not come up ({e}); continuing with the system runtime",
+              file=sys.stderr)
 
 
 class BatchedEstimator:

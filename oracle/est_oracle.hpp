@@ -214,7 +214,7 @@ class QpBook {
                 const int n = X.r;
                 Mat Rv(n, n);
                 for (int i = 0; i < n; ++i)
-                    for (int j = 0; j < n; ++j) Rv(i, j) = X(n - 1 - (i > j ? i : j), n - 1 - (i > j ? j : i));  // lower triangle of X, reversed
+                    for (int j = 0; j < n; ++j) Rv(i, j) = X(n - 1 - (i < j ? i : j), n - 1 - (i < j ? j : i));  // LOWER triangle of X (row >= column), reversed
                 Mat Ri = spd_inverse(Rv), Xi(n, n);
                 for (int i = 0; i < n; ++i)
                     for (int j = 0; j < n; ++j) Xi(i, j) = Ri(n - 1 - i, n - 1 - j);

@@ -199,10 +199,21 @@ def foot_state_spread(p, s, x_ref, nthreads=8):
     return base, foot
 
 
-def foot_allowance(spread_foot):
-    """allowance (in units of the tolerance) for the foot-position blocks of leg_odom_type 1 against the oracle: the oracle's own
-    one-ulp spread on the same log, never below the stated tolerance, never above the 10 x that used to be a flat allowance"""
-    return min(10.0, max(1.0, spread_foot))
+FOOT_ALLOWANCE = {0: 3.0, 1: 5.0}
+
+
+def foot_allowance(form):
+    """Allowance, in units of the stated tolerance, for the foot-position blocks of leg_odom_type 1 against the oracle, by form of the
+    arrival cost (dekf_params.arrival_cost_form).  Derived from what a CONSISTENT re-evaluation of the reference formula moves
+    (test_reference_formula_spread_on_foot_states): the oracle's own saddle inverse in another pivot order, or in long double, lands
+    1.5 x the tolerance away from its natural-order result on these blocks.  Form 0 (the reference's formula, another elimination on
+    the device): twice that, 3 x — measured 0.9 x (lane-sequential build, 4 x 240 ticks), 1.83 x (GPU, 32 x 2000 ticks of a 5 Hz
+    gait, profiles/r04_type1_long_parity.jsonl).  Form 1 (information form: the same cost by another route, no 1e20 - 1e20
+    cancellation, so it does not reproduce the reference's cancellation noise): 5 x — measured 2.6 x / 3.24 x.
+    The one-ulp yardstick of round 4 (foot_state_spread: 13 x on the foot blocks) is reported, no longer used as a limit: moving
+    EVERY entry of S by one ulp at EVERY tick is a random walk no implementation performs — on the long run it puts 36 x on the BASE
+    blocks, where the device is at 0.16 x — so it bounds the formula's sensitivity from above and calibrates nothing."""
+    return FOOT_ALLOWANCE[int(form)]
 
 
 def test_reference_formula_spread_on_foot_states():
@@ -213,9 +224,10 @@ def test_reference_formula_spread_on_foot_states():
         ~1.5 x the tolerance on the foot blocks — the reference's own evaluation is the outlier of the three;
       * one unit in the last place on the entries of S: an order of magnitude more, and even the base states move by about the
         tolerance.
-    So "within 1e-4 of the reference" is not defined for the foot blocks of this variant to better than ~10 x: the reference formula
-    evaluates the information a foot regains at touch-down through a 1e20 - 1e20 = 1e6 cancellation.  The device's default form
-    reproduces the oracle to 3 x (lane-sequential build, below), i.e. well inside the formula's own spread."""
+    So "within 1e-4 of the reference" is not defined for the foot blocks of this variant to better than ~1.5 x: the reference formula
+    evaluates the information a foot regains at touch-down through a 1e20 - 1e20 = 1e6 cancellation.  The allowance on these
+    blocks (foot_allowance: 3 x for the reference form, 5 x for the information form) is tied to the pivot-order figure, not to the
+    one-ulp figure."""
     p = _params()
     B, K = 8, 400
     s = make_streams(p, B, K, gait_hz=5.0)
@@ -233,12 +245,39 @@ def test_reference_formula_spread_on_foot_states():
     ulp_base, ulp_foot = foot_state_spread(p, s, x0)
     assert ulp_foot >= 5.0, ulp_foot                                       # 13 measured: one ulp in S
     assert 0.5 <= ulp_base <= 5.0, ulp_base                                # 1.2 measured: even the base states feel it
-    assert foot_allowance(ulp_foot) == 10.0
     # the device cores (lane-sequential build), default form, against the oracle on the first four robots: inside that spread
     Bh, Kh = 4, 240
     sh = {k: (np.ascontiguousarray(v[:Kh, :Bh]) if isinstance(v, np.ndarray) and v.shape[:2] == (K, B) else v) for k, v in s.items()}
     x, it, st, vb = _hostsim(p, sh, Bh, Kh)
     assert (st[1:] == 1).all()
     dev = block_err(x[1:, :, 9:], x0[1:Kh, :Bh, 9:])
-    assert dev <= foot_allowance(ulp_foot) and dev <= ulp_foot, (dev, ulp_foot)
+    assert dev <= foot_allowance(0) and dev <= 2.0 * piv, (dev, piv, ulp_foot)   # 0.92 measured
     assert block_err(x[1:, :, :9], x0[1:Kh, :Bh, :9]) <= 1.0
+    # the information form on the same log: 2.6 measured on the foot blocks, base blocks 0.09
+    pi = _params()
+    pi.arrival_cost_form = 1
+    xi, _, sti, _ = _hostsim(pi, sh, Bh, Kh)
+    assert (sti[1:] == 1).all()
+    assert block_err(xi[1:, :, 9:], x0[1:Kh, :Bh, 9:]) <= foot_allowance(1)
+    assert block_err(xi[1:, :, :9], x0[1:Kh, :Bh, :9]) <= 1.0
+
+
+def test_spd_inverses_in_another_elimination_order_change_nothing():
+    """Test knob variants 3 and 4 (oracle/est_oracle.hpp: the SPD inverses M^-1, Q^-1, R^-1 that feed the saddle matrix run their
+    Cholesky solve in the reversed elimination order, read from the LOWER triangle of M as the reference's SimplicialLLT does;
+    4: the pivoted inverse of S reversed as well).  S then differs in its last bits only: variant 3 stays with the reference's
+    evaluation, variant 4 with the reversed-pivot one (variant 2) — and nothing diverges, which it does within three swing phases
+    when both triangles of M feed the inverse."""
+    p = _params()
+    B, K = 4, 300
+    s = make_streams(p, B, K, gait_hz=5.0)
+    runs = {}
+    for v in (0, 2, 3, 4):
+        with O.marg_inverse_variant(v):
+            runs[v], _, _, _ = O.run_streams(p, s, nthreads=4)
+        assert np.isfinite(runs[v]).all()
+    foot = lambda a, b: block_err(a[1:, :, 9:], b[1:, :, 9:])
+    base = lambda a, b: block_err(a[1:, :, :9], b[1:, :, :9])
+    assert foot(runs[3], runs[0]) <= 1.0 and base(runs[3], runs[0]) <= 0.1, (foot(runs[3], runs[0]), base(runs[3], runs[0]))
+    assert foot(runs[4], runs[2]) <= 1.0 and base(runs[4], runs[2]) <= 0.1, (foot(runs[4], runs[2]), base(runs[4], runs[2]))
+    assert foot(runs[4], runs[0]) <= 3.0       # the pivot-order figure (1.5 x), whatever feeds S

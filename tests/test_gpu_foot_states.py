@@ -59,11 +59,11 @@ def test_arrival_cost_over_many_swing_phases(form):
     Foot-position states: the reference formula evaluates the information a foot regains at touch-down through a
     1e20 - 1e20 = 1e6 cancellation (1e-2 relative noise in that block of M), so two correct implementations of it — the
     oracle and the device's default form — already differ by a few 1e-4 relative there, and so does the information form.
-    The allowance is MEASURED, not assumed: the oracle against itself on this very log with the entries of its saddle matrix
-    moved by one unit in the last place (tests/test_foot_states.py: foot_state_spread — 13 x the tolerance on the log of
-    test_reference_formula_spread_on_foot_states); the device must stay inside that spread, inside 10 x in any case, and must
-    not creep.  (tools/stress_parity.py type1-long: 32 x 2000 ticks, same rule.)"""
-    from test_foot_states import foot_allowance, foot_state_spread
+    The allowance is tied to what a consistent re-evaluation of the reference formula moves (the oracle's saddle inverse in another
+    pivot order: 1.5 x the tolerance on these blocks, tests/test_foot_states.py): 3 x for the reference form, 5 x for the information
+    form (foot_allowance); the device must not creep either.  (tools/stress_parity.py type1-long: 32 x 2000 ticks, same rule;
+    the oracle's one-ulp spread on the log is still computed and reported there, but limits nothing.)"""
+    from test_foot_states import foot_allowance
     p = _params(arrival_cost_form=form)
     B, K = 8, 320
     s = make_streams(p, B, K, gait_hz=5.0)
@@ -74,10 +74,7 @@ def test_arrival_cost_over_many_swing_phases(form):
     assert (st[1:] == 1).all()
     base, foot = _base_and_foot_err(x[1:], x_ref[1:])
     assert base.max() <= 1.0, (int(base.argmax()) + 1, base.max())
-    spread_base, spread_foot = foot_state_spread(p, s, x_ref, nthreads=16)
-    assert spread_foot >= 2.0, spread_foot           # were the reference formula ever that well conditioned here, the allowance goes
-    assert foot.max() <= foot_allowance(spread_foot), (int(foot.argmax()) + 1, foot.max(), spread_foot)
-    assert foot.max() <= spread_foot, (foot.max(), spread_foot)   # inside the formula's own one-ulp spread
+    assert foot.max() <= foot_allowance(form), (int(foot.argmax()) + 1, foot.max(), form)
     assert np.abs(vb[1:] - vb_ref[1:]).max() <= 1e-4 * np.abs(vb_ref).max() + 1e-6
     # no creep: the last quarter of the log is no worse than the first three
     assert base[3 * K // 4:].max() <= max(2.0 * base[:3 * K // 4].max(), 0.05)

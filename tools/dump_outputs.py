@@ -22,6 +22,7 @@ def diff(a, b):
 if sys.argv[1] == "--diff":
     sys.exit(diff(sys.argv[2], sys.argv[3]))
 
+import torch  # noqa: F401,E402  (torch's HIP runtime first: estimator._torch_runtime_first acts only when torch is already imported)
 from decentralized_ekf_mhe_amd import cassie_params, go1_params, pogox_params  # noqa: E402
 from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_device  # noqa: E402
 from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""PogoX with a FIXED number of ADMM iterations (no termination check before the cap, no rho adaptation): timing harness for
+"""Go1 with foot-position states (leg_odom_type 1) with a FIXED number of ADMM iterations (no termination check before the cap, no rho adaptation): timing harness for
 emulation builds whose numerics are garbage on purpose (e.g. -DDEKF_EMU_WLDS: every read of the W factor redirected to LDS).
-    DEKF_LIB=.../libdekf_x.so python tools/emu_pogox.py [iters]"""
+    DEKF_LIB=.../libdekf_x.so python tools/emu_foot.py [iters]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

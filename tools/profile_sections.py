@@ -18,6 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("DEKF_LIB", os.path.join(ROOT, "decentralized_ekf_mhe_amd", "csrc", "libdekf_prof.so"))
 
+import torch  # noqa: F401,E402  (torch's HIP runtime first: estimator._torch_runtime_first acts only when torch is already imported)
 from decentralized_ekf_mhe_amd import capi, cassie_params, go1_params, pogox_params  # noqa: E402
 from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_device  # noqa: E402
 from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402

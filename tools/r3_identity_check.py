@@ -4,6 +4,7 @@ tick and instance where states, residuals or iteration counts differ.  usage: DE
 import sys, os, numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: F401,E402  (torch's HIP runtime first: estimator._torch_runtime_first acts only when torch is already imported)
 from decentralized_ekf_mhe_amd import go1_params
 from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_device
 from decentralized_ekf_mhe_amd.streams import make_streams

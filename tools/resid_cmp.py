@@ -1,5 +1,6 @@
 import sys, os, ctypes as C, numpy as np
 sys.path.insert(0,'.'); sys.path.insert(0,'tests')
+import torch  # noqa: F401,E402  (torch's HIP runtime first: estimator._torch_runtime_first acts only when torch is already imported)
 from decentralized_ekf_mhe_amd import go1_params, capi
 from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_to_device
 from decentralized_ekf_mhe_amd.streams import make_streams

@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import oracle_lib as O  # noqa: E402
+import torch  # noqa: F401,E402  (torch's HIP runtime first: estimator._torch_runtime_first acts only when torch is already imported)
 from decentralized_ekf_mhe_amd import cassie_params, go1_params, pogox_params  # noqa: E402
 from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_host, streams_to_device  # noqa: E402
 from decentralized_ekf_mhe_amd.streams import make_streams  # noqa: E402
@@ -119,17 +120,20 @@ def case(name, maker, B, K, threads, stream_kw=None, oracle_key=None, reps=1, **
            "iteration_counts_equal_frac": float((it[1:] == it_ref[1:]).mean()),
            "mean_iters": float(it[1:].mean()), "oracle_s": round(t_cpu, 1), "gpu_s_incl_host_copies": round(t_gpu, 1)}
     # foot-position blocks (leg_odom_type 1) after touch-downs carry the reference formula's own cancellation noise.  Their allowance
-    # is measured on this very log: the oracle against itself with its saddle matrix moved by one unit in the last place
-    # (tests/test_foot_states.py: foot_state_spread / foot_allowance), 10 x at most.
+    # (tests/test_foot_states.py: foot_allowance — 3 x the tolerance for the reference form, 5 x for the information form) is tied to
+    # what another pivot order of the oracle's own saddle inverse moves (1.5 x); the oracle's one-ulp spread on this very log is
+    # computed and REPORTED next to it, it limits nothing.
     limit = 1.0
     if p.leg_odom_type == 1 and p.est_type == 0 and res["swing_phases_per_foot_min"] >= 4:
         from test_foot_states import foot_allowance, foot_state_spread
         with heartbeat(f"oracle, one-ulp variant: {name}"):
             sb, sf = foot_state_spread(p, s, x_ref, nthreads=threads)
         res["oracle_one_ulp_spread_over_tolerance"] = {"base_blocks": sb, "foot_blocks": sf}
-        limit = foot_allowance(sf)
+        limit = foot_allowance(p.arrival_cost_form)
     elif p.leg_odom_type == 1:
-        limit = 10.0   # short logs (no marginalised swing phases to speak of) and the KF mode: tests/test_foot_states.py
+        # short logs (no marginalised swing phases to speak of): the reference form's cap; the KF mode of this variant: 10 x (its
+        # covariance recursion is that ill-conditioned in the ORACLE too: tests/test_foot_states.py::test_kf_mode_*)
+        limit = 10.0 if p.est_type == 1 else 3.0
     res["foot_block_allowance_over_tolerance"] = limit
     print(json.dumps(res), flush=True)
     return (tiles_identical and res["worst_base_block_error_over_tolerance"] <= 1.0 and res["worst_block_error_over_tolerance"] <= limit and
