@@ -21,6 +21,15 @@
 // wavefront-sized tiles (wtiles): a wavefront executes one kind's straight-line body, and a row
 // block never leaves its lane, so phase R needs no LDS exchange and no barrier inside.
 #pragma once
+// ONE RESULT PER ROBOT, WHATEVER THE BATCH.  The iteration phases exist in several code shapes (row blocks in registers for a chunk of
+// iterations: three-workgroup and rows-in-registers kernels; row tiles prefetched per iteration: two-workgroup kernels; plain tile
+// loops: the generic kernels), and which shape runs depends on the batch (dekf_create).  Left to -ffp-contract=fast the compiler
+// decides per shape which product of an a b + c d it fuses, and the shapes drifted apart by an ulp per iteration (1e-8 in the states
+// after 75 iterations with VO weights of 4.4e9).  So this header is compiled with contraction OFF: a product and a sum are rounded
+// separately unless the source says fma(), and the hot expressions of the row and x-column phases say it, in the same form in every
+// shape (dot3 / fma chains below).  Measured (Go1, B = 4096, A/B on one box): contraction off without the explicit forms +5.3 % solve
+// time, with them see EXPERIMENTS.md round 5; r3 == ll bit for bit (tools/r3_identity_check.py, tests/test_gpu_configs.py).
+#pragma clang fp contract(off)
 // (no namespace block of its own: the including header is inside namespace dekf)
 
 // sum over the rows that touch x_k[a] / x_k[3+a] / x_k[6+a] of A(row, col) * w(row), w(row) already
@@ -58,7 +67,7 @@ DEKF_FN double gather_vcol(const Q& q, int k, int a, WF w) {
 #pragma unroll
         for (int leg = 0; leg < L; ++leg) g += w(q.ix.rm(k, 3 * leg + a));
     }
-    return g + (hn ? n0 + q.c.dt * n1 : 0.0) - (hp ? p0 : 0.0);
+    return g + (hn ? fma(q.c.dt, n1, n0) : 0.0) - (hp ? p0 : 0.0);
 }
 template <class Q, class WF>
 DEKF_FN double gather_bcol(const Q& q, int k, int a, WF w) {
@@ -1002,7 +1011,7 @@ DEKF_FN void row_block_compute(Q& q, int r0, int sv0, cdptr ar, const SM& S, con
 #pragma unroll
     for (int j = 0; j < NR; ++j) {
         const double sj = p.t0[j] + sl[j];       // slack solution
-        const double ztn = ar[j] - c2[j] * sj;   // (A xt)(r)
+        const double ztn = fma(-c2[j], sj, ar[j]);   // (A xt)(r)
         xn[j] = relax(alpha, sj, p.x0[j]);
         const double zh = relax(alpha, ztn, p.z0[j]);
         double rv;
@@ -1011,10 +1020,10 @@ DEKF_FN void row_block_compute(Q& q, int r0, int sv0, cdptr ar, const SM& S, con
             zn[j] = p.lo[j];
         } else {
             rv = rv_blk;
-            zn[j] = dmin(dmax(zh + rinv_blk * p.y0[j], p.lo[j]), hi[j]);
+            zn[j] = dmin(dmax(fma(rinv_blk, p.y0[j], zh), p.lo[j]), hi[j]);
         }
-        yn[j] = p.y0[j] + rv * (zh - zn[j]);
-        un[j] = rv * zn[j] - yn[j];
+        yn[j] = fma(rv, zh - zn[j], p.y0[j]);
+        un[j] = fma(rv, zn[j], -yn[j]);
         rhs[j] = lin2(sigma, xn[j], -c2[j], un[j]);
     }
     S.apply(rhs, t);
@@ -1025,7 +1034,7 @@ DEKF_FN void row_block_compute(Q& q, int r0, int sv0, cdptr ar, const SM& S, con
         q.y[r] = yn[j];
         q.z[r] = zn[j];
         q.zt[r] = t[j];
-        const double wj = p.e[j] * (un[j] + p.cf[j] * t[j]);
+        const double wj = p.e[j] * fma(p.cf[j], t[j], un[j]);
         q.at[r] = wj;
         if (wout) wout[j] = wj;
     }
@@ -1049,7 +1058,7 @@ DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma,
         const double d = q.D[sv];
         e[j] = q.E[r];
         cf[j] = rv * e[j] * d;
-        un[j] = rv * q.z[r] - q.y[r];
+        un[j] = fma(rv, q.z[r], -q.y[r]);
         rhs[j] = lin2(sigma, q.x[sv], -(e[j] * d), un[j]);
     }
     S.apply(rhs, t);
@@ -1057,7 +1066,7 @@ DEKF_FN void row_block_restart(Q& q, int r0, int sv0, const SM& S, double sigma,
     for (int j = 0; j < NR; ++j) {
         q.cf[r0 + j] = cf[j];
         q.zt[r0 + j] = t[j];
-        const double wj = e[j] * (un[j] + cf[j] * t[j]);
+        const double wj = e[j] * fma(cf[j], t[j], un[j]);
         q.at[r0 + j] = wj;
         if (wout) wout[j] = wj;
     }
@@ -1075,7 +1084,7 @@ struct SymMat {  // symmetric N x N, packed upper triangle, held in registers
         for (int i = 0; i < N; ++i) {
             double a = 0.0;
 #pragma unroll
-            for (int j = 0; j < N; ++j) a += p[i < j ? symidx(i, j, N) : symidx(j, i, N)] * in[j];
+            for (int j = 0; j < N; ++j) a = fma(p[i < j ? symidx(i, j, N) : symidx(j, i, N)], in[j], a);
             out[i] = a;
         }
     }
@@ -1093,9 +1102,9 @@ struct VoOrBiasMat {
         p[3] = vo ? s3 : s1; p[4] = vo ? s4 : 0.0; p[5] = vo ? s5 : s2;
     }
     DEKF_FN void apply(cdptr in, dptr out) const {
-        out[0] = p[0] * in[0] + p[1] * in[1] + p[2] * in[2];
-        out[1] = p[1] * in[0] + p[3] * in[1] + p[4] * in[2];
-        out[2] = p[2] * in[0] + p[4] * in[1] + p[5] * in[2];
+        out[0] = dot3(p[0], in[0], p[1], in[1], p[2], in[2]);
+        out[1] = dot3(p[1], in[0], p[3], in[1], p[4], in[2]);
+        out[2] = dot3(p[2], in[0], p[4], in[1], p[5], in[2]);
     }
 };
 
@@ -1126,9 +1135,9 @@ struct DynPairMat {
         for (int i = 0; i < 3; ++i) {
             double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc += a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)] * in[j];
+            for (int j = 0; j < 3; ++j) acc = fma(a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)], in[j], acc);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc += b[3 * i + j] * pin[j];
+            for (int j = 0; j < 3; ++j) acc = fma(b[3 * i + j], pin[j], acc);
             out[i] = acc;
         }
     }
@@ -1189,8 +1198,8 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
                 double ar[3];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const double rb = Rk[3 * a] * xk[6] + Rk[3 * a + 1] * xk[7] + Rk[3 * a + 2] * xk[8];
-                    ar[a] = E[r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[NS + o + a]);
+                    const double rb = dot3(Rk[3 * a], xk[6], Rk[3 * a + 1], xk[7], Rk[3 * a + 2], xk[8]);
+                    ar[a] = E[r0 + a] * (fma(-c2, rb, fma(c1, xk[3 + a], xk[o + a])) - xk[NS + o + a]);
                 }
                 row_block_update<3, true>(q, r0, sv0, ar, S, alpha, sigma, true, wo);
             }
@@ -1200,11 +1209,11 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
                 const double pw = pair_swap(wo[r]);
-                u[r] = vel ? hdt2 * pw + dt * wo[r] : hdt2 * wo[r] + dt * pw;
+                u[r] = vel ? fma(hdt2, pw, dt * wo[r]) : fma(hdt2, wo[r], dt * pw);
             }
             if (!vel) {
 #pragma unroll
-                for (int a = 0; a < 3; ++a) q.gb[3 * k + a] = Rk[a] * u[0] + Rk[3 + a] * u[1] + Rk[6 + a] * u[2];
+                for (int a = 0; a < 3; ++a) q.gb[3 * k + a] = dot3(Rk[a], u[0], Rk[3 + a], u[1], Rk[6 + a], u[2]);
             }
             return;
         }
@@ -1222,16 +1231,16 @@ DEKF_FN void phase_rows(Q& q, double alpha, double sigma) {
                 double ar[6];
 #pragma unroll
                 for (int a = 0; a < 3; ++a) {
-                    const double rb = R[3 * a] * xk[6] + R[3 * a + 1] * xk[7] + R[3 * a + 2] * xk[8];
-                    ar[a] = E[r0 + a] * (xk[a] + dt * xk[3 + a] - hdt2 * rb - xk[NS + a]);
-                    ar[3 + a] = E[r0 + 3 + a] * (xk[3 + a] - dt * rb - xk[NS + 3 + a]);
+                    const double rb = dot3(R[3 * a], xk[6], R[3 * a + 1], xk[7], R[3 * a + 2], xk[8]);
+                    ar[a] = E[r0 + a] * (fma(-hdt2, rb, fma(dt, xk[3 + a], xk[a])) - xk[NS + a]);
+                    ar[3 + a] = E[r0 + 3 + a] * (fma(-dt, rb, xk[3 + a]) - xk[NS + 3 + a]);
                 }
                 row_block_update<6, true>(q, r0, sv0, ar, S, alpha, sigma, true, wo);
             }
             for (int a = 0; a < 3; ++a) {
-                double g = 0.0;
-                for (int r = 0; r < 3; ++r) g += R[3 * r + a] * (hdt2 * wo[r] + dt * wo[3 + r]);
-                q.gb[3 * k + a] = g;
+                // (the lane pair's forms: u_r = fma(hdt2, w_p, dt w_v), then the three products in order)
+                const double u0 = fma(hdt2, wo[0], dt * wo[3]), u1 = fma(hdt2, wo[1], dt * wo[4]), u2 = fma(hdt2, wo[2], dt * wo[5]);
+                q.gb[3 * k + a] = dot3(R[a], u0, R[3 + a], u1, R[6 + a], u2);
             }
             return;
         }
@@ -1289,10 +1298,10 @@ struct RowTile {
         for (int i = 0; i < 3; ++i) {
             double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc += a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)] * in[j];
+            for (int j = 0; j < 3; ++j) acc = fma(a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)], in[j], acc);
             if (kind == 1) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc += b[3 * i + j] * pin[j];
+                for (int j = 0; j < 3; ++j) acc = fma(b[3 * i + j], pin[j], acc);
             }
             out[i] = acc;
         }
@@ -1357,19 +1366,19 @@ DEKF_FN void row_tile_finish(Q& q, const RowTile& t, double alpha, double sigma)
         const int o = vel ? 3 : 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double rb = Rk[3 * a] * xk[6] + Rk[3 * a + 1] * xk[7] + Rk[3 * a + 2] * xk[8];
-            ar[a] = E[t.r0 + a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+            const double rb = dot3(Rk[3 * a], xk[6], Rk[3 * a + 1], xk[7], Rk[3 * a + 2], xk[8]);
+            ar[a] = E[t.r0 + a] * (fma(-c2, rb, fma(c1, xk[3 + a], xk[o + a])) - xk[9 + o + a]);
         }
         row_block_compute<3, true>(q, t.r0, t.sv0, ar, t, t.pre, alpha, sigma, true, wo);
         double u[3];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double pw = pair_swap(wo[r]);
-            u[r] = vel ? hdt2 * pw + dt * wo[r] : hdt2 * wo[r] + dt * pw;
+            u[r] = vel ? fma(hdt2, pw, dt * wo[r]) : fma(hdt2, wo[r], dt * pw);
         }
         if (!vel) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) q.gb[3 * t.k + a] = Rk[a] * u[0] + Rk[3 + a] * u[1] + Rk[6 + a] * u[2];
+            for (int a = 0; a < 3; ++a) q.gb[3 * t.k + a] = dot3(Rk[a], u[0], Rk[3 + a], u[1], Rk[6 + a], u[2]);
         }
     } else {
         const int o = t.vo ? 0 : 6;
@@ -1427,10 +1436,10 @@ struct RowRegsT {
         for (int i = 0; i < 3; ++i) {
             double acc = 0.0;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) acc += a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)] * in[j];
+            for (int j = 0; j < 3; ++j) acc = fma(a[i < j ? symidx(i, j, 3) : symidx(j, i, 3)], in[j], acc);
             if constexpr (KIND == 1) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j) acc += b[3 * i + j] * pin[j];
+                for (int j = 0; j < 3; ++j) acc = fma(b[3 * i + j], pin[j], acc);
             }
             out[i] = acc;
         }
@@ -1527,14 +1536,14 @@ DEKF_FN void row_regs_fill(Q& q, double sigma, RowRegsT<KIND>& t, cdptr sp) {
     for (int j = 0; j < 3; ++j) {
         const double rv = KIND != 2 ? rho_eq : q.rho_of(t.lo[j], hi[j]);
         t.cf[j] = rv * t.e[j] * dd[j];
-        un[j] = rv * zz[j] - t.y[j];
+        un[j] = fma(rv, zz[j], -t.y[j]);
         rhs[j] = lin2(sigma, t.xs[j], -(t.e[j] * dd[j]), un[j]);
     }
     t.apply(rhs, tn);
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         t.t[j] = tn[j];
-        wo[j] = t.e[j] * (un[j] + t.cf[j] * tn[j]);
+        wo[j] = t.e[j] * fma(t.cf[j], tn[j], un[j]);
         q.at[t.r0 + j] = wo[j];
     }
     if constexpr (KIND == 1) {
@@ -1546,11 +1555,11 @@ DEKF_FN void row_regs_fill(Q& q, double sigma, RowRegsT<KIND>& t, cdptr sp) {
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double pw = pair_swap(wo[r]);
-            u[r] = t.vel ? hdt2 * pw + dt * wo[r] : hdt2 * wo[r] + dt * pw;
+            u[r] = t.vel ? fma(hdt2, pw, dt * wo[r]) : fma(hdt2, wo[r], dt * pw);
         }
         if (!t.vel) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) q.gb[3 * t.k + a] = R[a] * u[0] + R[3 + a] * u[1] + R[6 + a] * u[2];
+            for (int a = 0; a < 3; ++a) q.gb[3 * t.k + a] = dot3(R[a], u[0], R[3 + a], u[1], R[6 + a], u[2]);
         }
     }
 }
@@ -1581,8 +1590,8 @@ DEKF_FN void row_regs_iter(Q& q, RowRegsT<KIND>& t, double alpha, double sigma, 
         const int o = vel ? 3 : 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a) {
-            const double rb = Rk[3 * a] * xk[6] + Rk[3 * a + 1] * xk[7] + Rk[3 * a + 2] * xk[8];
-            ar[a] = t.e[a] * (xk[o + a] + c1 * xk[3 + a] - c2 * rb - xk[9 + o + a]);
+            const double rb = dot3(Rk[3 * a], xk[6], Rk[3 * a + 1], xk[7], Rk[3 * a + 2], xk[8]);
+            ar[a] = t.e[a] * (fma(-c2, rb, fma(c1, xk[3 + a], xk[o + a])) - xk[9 + o + a]);
         }
     } else if (KIND == 0 || t.meas) {
 #pragma unroll
@@ -1605,14 +1614,14 @@ DEKF_FN void row_regs_iter(Q& q, RowRegsT<KIND>& t, double alpha, double sigma, 
         if constexpr (eq) zprev = first_cold ? 0.0 : t.lo[j];
         else zprev = t.z[j];
         const double sj = t.t[j] + sl[j];
-        const double ztn = ar[j] - t.c2[j] * sj;
+        const double ztn = fma(-t.c2[j], sj, ar[j]);
         const double xn = relax(alpha, sj, t.xs[j]);
         const double zh = relax(alpha, ztn, zprev);
         double zn;
         if constexpr (eq) zn = t.lo[j];
-        else zn = dmin(dmax(zh + rinv_blk * t.y[j], t.lo[j]), t.b[j]);
-        const double yn = t.y[j] + rv_blk * (zh - zn);
-        un[j] = rv_blk * zn - yn;
+        else zn = dmin(dmax(fma(rinv_blk, t.y[j], zh), t.lo[j]), t.b[j]);
+        const double yn = fma(rv_blk, zh - zn, t.y[j]);
+        un[j] = fma(rv_blk, zn, -yn);
         rhs[j] = lin2(sigma, xn, -t.c2[j], un[j]);
         t.xs[j] = xn;
         if constexpr (!eq) t.z[j] = zn;
@@ -1622,7 +1631,7 @@ DEKF_FN void row_regs_iter(Q& q, RowRegsT<KIND>& t, double alpha, double sigma, 
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         t.t[j] = tn[j];
-        wo[j] = t.e[j] * (un[j] + t.cf[j] * tn[j]);
+        wo[j] = t.e[j] * fma(t.cf[j], tn[j], un[j]);
         q.at[t.r0 + j] = wo[j];
     }
     if constexpr (KIND == 1) {
@@ -1630,11 +1639,11 @@ DEKF_FN void row_regs_iter(Q& q, RowRegsT<KIND>& t, double alpha, double sigma, 
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const double pw = pair_swap(wo[r]);
-            u[r] = t.vel ? hdt2 * pw + dt * wo[r] : hdt2 * wo[r] + dt * pw;
+            u[r] = t.vel ? fma(hdt2, pw, dt * wo[r]) : fma(hdt2, wo[r], dt * pw);
         }
         if (!t.vel) {
 #pragma unroll
-            for (int a = 0; a < 3; ++a) q.gb[3 * t.k + a] = Rk[a] * u[0] + Rk[3 + a] * u[1] + Rk[6 + a] * u[2];
+            for (int a = 0; a < 3; ++a) q.gb[3 * t.k + a] = dot3(Rk[a], u[0], Rk[3 + a], u[1], Rk[6 + a], u[2]);
         }
     }
 }
@@ -1699,7 +1708,7 @@ DEKF_FN void xcols_regs_tile(Q& q, const XcolRegs<XKIND>& x, double sigma) {
         double gm = 0.0;
 #pragma unroll
         for (int leg = 0; leg < Q::LEGS; ++leg) gm += at[x.r[0] + 3 * leg];
-        g = gm + (x.hn ? n0 + q.c.dt * n1 : 0.0) - (x.hp ? p0 : 0.0);
+        g = gm + (x.hn ? fma(q.c.dt, n1, n0) : 0.0) - (x.hp ? p0 : 0.0);
     } else {
         const double n0 = at[x.r[0]], n1 = q.gb[x.r[1]], p0 = at[x.r[2]];
         g = (x.hn ? n0 - n1 : 0.0) - (x.hp ? p0 : 0.0);
@@ -2296,3 +2305,4 @@ DEKF_FN void residual_norms(Q& q, dptr ra, dptr va, const ResidVec* rv = nullptr
 #pragma unroll
     for (int r = 0; r < 8; ++r) va[r] = acc[6 + r];
 }
+#pragma clang fp contract(fast)  // (what follows the include in mhe_solve_core.h is shared by every kernel shape)

@@ -434,6 +434,9 @@ inline double rsqrt_fast(double x) { return 1.0 / std::sqrt(x); }
 // apart by an ulp per iteration when their row loops were restructured).
 DEKF_FN double lin2(double a, double x, double b, double y) { return fma(a, x, b * y); }
 DEKF_FN double relax(double alpha, double v, double w) { return fma(alpha, v, uni(1.0 - alpha) * w); }
+// a0 b0 + a1 b1 + a2 b2 as ONE rounded product and two fused multiply-adds, in this order: the form every shape of the row phase uses
+// (mhe_admm_core.h is compiled with contraction off, so what is not written as fma() is not fused)
+DEKF_FN double dot3(double a0, double b0, double a1, double b1, double a2, double b2) { return fma(a2, b2, fma(a1, b1, a0 * b0)); }
 DEKF_FN double dmax(double a, double b) { return a > b ? a : b; }
 DEKF_FN double dmin(double a, double b) { return a < b ? a : b; }
 

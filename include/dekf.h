@@ -121,11 +121,12 @@ typedef struct dekf_params {
                                      * +2 % at 8192 (EXPERIMENTS.md II §7): it hides the 0.1 ms of EKF + assemble + launch gaps, the
                                      * partial last round of a launch costs nothing to begin with. */
     int solve_workgroups_per_cu;    /* 0: as many as the CU holds (3 for full Go1 / Cassie windows when the batch exceeds the 512
-                                     * slots of the two-workgroup kernels); 1 or 2: cap — 2 keeps the two-workgroup solve kernels
-                                     * for full windows too.  The two kernel families run the same algorithm with the same
-                                     * iteration and rho-update counts; their states agree to about 1e-8 (1e-2 of the tolerance),
-                                     * not bit for bit — so an instance's last bits depend on whether its batch is above 512
-                                     * (tests/test_gpu_configs.py). */
+                                     * slots of the two-workgroup kernels, 2 for full PogoX windows above 256); 1 or 2: cap — 2
+                                     * keeps the two-workgroup solve kernels for full windows too.  A launch-tuning knob only: every
+                                     * kernel family produces the SAME BITS for a given robot log (since round 5 the iteration phases
+                                     * are compiled with floating-point contraction off and explicit fma; tests/test_gpu_configs.py
+                                     * holds r3 == ll, r3 == lg and rr == gg with array_equal), so a robot's estimate does not depend
+                                     * on the size of the fleet it is batched with. */
 } dekf_params;
 
 typedef struct dekf_handle_s* dekf_handle;

@@ -31,7 +31,8 @@ shape, out = sys.argv[1], sys.argv[2]
 cases = {"go1foot": (go1_params, 96, 260, dict(leg_odom_type=1)), "cassiefoot": (cassie_params, 64, 200, dict(leg_odom_type=1)),
          "pogoxfoot": (pogox_params, 32, 160, dict(leg_odom_type=1, N=30)), "go1": (go1_params, 64, 120, {}),
          "pogox": (pogox_params, 320, 128, {}), "pogox64": (pogox_params, 64, 128, {}), "cassie30": (cassie_params, 64, 70, dict(N=30)),
-         "go1n13": (go1_params, 64, 50, dict(N=13)), "go1n12": (go1_params, 64, 50, dict(N=12))}
+         "go1n13": (go1_params, 64, 50, dict(N=13)), "go1n12": (go1_params, 64, 50, dict(N=12)),
+         "go1r3": (go1_params, 832, 70, {}), "cassier3": (cassie_params, 832, 70, {})}  # batches that launch the three-workgroup kernels
 maker, B, K, kw = cases[shape]
 p = maker()
 p.ekf_rate = p.rate
