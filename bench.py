@@ -319,6 +319,8 @@ def run_bench(args, env, rank, world):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "traffic_rate_gbs": (traffic / avg_solve_s / 1e9) if traffic else None,
+                         "traffic_over_algorithmic": (traffic / (B_ALG_GO1 * B)) if traffic else None,
                          "kernel": kernel, "avg_launch_ms": avg_solve_s * 1e3, "launches": solve_n,
                          "alg_bytes_per_step": B_ALG_GO1, "units_per_launch": B,
                          # the contract's roofline is the HBM one; what actually limits this kernel is the chain of

@@ -41,7 +41,7 @@ inline void default_params(dekf_params* p) {
     set3(p->ekf_process_std, 0.1, 0.1, 0.1);
     set3(p->ekf_gravity_meas_std, 4.0, 4.0, 4.0);
     p->ekf_quaternion_init[0] = 1.0;
-    p->ekf_rate = 500; p->ekf_history = 64;
+    p->ekf_rate = 500; p->ekf_history = 256;
     p->polish_refine_iter = 3;
     p->arrival_cost_form = 0; p->solve_pipeline = 0; p->solve_workgroups_per_cu = 0;
 }

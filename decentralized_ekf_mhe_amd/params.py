@@ -87,7 +87,7 @@ def go1_params():
     _set(p.ekf_gravity_meas_std, [4.0] * 3)
     _set(p.ekf_vo_meas_std, [0.0001] * 4)
     _set(p.ekf_quaternion_init, [1.0, 0.0, 0.0, 0.0])
-    p.ekf_rate, p.ekf_history = 500, 64
+    p.ekf_rate, p.ekf_history = 500, 256
     p.polish_refine_iter = 3
     p.arrival_cost_form, p.solve_pipeline, p.solve_workgroups_per_cu = 0, 0, 0
     return p

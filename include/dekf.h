@@ -105,7 +105,8 @@ typedef struct dekf_params {
     double ekf_vo_meas_std[4];
     double ekf_quaternion_init[4];  /* w x y z */
     int ekf_rate;                   /* 500 */
-    int ekf_history;                /* depth of the rewind ring (reference: unbounded); size it as
+    int ekf_history;                /* depth of the rewind ring (reference: unbounded); default 256 = 0.5 s at 500 Hz (an ORB-SLAM3
+                                     * relocalisation stall), 55 KB per instance; size it as
                                      * ceil(worst VO pose latency * ekf_rate) + 2, INTEGRATION.md section 5 */
     int polish_refine_iter;         /* OSQP's polish_refine_iter (refinement steps of the polishing solve; OSQP default 3, the
                                      * reference does not set it).  Used when `polish` is on. */

@@ -83,7 +83,11 @@ def run(name, maker, B, steps, **kw):
         roof = {"bound": "hbm", "achieved": b_alg * B / avg_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": b_alg * B / avg_s / 1e9 / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": src, "kernel": kernel,
                 "avg_launch_ms": avg_s * 1e3, "launches": tim["solve"][1], "alg_bytes_per_step": b_alg, "units_per_launch": B,
-                "solve_workgroups": li["solve_workgroups"]}
+                "solve_workgroups": li["solve_workgroups"],
+                # what the kernel really moves beyond L2 (TCC FETCH / WRITE: Infinity-Cache hits included), as a rate: for the
+                # shapes whose factor streams from the slab every iteration THIS is the resource they run against
+                "traffic_rate_gbs": (traffic / avg_s / 1e9) if traffic else None,
+                "traffic_over_algorithmic": (traffic / (b_alg * B)) if traffic else None}
     elif kernel and tim["solve"][1] > 0:
         # SURVEY 8(d) prices leg_odom_type 0 only; the foot-state variant carries 3 L more states per window step: no contract figure
         roof = {"kernel": kernel, "avg_launch_ms": tim["solve"][0] / tim["solve"][1], "launches": tim["solve"][1],
