@@ -208,7 +208,7 @@ def foot_allowance(form):
     (test_reference_formula_spread_on_foot_states): the oracle's own saddle inverse in another pivot order, or in long double, lands
     1.5 x the tolerance away from its natural-order result on these blocks.  Form 0 (the reference's formula, another elimination on
     the device): twice that, 3 x — measured 0.9 x (lane-sequential build, 4 x 240 ticks), 1.83 x (GPU, 32 x 2000 ticks of a 5 Hz
-    gait, profiles/r04_type1_long_parity.jsonl).  Form 1 (information form: the same cost by another route, no 1e20 - 1e20
+    gait, profiles/r05_type1_long_parity.jsonl).  Form 1 (information form: the same cost by another route, no 1e20 - 1e20
     cancellation, so it does not reproduce the reference's cancellation noise): 5 x — measured 2.6 x / 3.24 x.
     The one-ulp yardstick of round 4 (foot_state_spread: 13 x on the foot blocks) is reported, no longer used as a limit: moving
     EVERY entry of S by one ulp at EVERY tick is a random walk no implementation performs — on the long run it puts 36 x on the BASE
