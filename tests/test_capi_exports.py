@@ -51,3 +51,32 @@ def test_product_does_not_reference_oracle():
             if f.endswith((".py", ".h", ".hip", ".sh", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in txt and "oracle_lib" not in txt and "libhostsim" not in txt, f
+
+
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """the boundary is a C ABI: include/dekf.h must compile as C99 (no C++ in the signatures), and a program written in C must link
+    against libdekf.so, read the defaults and be refused a handle on a box without a device — through the same entry points the
+    reference-side binding of INTEGRATION.md uses"""
+    import subprocess
+    src = tmp_path / "c_client.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <string.h>\n#include "dekf.h"\n'
+        "int main(void) {\n"
+        "    dekf_params p;\n"
+        "    dekf_handle h = 0;\n"
+        "    dekf_default_params(&p);\n"
+        '    printf("abi %d N %d legs %d rate %d ring %d\\n", dekf_abi_version(), p.N, p.num_legs, p.rate, p.ekf_history);\n'
+        "    int st = dekf_create(&p, 4, 0, 0, &h);\n"
+        '    printf("create %d handle %s\\n", st, h ? "set" : "null");\n'
+        "    if (st == 0) dekf_destroy(h);\n"
+        "    return 0;\n}\n")
+    lib_dir = os.path.join(ROOT, "decentralized_ekf_mhe_amd", "csrc")
+    exe = tmp_path / "c_client"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+                           "-L", lib_dir, "-ldekf", f"-Wl,-rpath,{lib_dir}"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "abi 3 N 20 legs 4 rate 200 ring 256" in out.stdout, out.stdout
+    import torch
+    if not torch.cuda.is_available():
+        assert f"create {capi.DEKF_ERR_NO_DEVICE} handle null" in out.stdout, out.stdout
