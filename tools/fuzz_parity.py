@@ -78,6 +78,11 @@ def draw(rng):
         #                                              stress_parity.case counts only status 1 as solved, so the fuzz keeps the cap above what these logs need)
     if rng.random() < 0.2 and shape != "go1foot":
         kw["polish"] = 1
+    if rng.random() < 0.2:
+        kw["solve_pipeline"] = 1   # device-side switch (the oracle ignores it): consecutive steps overlap, results must not change
+    if rng.random() < 0.08 and shape in ("go1", "cassie", "go1foot"):
+        kw = {k: v for k, v in kw.items() if k in ("leg_odom_type", "N", "solve_pipeline")}
+        kw["est_type"] = 1         # the Kalman-filter alternative (DecentralEst.cpp:592-861) instead of the QP
     reps = 1
     if rng.random() < 0.5:  # past the residency threshold of the shape: the three-workgroup / rows-in-registers kernels
         reps = thr // B + 1
