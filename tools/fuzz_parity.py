@@ -59,7 +59,7 @@ def draw(rng):
         maker, B, K, thr = go1_params, 16, rng.randint(50, 110), 512
         kw["leg_odom_type"] = 1
         kw["arrival_cost_form"] = rng.choice([0, 1])
-    stream_kw["gait_hz"] = rng.choice([1.0, 2.0, 2.0, 3.5, 5.0]) if shape != "go1foot" else rng.choice([1.0, 2.0])
+    stream_kw["gait_hz"] = rng.choice([0.3, 1.0, 2.0, 2.0, 3.5, 5.0, 8.0]) if shape != "go1foot" else rng.choice([1.0, 2.0])
     if rng.random() < 0.15:
         stream_kw["vo"] = False
     else:
