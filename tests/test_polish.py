@@ -205,3 +205,40 @@ def test_gpu_polish_off_is_untouched_by_the_polish_code():
             assert (info["polish_status"] != 0).all()
         est.close()
     assert np.array_equal(its[0], its[1])
+
+
+def test_a_polished_point_that_violates_its_constraints_is_never_kept():
+    """Found by tools/fuzz_parity.py (round 5, case 23.23).  Go1 with 50 Hz VO, termination checked every 10 iterations: at ticks 26
+    and 27 adaptive rho has climbed to 2e5, the regularised polishing system does not converge in its three refinement steps against
+    weights of 4.4e9, and oracle and device compute the SAME polished point: pri_res 8.6e-4 (the iterate: 1e-11), dua_res below the
+    iterate's.  OSQP's acceptance test has a clause for exactly that — `pol_dua < dua && pri < 1e-10` — and it accepts whatever the
+    polished primal residual is.  The oracle's iterate sits at pri_res 1e-6 (its generic sparse LDL' at that rho), so OSQP rejects; the
+    device's sits at 1e-11, so the clause fired and a point 0.11 off replaced an iterate at 1e-9 of the optimum.  The device now keeps a
+    polished point only inside the primal tolerance its iterate was held to (mhe_solve_core.h); here that makes it agree with the
+    oracle's decision, and x_T stays at the exact optimum of the oracle's own QP."""
+    p = go1_params()
+    p.ekf_rate = p.rate
+    p.polish, p.check_termination = 1, 10
+    B, K, inst = 24, 28, 17
+    s = make_streams(p, B, K, gait_hz=2.0, seed0=1592604737, vo_latency=0.03, vo_rate=50.0)
+    s1 = {k: (np.ascontiguousarray(v[:, inst:inst + 1]) if isinstance(v, np.ndarray) and v.ndim >= 2 and v.shape[1] == B else v) for k, v in s.items()}
+    pipe, hs = O.Pipe(p), HS.HostSim(p, 1)
+    seen_guarded_tick = False
+    for k in range(K):
+        pipe.feed(s, k, inst)
+        pipe.step(k)
+        hs.feed(s1, k)
+        hs.step(k)
+        o = hs.get()
+        if k < 24:
+            continue
+        pol = pipe.est.polish_info()
+        assert o["polish_status"][0] == pol["status"], (k, o["polish_status"][0], pol)
+        H, g, A, l, u = pipe.est.qp()
+        xt = RN.kkt_exact(H, g, A, l, u)[0][-21:-12]
+        x_or = pipe.est.solution()[-21:-12]
+        # never farther from the optimum than the reference algorithm's own result (2e-5 at the ticks where its iterate stalls at rho 2e5)
+        assert np.abs(o["x"][0] - xt).max() <= np.abs(x_or - xt).max() + 1e-9, (k, np.abs(o["x"][0] - xt).max(), np.abs(x_or - xt).max())
+        if pol["status"] == -1 and pol["pri_res"] > 1e-4 and o["pri_res"][0] < 1e-10:
+            seen_guarded_tick = True   # the polished point was bad, the device's iterate below 1e-10: OSQP's third clause would have fired
+    assert seen_guarded_tick
