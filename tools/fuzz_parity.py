@@ -78,10 +78,27 @@ def draw(rng):
         #                                              stress_parity.case counts only status 1 as solved, so the fuzz keeps the cap above what these logs need)
     if rng.random() < 0.2 and shape != "go1foot":
         kw["polish"] = 1
+    # weights and solver constants away from parameters_go1.yaml (every one of them is a ROS parameter of the reference's nodes)
+    scale = {}
+    if rng.random() < 0.35:
+        for name, choices in (("vo_p_std", [0.1, 10.0, 100.0]), ("accel_input_std", [0.3, 3.0]), ("gyro_input_std", [0.3, 3.0]),
+                              ("joint_velocity_std", [0.3, 3.0]), ("foot_slide_std", [0.3, 3.0]), ("accel_bias_std", [0.1, 10.0]),
+                              ("p_process_std", [0.1, 10.0])):
+            if rng.random() < 0.3:
+                scale[name] = rng.choice(choices)
+    if scale:
+        kw["_scale_std"] = scale
+    if rng.random() < 0.3:
+        name, val = rng.choice([("rho", 0.01), ("rho", 1.0), ("alpha", 1.0), ("alpha", 1.8), ("sigma", 1e-6), ("scaling_iters", 0), ("scaling_iters", 5),
+                                ("scaling_iters", 15), ("adaptive_rho_tolerance", 2.0), ("adaptive_rho_tolerance", 10.0), ("delta", 1e-6),
+                                ("polish_refine_iter", 1), ("polish_refine_iter", 5)])
+        kw[name] = val
     if rng.random() < 0.2:
         kw["solve_pipeline"] = 1   # device-side switch (the oracle ignores it): consecutive steps overlap, results must not change
-    if rng.random() < 0.08 and shape in ("go1", "cassie", "go1foot"):
-        kw = {k: v for k, v in kw.items() if k in ("leg_odom_type", "N", "solve_pipeline")}
+    # (the KF mode of the foot-state variant is left out: its covariance recursion is ill-conditioned in the ORACLE itself — the oracle
+    # against itself spreads 1e-3 .. 10 x the tolerance, tests/test_foot_states.py — and a recursion has no exact optimum to arbitrate with)
+    if rng.random() < 0.08 and shape in ("go1", "cassie"):
+        kw = {k: v for k, v in kw.items() if k in ("leg_odom_type", "N", "solve_pipeline", "_scale_std")}
         kw["est_type"] = 1         # the Kalman-filter alternative (DecentralEst.cpp:592-861) instead of the QP
     reps = 1
     if rng.random() < 0.5:  # past the residency threshold of the shape: the three-workgroup / rows-in-registers kernels
@@ -152,7 +169,18 @@ def main():
         if time.time() - t0 > budget:
             break
         shape, maker, B, K, reps, kw, stream_kw = draw(rng)
-        name = f"fuzz {seed}.{i} {shape} B={B}x{reps} K={K} " + json.dumps({**kw, **{('stream.' + k): v for k, v in stream_kw.items()}}, sort_keys=True)
+        scale = kw.pop("_scale_std", None)
+        if scale:
+            base = maker
+
+            def maker(base=base, scale=scale):   # the shape's parameters with some standard deviations scaled
+                q = base()
+                for fld, f in scale.items():
+                    arr = getattr(q, fld)
+                    for j in range(len(arr)):
+                        arr[j] = arr[j] * f
+                return q
+        name = f"fuzz {seed}.{i} {shape} B={B}x{reps} K={K} " + (json.dumps({"scaled": scale}, sort_keys=True) + " " if scale else "") + json.dumps({**kw, **{('stream.' + k): v for k, v in stream_kw.items()}}, sort_keys=True)
         try:
             good = SP.case(name, maker, B, K, th, stream_kw=stream_kw, reps=reps, **kw)
             r = SP.last_result
