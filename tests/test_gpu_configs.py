@@ -96,20 +96,19 @@ def test_pogox_full_batch_1024():
 
 
 # ---------------------------------------------------------------- the reference's two timers together
-def _multirate_schedule(p, B, n_mhe, seed_first=0):
+def _multirate_schedule(p, B, n_mhe, seed_first=0, **stream_kw):
     """Sensor events on a 1 ms grid: IMU + joint states every 2 ms (500 Hz, each followed by one EKF timer tick,
     orien_ekf.cpp:43), the MHE timer every 5 ms (EstSub.cpp:25, parameters_go1.yaml:33), VO as it arrives."""
     grid = p.copy()
     grid.rate = 1000
     n_grid = 5 * (n_mhe - 1) + 1
-    return make_streams(grid, B, n_grid, first_instance=seed_first), n_grid
+    return make_streams(grid, B, n_grid, first_instance=seed_first, **stream_kw), n_grid
 
 
-def test_multirate_ekf_500hz_mhe_200hz_matches_oracle():
-    p = go1_params()
-    assert (p.ekf_rate, p.rate) == (500, 200)
-    B, n_mhe = 6, 48
-    s, n_grid = _multirate_schedule(p, B, n_mhe)
+def _multirate_case(p, B, n_mhe, **stream_kw):
+    """both nodes of the reference at their own rates on one event schedule, device against the oracle; returns how many EKF ticks
+    replayed history (orien_ekf.cpp:175-205) and the worst replay depth"""
+    s, n_grid = _multirate_schedule(p, B, n_mhe, **stream_kw)
     sh = streams_host(s)
     # ---- GPU: dekf_ekf_step on every IMU sample, dekf_initialize / dekf_update on the 5 ms timer
     est = BatchedEstimator(p, B)
@@ -133,7 +132,7 @@ def test_multirate_ekf_500hz_mhe_200hz_matches_oracle():
     xs, qs, sts = np.array(xs), np.array(qs), np.array(sts)
     # ---- oracle: orien_ekf and DecentralizedEstimation restatements driven by the same events
     x_ref, q_ref = np.zeros_like(xs), np.zeros_like(qs)
-    replays = 0
+    replays, deepest = 0, 0
     for b in range(B):
         ekf, mhe = O.Ekf(p), O.Est(p)
         for i in range(n_grid):
@@ -146,6 +145,7 @@ def test_multirate_ekf_500hz_mhe_200hz_matches_oracle():
                 mhe.set_leg(s["p_foot"][i, b], s["J"][i, b], s["qdot"][i, b], s["contact"][i, b])
                 ekf.step()
                 replays += ekf.last_replay() > 0
+                deepest = max(deepest, ekf.last_replay())
                 mhe.set_quat(ekf.get()[0])
             if i % 5 == 0:
                 T = i // 5
@@ -155,10 +155,32 @@ def test_multirate_ekf_500hz_mhe_200hz_matches_oracle():
                     mhe.update(T)
                 x_ref[T, b] = mhe.get()[0]
                 q_ref[T, b] = ekf.get()[0]
-    assert replays > 0                      # VO poses did rewind the 500 Hz filter
     assert np.abs(qs - q_ref).max() < 1e-9
     assert (sts[1:] == 1).all()
     assert block_err(xs[1:], x_ref[1:]) <= 1.0
+    return replays, deepest
+
+
+def test_multirate_ekf_500hz_mhe_200hz_matches_oracle():
+    p = go1_params()
+    assert (p.ekf_rate, p.rate) == (500, 200)
+    replays, _ = _multirate_case(p, 6, 48)
+    assert replays > 0                      # VO poses did rewind the 500 Hz filter
+
+
+def test_multirate_random_vo_schedules_rewind_the_filter_like_the_oracle():
+    """the same two-rate replay over drawn VO schedules: pose rates 10 .. 50 Hz, latencies up to 150 ms (75 samples of the 500 Hz
+    filter: inside the default rewind ring of 256, far beyond the 64 it had until round 5), other stream seeds"""
+    import random
+    rng = random.Random(11)
+    p = go1_params()
+    worst, total = 0, 0
+    for _ in range(5):
+        kw = dict(vo_rate=rng.choice([10.0, 20.0, 30.0, 50.0]), vo_latency=rng.choice([0.005, 0.03, 0.08, 0.15]), seed0=0x5EED0000 + rng.randint(1, 1 << 20))
+        replays, deepest = _multirate_case(p, 4, 70, **kw)   # 0.35 s: a 10 Hz pose with 150 ms of latency arrives inside the run
+        total += replays
+        worst = max(worst, deepest)
+    assert total > 0 and worst > 64 // 2          # poses did rewind the filter, some replay deeper than half the old ring
 
 
 # ---------------------------------------------------------------- error paths
