@@ -213,9 +213,9 @@ def test_a_polished_point_that_violates_its_constraints_is_never_kept():
     weights of 4.4e9, and oracle and device compute the SAME polished point: pri_res 8.6e-4 (the iterate: 1e-11), dua_res below the
     iterate's.  OSQP's acceptance test has a clause for exactly that — `pol_dua < dua && pri < 1e-10` — and it accepts whatever the
     polished primal residual is.  The oracle's iterate sits at pri_res 1e-6 (its generic sparse LDL' at that rho), so OSQP rejects; the
-    device's sits at 1e-11, so the clause fired and a point 0.11 off replaced an iterate at 1e-9 of the optimum.  The device now keeps a
-    polished point only inside the primal tolerance its iterate was held to (mhe_solve_core.h); here that makes it agree with the
-    oracle's decision, and x_T stays at the exact optimum of the oracle's own QP."""
+    device's sits at 1e-11, so the clause fired and a point 0.11 off replaced an iterate at 1e-9 of the optimum.  The device's clause is symmetric
+    now (pol_pri < 1e-10 as well, mhe_solve_core.h); here that makes it agree with the oracle's decision, and x_T stays at the exact
+    optimum of the oracle's own QP."""
     p = go1_params()
     p.ekf_rate = p.rate
     p.polish, p.check_termination = 1, 10

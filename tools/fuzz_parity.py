@@ -30,10 +30,11 @@ import stress_parity as SP  # noqa: E402
 import oracle_lib as O  # noqa: E402
 import ref_numpy as RN  # noqa: E402
 from decentralized_ekf_mhe_amd import cassie_params, go1_params, pogox_params  # noqa: E402
+from test_gpu_parity import tripod_params, two_joint_quadruped_params  # noqa: E402  (3 legs x 6 joints; 4 legs x 2 joints)
 
 
 def draw(rng):
-    shape = rng.choice(["go1", "go1", "cassie", "pogox", "go1_short", "go1_odd", "cassie_long", "go1foot"])
+    shape = rng.choice(["go1", "go1", "cassie", "pogox", "go1_short", "go1_odd", "cassie_long", "go1foot", "tripod", "quad2j"])
     kw, stream_kw = {}, {}
     if shape == "go1":
         maker, B, K, thr = go1_params, 24, rng.randint(60, 140), 512
@@ -55,6 +56,12 @@ def draw(rng):
         maker, B, thr = cassie_params, 16, 512
         kw["N"] = rng.choice([30, 36])
         K = kw["N"] + rng.randint(20, 50)
+    elif shape == "tripod":   # the 3-leg kernel set (no BASELINE shape uses it)
+        maker, B, thr = tripod_params, 16, 512
+        kw["N"] = rng.choice([8, 12, 15, 20])
+        K = kw["N"] + rng.randint(20, 60)
+    elif shape == "quad2j":   # the fixed-horizon Go1 kernels behind another joint count in the term construction
+        maker, B, K, thr = two_joint_quadruped_params, 24, rng.randint(60, 120), 512
     else:
         maker, B, K, thr = go1_params, 16, rng.randint(50, 110), 512
         kw["leg_odom_type"] = 1
