@@ -327,8 +327,10 @@ def test_rccl_allgather_two_ranks_equals_single_rank_results(tmp_path):
     ref.close()
 
 
-@pytest.mark.parametrize("maker", [go1_params, cassie_params], ids=["go1", "cassie"])
-def test_three_workgroup_kernel_agrees_with_the_two_workgroup_kernel(maker):
+@pytest.mark.parametrize("maker,kw", [(go1_params, {}), (cassie_params, {}), (go1_params, dict(polish=1)), (cassie_params, dict(polish=1)),
+                                      (go1_params, dict(check_termination=10, adaptive_rho_interval=10)), (go1_params, dict(adapt_rho=0, max_qp_iter=150))],
+                         ids=["go1", "cassie", "go1-polish", "cassie-polish", "go1-checks-every-10", "go1-fixed-rho-capped"])
+def test_three_workgroup_kernel_agrees_with_the_two_workgroup_kernel(maker, kw):
     """ONE RESULT PER ROBOT, WHATEVER THE BATCH.  Full windows of the fixed-horizon shapes run k_mhe_solve_r3_* (three workgroups per
     CU, row state in registers, one specialised row loop per wavefront) when the batch exceeds the two-workgroup kernels' slots;
     dekf_params.solve_workgroups_per_cu = 2 keeps the two-workgroup kernel for every tick.  Same operations on the same operands, and
@@ -337,6 +339,8 @@ def test_three_workgroup_kernel_agrees_with_the_two_workgroup_kernel(maker):
     two shapes and the states differed by 1e-13 .. 1e-8.  At a batch that uses all 768 slots unevenly."""
     p = maker()
     p.ekf_rate = p.rate
+    for k_, v_ in kw.items():
+        setattr(p, k_, v_)
     B, K = 1000, p.N + 12
     sd = streams_to_device(make_streams(p, B, K))
 
@@ -347,6 +351,7 @@ def test_three_workgroup_kernel_agrees_with_the_two_workgroup_kernel(maker):
         wg = est.launch_info()["solve_workgroups"]
         assert ("_r3_" in est.solve_kernel_name(True)) == (cap == 0), est.solve_kernel_name(True)
         assert "_r3_" not in est.solve_kernel_name(False)
+        assert ("_pol" in est.solve_kernel_name(True)) == bool(p.polish)
         for k in range(K):
             est.push_stream_step(sd, k)
             est.step(k)
@@ -357,10 +362,11 @@ def test_three_workgroup_kernel_agrees_with_the_two_workgroup_kernel(maker):
     wg3, o3, i3 = run(0)
     wg2, o2, i2 = run(2)
     assert wg3 > wg2, (wg3, wg2)  # the three-workgroup kernel really was selected (more resident workgroups)
-    assert (o3["status"] == 1).all() and (o2["status"] == 1).all()
-    for key in ("quat", "x", "v_b"):
+    if "max_qp_iter" not in kw:
+        assert (o3["status"] == 1).all() and (o2["status"] == 1).all()
+    for key in ("quat", "x", "v_b", "status"):
         assert np.array_equal(o3[key], o2[key]), (key, np.abs(o3[key] - o2[key]).max())
-    for key in ("iters", "rho_updates", "pri_res", "dua_res"):
+    for key in ("iters", "rho_updates", "pri_res", "dua_res", "polish_status"):
         assert np.array_equal(i3[key], i2[key]), key
 
 
@@ -392,12 +398,14 @@ def test_three_workgroup_kernel_with_vo_rows_and_two_rho_updates():
         assert np.array_equal(i3[key], i2[key]), key
 
 
-def test_one_legged_long_window_kernels_agree_bit_for_bit():
+@pytest.mark.parametrize("polish", [0, 1], ids=["plain", "polish"])
+def test_one_legged_long_window_kernels_agree_bit_for_bit(polish):
     """PogoX (N = 100): batches above the generic kernel's 256 slots run full windows on k_mhe_solve_rr_1 (rows in registers at a
     run-time horizon, compact x blocks), smaller ones on k_mhe_solve_gg_1 (tile loops over LDS-resident iterates).  The same 24 logs
     as a batch of 24 and tiled to 288: the first tile must carry the bits of the small batch."""
     p = pogox_params()
     p.ekf_rate = p.rate
+    p.polish = polish
     D, reps, K = 24, 12, p.N + 6
     s = make_streams(p, D, K)
     tiled = {k: (np.ascontiguousarray(np.tile(v, (1, reps) + (1,) * (v.ndim - 2))) if isinstance(v, np.ndarray) else v) for k, v in s.items()}
@@ -416,7 +424,7 @@ def test_one_legged_long_window_kernels_agree_bit_for_bit():
     assert (o1["status"] == 1).all() and (o2["status"] == 1).all()
     for key in ("x", "v_b", "quat"):
         assert np.array_equal(o1[key], o2[key][:D]), (key, np.abs(o1[key] - o2[key][:D]).max())
-    for key in ("iters", "rho_updates", "pri_res", "dua_res"):
+    for key in ("iters", "rho_updates", "pri_res", "dua_res", "polish_status"):
         assert np.array_equal(i1[key], i2[key][:D]), key
 
 
