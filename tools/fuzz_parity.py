@@ -112,6 +112,8 @@ def draw(rng):
     if rng.random() < 0.08 and shape in ("go1", "cassie"):
         kw = {k: v for k, v in kw.items() if k in ("leg_odom_type", "N", "solve_pipeline", "_scale_std")}
         kw["est_type"] = 1         # the Kalman-filter alternative (DecentralEst.cpp:592-861) instead of the QP
+    if rng.random() < 0.1 and shape != "pogox":
+        K *= 4      # a long log now and then: several marginalised windows, many VO intervals, drift would show
     reps = 1
     if rng.random() < 0.5:  # past the residency threshold of the shape: the three-workgroup / rows-in-registers kernels
         reps = thr // B + 1
