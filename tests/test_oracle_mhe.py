@@ -232,6 +232,40 @@ def test_marginalised_window_equals_the_never_marginalised_problem_with_vo():
     assert dropped_with_vo > 10     # steps WITH active VO rows were folded into the arrival cost (24-dim branch)
 
 
+def test_marginalised_window_equals_the_full_problem_over_drawn_robots_and_vo_schedules():
+    """The same pin as above (the oracle's marginalised window against the never-marginalised problem that ref_numpy builds with its own
+    term construction, VO sync, Bezier bounds and block layout), over DRAWN configurations: Go1 / Cassie / PogoX at several horizons, VO at
+    10 .. 50 Hz with 0 .. 120 ms of latency, gaits of 1 .. 5 Hz — the regimes tools/fuzz_parity.py takes the device through.  Both optima
+    are exact (dense KKT), so they agree to rounding: 2e-12 measured, whatever the schedule."""
+    import random
+    from decentralized_ekf_mhe_amd import cassie_params, pogox_params
+    rng = random.Random(3)
+    with_vo = 0
+    for _ in range(8):
+        maker, N = rng.choice([(go1_params, 10), (go1_params, 20), (cassie_params, 12), (pogox_params, 16)])
+        p = maker()
+        p.ekf_rate = p.rate
+        p.N = N
+        skw = dict(vo_rate=rng.choice([10.0, 20.0, 30.0, 50.0]), vo_latency=rng.choice([0.0, 0.01, 0.03, 0.06, 0.12]),
+                   gait_hz=rng.choice([1.0, 2.0, 3.5, 5.0]), seed0=0x5EED0000 + rng.randint(1, 1 << 20))
+        nsteps = N + 26
+        s = make_streams(p, 1, nsteps, **skw)
+        want = (N + 4, N + 13, N + 25)
+        qps = {}
+        pipe, quats = _run(p, s, 0, nsteps, lambda k, pp: qps.__setitem__(k, pp.est.qp()) if k in want else None)
+        nm = 3 * p.num_legs
+        for T in want:
+            H, g, A, l, u = qps[T]
+            x_win, _ = RN.kkt_exact(H, g, A, l, u)
+            (H2, g2, A2, l2, u2), track = RN.window_qp(p, s, 0, quats, T, vo=True, return_track=True)
+            x_full, _ = RN.kkt_exact(H2, g2, A2, l2, u2)
+            a, r = x_win[-(9 + nm):-nm], x_full[-(9 + nm):-nm]
+            for blk in (slice(0, 3), slice(3, 6), slice(6, 9)):
+                assert relerr(a[blk], r[blk]) < 1e-9, (maker.__name__, N, skw, T, blk, relerr(a[blk], r[blk]))
+        with_vo += len(track.bounds) > 0
+    assert with_vo >= 3      # VO equalities were active in several of the draws
+
+
 def test_bezier_ka5():
     """KA5: the curve starts at the first and ends at the last of its four control points, only the last four way
     points count, and the node differences UpdateVOConstraints consumes add up to last node - first node."""
