@@ -37,6 +37,8 @@ def alg_bytes_per_step(p):
 def measured_traffic(kernel, batch):
     import bench
     f = os.path.join(ROOT, "profiles", f"traffic_{kernel}.json")
+    if not os.path.exists(f):  # (the bench line's kernel: tools/collect_traffic.sh without a shape writes traffic_k_mhe_solve.json)
+        f = os.path.join(ROOT, "profiles", "traffic_k_mhe_solve.json")
     try:
         d = json.load(open(f))
     except Exception:
@@ -90,8 +92,11 @@ def run(name, maker, B, steps, **kw):
                 "traffic_over_algorithmic": (traffic / (b_alg * B)) if traffic else None}
     elif kernel and tim["solve"][1] > 0:
         # SURVEY 8(d) prices leg_odom_type 0 only; the foot-state variant carries 3 L more states per window step: no contract figure
-        roof = {"kernel": kernel, "avg_launch_ms": tim["solve"][0] / tim["solve"][1], "launches": tim["solve"][1],
-                "alg_bytes_per_step": None, "note": "SURVEY.md 8(d) has no byte figure for leg_odom_type 1"}
+        avg_s = tim["solve"][0] / tim["solve"][1] * 1e-3
+        traffic, src = measured_traffic(kernel, B)
+        roof = {"kernel": kernel, "avg_launch_ms": avg_s * 1e3, "launches": tim["solve"][1],
+                "alg_bytes_per_step": None, "note": "SURVEY.md 8(d) has no byte figure for leg_odom_type 1",
+                "traffic": traffic, "traffic_source": src, "traffic_rate_gbs": (traffic / avg_s / 1e9) if traffic else None}
     print(json.dumps({"shape": name, "roofline": roof, "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items()}, "legs": p.num_legs, "N": p.N, "batch": B, "steps": steps,
                       "estimator_steps_per_s": B * steps / dt, "ms_per_step": 1e3 * dt / steps,
                       "mean_iters": float(info["iters"].mean()), "solved_frac": float((o["status"] == 1).mean()),
@@ -101,6 +106,7 @@ def run(name, maker, B, steps, **kw):
 SHAPES = {  # the single-shape form (profilers put `python3 tools/bench_shapes.py <shape>` behind `--`)
     "go1": ("go1 N=20 (bench line shape)", go1_params, 4096, 30, {}),
     "go1_8192": ("go1 N=20, per-rank batch of the 8-GPU config", go1_params, 8192, 20, {}),
+    "go1_65536": ("go1 N=20, the WHOLE batch of the 8-GPU config (65 536) on one GPU", go1_params, 65536, 10, {}),
     "cassie": ("cassie N=20", cassie_params, 4096, 30, {}),
     "pogox": ("pogox N=100", pogox_params, 1024, 12, {}),
     "go1foot": ("go1 with foot-position states (leg_odom_type 1, 21-dim blocks)", go1_params, 4096, 8, dict(leg_odom_type=1)),
@@ -113,6 +119,7 @@ if __name__ == "__main__":
         sys.exit(0)
     run("go1 N=20 (bench line shape)", go1_params, 4096, 100)
     run("go1 N=20, per-rank batch of the 8-GPU config", go1_params, 8192, 60)
+    run("go1 N=20, the WHOLE batch of the 8-GPU config (65 536) on one GPU", go1_params, 65536, 20)
     run("cassie N=20", cassie_params, 4096, 100)
     run("pogox N=100", pogox_params, 1024, 60)
     run("go1 N=20 with osqp.polish (the node's declared default; k_mhe_solve_r3_4_n20_pol)", go1_params, 4096, 100, polish=1)
