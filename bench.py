@@ -263,9 +263,17 @@ def run_bench(args, env, rank, world):
                 dist.all_gather_into_tensor(vb_all.view(world * B, 3), vb_mine)
 
     run(0, fill)      # window fill that the requested warm-up does not cover (0 with the defaults)
-    run(fill, fill + W)
+    # Kernel times by HIP events on the handle's stream.  An event pair costs the stream about 7 us (measured: 1.955 against 1.934 ms
+    # per step with six pairs on / off), so the TIMED region brackets only the dominant kernel — the MHE solve, what roofline.achieved
+    # is priced on — and the small kernels (EKF tick, term construction) are timed over the last warm-up steps instead.
+    w_all = min(W, 20)
+    run(fill, fill + W - w_all)
     est.sync()
-    est.timing_enable(True)
+    est.timing_enable(1)
+    run(fill + W - w_all, fill + W)
+    est.sync()
+    tim_warm = est.timing_read()
+    est.timing_enable(2)
     if world > 1:
         dist.barrier()
     env.device_sync()
@@ -278,6 +286,9 @@ def run_bench(args, env, rank, world):
     elapsed = time.perf_counter() - t0
     tim = est.timing_read()
     est.timing_enable(False)
+    for cls in ("ekf", "assemble"):   # (not bracketed in the timed region: the warm-up's figures)
+        if tim[cls][1] == 0:
+            tim[cls] = tim_warm[cls]
 
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=env.device)

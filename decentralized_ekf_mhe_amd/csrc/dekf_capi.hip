@@ -83,8 +83,8 @@ struct dekf_handle_s {
     size_t lds_solve = 0, lds_asm = 0, lds_kf = 0;
     int ekf_count = 0, pushes = 0, next_T = 0;
     bool initialized = false;
-    // timing
-    bool timing = false;
+    // timing: 0 off, 1 every kernel class, 2 only the MHE solve (class 2)
+    int timing = 0;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DEKF_TIMING_CLASSES];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     // Step pipelining (dekf_params.solve_pipeline): the solve of step T runs on solve_stream[T & 1] out of set T & 1 of the
@@ -179,7 +179,7 @@ struct Timed {  // brackets one launch with events when timing is on
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
     Timed(dekf_handle h_, int cls_, hipStream_t st_ = nullptr) : h(h_), cls(cls_), st(st_ ? st_ : h_->stream) {
-        if (!h->timing) return;
+        if (!h->timing || (h->timing == 2 && cls != 2)) return;
         if (!h->ev_pool.empty()) { a = h->ev_pool.back().first; b = h->ev_pool.back().second; h->ev_pool.pop_back(); }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
             if (a) (void)hipEventDestroy(a);
@@ -664,7 +664,7 @@ dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where) {
 
 dekf_status dekf_timing_enable(dekf_handle h, int on) {
     if (!h) return fail(DEKF_ERR_INVALID, "null handle");
-    h->timing = on != 0;
+    h->timing = on == 2 ? 2 : (on != 0 ? 1 : 0);
     // events are created here, not inside the timed region: enough pairs for a few hundred steps of three launches
     if (h->timing) {
         size_t have = h->ev_pool.size();

@@ -170,6 +170,7 @@ class BatchedEstimator:
 
     # ---- measurement ------------------------------------------------------------------
     def timing_enable(self, on=True):
+        """True / 1: HIP events around every kernel launch; 2: around the MHE solve launches only (an event pair costs the stream ~7 us)"""
         capi.check(self.lib.dekf_timing_enable(self.h, int(on)))
 
     def timing_read(self):

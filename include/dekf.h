@@ -222,8 +222,9 @@ dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where);
 #define DEKF_SOLVE_NUMERIC -1   /* non-finite value or zero pivot */
 
 /* ---- measurement (the reference's tic/toc helpers, DecentralEst.cpp:1031-1044) ------- */
-/* When enabled, every kernel launch of the hot path is bracketed by HIP events on the
- * handle's stream.  dekf_timing_read synchronises and returns, per kernel class
+/* on = 1: every kernel launch of the hot path is bracketed by HIP events on the handle's stream; on = 2: only the
+ * MHE solve launches (class 2) — an event pair costs the stream about 7 us, six of them per step are 1 % of a
+ * 2 ms step, so a throughput measurement that only needs the dominant kernel's launch time asks for 2; on = 0: off.  dekf_timing_read synchronises and returns, per kernel class
  * (0 ekf tick, 1 MHE assemble/marginalise [or KF update], 2 MHE ADMM solve), the summed
  * device milliseconds and the number of launches since the last read. */
 #define DEKF_TIMING_CLASSES 3
