@@ -159,6 +159,36 @@ def cpu_baseline(params, total_steps, seed_first, gpu_x_final=None):
     return out
 
 
+def pipelined_leg(env, p, B, sd, total, K):
+    """The same K steps with dekf_params.solve_pipeline = 1 (the solve of step T on a second stream out
+    of its own set of buffers, so that the pushes, the EKF tick, the term construction and the solve of step T + 1 start under its
+    last round; results bit-identical, tests/test_gpu_configs.py).  Reported NEXT TO `value`, never as it: consecutive solve
+    launches overlap in this mode, so a launch duration — what `roofline` is priced on — is no longer the cost of a launch, and
+    a caller that needs step T's estimate before it can produce step T + 1's samples (closed loop) cannot use it."""
+    p2 = p.copy()
+    p2.solve_pipeline = 1
+    est = env.make_estimator(p2, B)
+    try:
+        for k in range(total - K):
+            est.push_stream_step(sd, k)
+            est.step(k)
+        est.sync()
+        env.device_sync()
+        t0 = time.perf_counter()
+        for k in range(total - K, total):
+            est.push_stream_step(sd, k)
+            est.step(k)
+        est.sync()
+        env.device_sync()
+        dt = time.perf_counter() - t0
+        solved = float((est.get()["status"] == 1).mean())
+    finally:
+        est.close()
+    return {"value": B * K / dt, "unit": "estimator-steps/s", "ms_per_step": dt / K * 1e3, "steps": K, "solved_frac": solved,
+            "what": "dekf_params.solve_pipeline = 1: consecutive steps overlap on two streams (same results bit for bit); "
+                    "open-loop replay only, so it is reported beside `value`, not as it"}
+
+
 def default_batch(gpus):
     """instances per GPU when --batch is not given: configs[1] at one GPU; at N > 1 the per-rank share of configs[3]
     (65 536 over 8 GPUs), so that the driver's plain `bench.py --gpus 8` IS that configuration"""
@@ -359,6 +389,8 @@ def run_bench(args, env, rank, world):
                 line["solver"]["max_rel_err_vs_oracle"] = err["max_rel_err"]
                 line["solver"]["error_vs_oracle"] = err
     est.close()
+    if line is not None and world == 1 and env.real and not getattr(args, "pipeline", False) and not getattr(args, "no_pipelined_leg", False):
+        line["with_step_pipelining"] = pipelined_leg(env, p, B, sd, total, K)
     return line
 
 
@@ -393,6 +425,8 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=None, help="instances per GPU (default 4096 at --gpus 1, else 8192)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-allgather", action="store_true")
+    ap.add_argument("--no-pipelined-leg", action="store_true", help="skip the extra K steps with solve_pipeline = 1 (N = 1 only; "
+                    "reported as with_step_pipelining beside value)")
     ap.add_argument("--pipeline", action="store_true", help="dekf_params.solve_pipeline = 1: consecutive steps overlap (A/B; the launch "
                     "durations the roofline is priced on then overlap too, so the default keeps the steps in order)")
     # test hook (tests/test_bench_orchestration.py): "module:function" returning a BenchEnv for (rank, local_rank, world);

@@ -94,7 +94,7 @@ struct dekf_handle_s {
     bool pipelined = false;
     DevState sp[2];               // sp[0] == s; sp[1]: the second set
     hipStream_t solve_stream[2] = {nullptr, nullptr};
-    hipEvent_t ev_asm[2] = {nullptr, nullptr}, ev_solve[2] = {nullptr, nullptr};
+    hipEvent_t ev_asm[2] = {nullptr, nullptr}, ev_solve[2] = {nullptr, nullptr}, ev_mark[2] = {nullptr, nullptr};
     bool solve_pending[2] = {false, false};
     int last_par = 0;             // set the newest results are in
     // RCCL: the all-gather runs on its own stream out of a snapshot of v_b, so that it overlaps the next step
@@ -366,10 +366,18 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     h->sp[0] = h->s;
     h->sp[1] = h->pipelined ? second_set(h->c, h->s, solve_slots) : h->s;
     if (h->pipelined) {
+        // The two solve streams are created at the greatest stream priority: HIP maps streams round-robin onto a few hardware queues
+        // PER PRIORITY CLASS (GPU_MAX_HW_QUEUES, default 4), and a stream-wait is a barrier packet that holds its whole queue — with
+        // one more normal-priority stream alive in the process (another handle, idle) a solve stream shared a queue with the handle's
+        // own stream and the mode ran at 1.34 M instead of 2.1 M steps/s (profiles/r05_step_pipelining_queues.txt).  In their own
+        // class they share queues with nothing the caller creates by default.
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
         for (int i = 0; i < 2 && ok; ++i) {
-            ok = hipStreamCreateWithFlags(&h->solve_stream[i], hipStreamNonBlocking) == hipSuccess &&
+            ok = hipStreamCreateWithPriority(&h->solve_stream[i], hipStreamNonBlocking, prio_greatest) == hipSuccess &&
                  hipEventCreateWithFlags(&h->ev_asm[i], hipEventDisableTiming) == hipSuccess &&
-                 hipEventCreateWithFlags(&h->ev_solve[i], hipEventDisableTiming) == hipSuccess;
+                 hipEventCreateWithFlags(&h->ev_solve[i], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreate(&h->ev_mark[i]) == hipSuccess;
         }
         if (!ok) {
             dekf_destroy(h);
@@ -396,6 +404,7 @@ dekf_status dekf_destroy(dekf_handle h) {
         if (h->solve_stream[i]) { (void)hipStreamSynchronize(h->solve_stream[i]); (void)hipStreamDestroy(h->solve_stream[i]); }
         if (h->ev_asm[i]) (void)hipEventDestroy(h->ev_asm[i]);
         if (h->ev_solve[i]) (void)hipEventDestroy(h->ev_solve[i]);
+        if (h->ev_mark[i]) (void)hipEventDestroy(h->ev_mark[i]);
     }
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) rccl_destroy(h->comm);
@@ -565,6 +574,11 @@ dekf_status dekf_update(dekf_handle h, int T) {
             HIPCHK(hipStreamWaitEvent(ss, h->ev_asm[par], 0));
             // an all-gather in flight still reads this set's v_b until its snapshot copy is through (dekf_allgather_vb)
             if (h->ag_pending) HIPCHK(hipStreamWaitEvent(ss, h->ev_vb_ready, 0));
+            // A recorded event between the stream-waits and the launch: measured, not understood.  Without it the solve of step
+            // T + 1 does not start under the last round of step T's solve and the mode gains nothing (2.09 M steps/s, Go1 at 4096);
+            // with it the two overlap (2.16 M).  Found because bench.py's timing events had the same effect; an event recorded only
+            // AFTER the launch does not (profiles/r05_step_pipelining_queues.txt).
+            HIPCHK(hipEventRecord(h->ev_mark[par], ss));
         }
         int kstart = T - h->c.N + 1 > 0 ? T - h->c.N + 1 : 0;
         {

@@ -32,6 +32,10 @@ def test_bench_line_has_the_contract_fields():
     assert d["value"] > 0 and d["solver"]["solved_frac"] == 1.0
     # value = instances x steps / elapsed
     assert abs(d["value"] - 256 * 8 / (d["ms_per_step"] * 8e-3)) / d["value"] < 1e-6
+    # the overlapped-steps figure rides beside value (same K steps, solve_pipeline = 1), never in its place
+    wp = d["with_step_pipelining"]
+    assert wp["steps"] == 8 and wp["solved_frac"] == 1.0 and wp["value"] > 0
+    assert abs(wp["value"] - 256 * 8 / (wp["ms_per_step"] * 8e-3)) / wp["value"] < 1e-6
 
 
 @pytest.mark.gpu
