@@ -33,7 +33,7 @@ struct DevCfg {
     int ns;               // dim_state = 9 + 3 L ft (DecentralEst.cpp:20)
     int SV, SC;           // per-step variable / row block: 2 ns + nm + 3, nm + ns + 3
     int ring;             // 4N+1 stack entries
-    int wcap;             // N+1 window records
+    int wcap;             // window records: N + 1 (N + 2 for a pipelined handle)
     int rec;              // doubles per window record
     int snap_len;         // doubles per instance of the solve's input snapshot: M_p (ns^2) | n_p (ns) | VO flag + bound of every ring slot (4 wcap)
     int est_type;
@@ -165,8 +165,9 @@ struct DevState {
     int* st_dtime;
     double *rec, *Mp, *np_;
     // What a solve reads of the state the NEXT step's assemble overwrites (arrival cost, VO flags / bounds of the window), copied
-    // by k_mhe_assemble at its end: [B][snap_len].  Two copies exist (by parity of T, as for the outputs and the solver scratch),
-    // so that step T + 1's EKF tick and assemble can run under the tail of step T's solve (dekf_capi.hip: dekf_update).
+    // by k_mhe_assemble at its end: [B][snap_len].  A pipelined handle has three copies (by T mod 3; outputs and solver scratch: two,
+    // by parity of T), so that the EKF tick and the assemble of step T + 1 — and of step T + 2 — can run while step T's solve is
+    // still waiting for, or holding, the machine (dekf_capi.hip: dekf_update).
     double* snap;
     double *wp, *wpt;
     int* wp_count;

@@ -88,13 +88,16 @@ struct dekf_handle_s {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[DEKF_TIMING_CLASSES];
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_pool;
     // Step pipelining (dekf_params.solve_pipeline): the solve of step T runs on solve_stream[T & 1] out of set T & 1 of the
-    // per-solve data (input snapshot, outputs, scratch slabs), so the pushes, the EKF tick and the assemble of step T + 1 — and
-    // then its solve — start while the last round of step T's persistent workgroups is still running (a launch of B instances
-    // on S slots runs ceil(B / S) rounds, the last one partly empty: 4096 on 768 is 5.33).
+    // per-solve data (outputs, scratch slabs) and copy T mod 3 of its input snapshot, so the pushes, the EKF tick and the
+    // assemble of step T + 1 — and then its solve — start while the last round of step T's persistent workgroups is still
+    // running (a launch of B instances on S slots runs ceil(B / S) rounds, the last one partly empty: 4096 on 768 is 5.33).
     bool pipelined = false;
     DevState sp[2];               // sp[0] == s; sp[1]: the second set
     hipStream_t solve_stream[2] = {nullptr, nullptr};
     hipEvent_t ev_asm[2] = {nullptr, nullptr}, ev_solve[2] = {nullptr, nullptr}, ev_mark[2] = {nullptr, nullptr};
+    // input snapshots by T mod 3: ev_snap_free[i] is recorded behind the solve that read copy i, the assemble of three steps on waits for it
+    hipEvent_t ev_snap_free[3] = {nullptr, nullptr, nullptr};
+    bool snap_busy[3] = {false, false, false};
     bool solve_pending[2] = {false, false};
     int last_par = 0;             // set the newest results are in
     // RCCL: the all-gather runs on its own stream out of a snapshot of v_b, so that it overlaps the next step
@@ -102,6 +105,10 @@ struct dekf_handle_s {
     int world = 1, rank = 0;
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_vb_ready = nullptr, ev_ag_done = nullptr;
+    // pipelined mode: recorded when the all-gather's snapshot copy has READ set i's v_b — what the next solve into set i waits for
+    // (one event per set: the solve of step T + 1 must not wait for the copy that follows the solve of step T, or nothing overlaps)
+    hipEvent_t ev_vb_read[2] = {nullptr, nullptr};
+    bool vb_read_pending[2] = {false, false};
     double* vb_snapshot = nullptr;
     bool ag_pending = false;
 };
@@ -379,6 +386,7 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
                  hipEventCreateWithFlags(&h->ev_solve[i], hipEventDisableTiming) == hipSuccess &&
                  hipEventCreate(&h->ev_mark[i]) == hipSuccess;
         }
+        for (int i = 0; i < DEKF_SNAP_SETS && ok; ++i) ok = hipEventCreateWithFlags(&h->ev_snap_free[i], hipEventDisableTiming) == hipSuccess;
         if (!ok) {
             dekf_destroy(h);
             return fail(DEKF_ERR_HIP, "could not create the solve streams");
@@ -406,10 +414,12 @@ dekf_status dekf_destroy(dekf_handle h) {
         if (h->ev_solve[i]) (void)hipEventDestroy(h->ev_solve[i]);
         if (h->ev_mark[i]) (void)hipEventDestroy(h->ev_mark[i]);
     }
+    for (int i = 0; i < DEKF_SNAP_SETS; ++i) if (h->ev_snap_free[i]) (void)hipEventDestroy(h->ev_snap_free[i]);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) rccl_destroy(h->comm);
     if (h->ev_vb_ready) (void)hipEventDestroy(h->ev_vb_ready);
     if (h->ev_ag_done) (void)hipEventDestroy(h->ev_ag_done);
+    for (int i = 0; i < 2; ++i) if (h->ev_vb_read[i]) (void)hipEventDestroy(h->ev_vb_read[i]);
     if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
     if (h->vb_snapshot) (void)hipFree(h->vb_snapshot);
     for (auto& v : h->ev) for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
@@ -426,6 +436,9 @@ dekf_status dekf_reset(dekf_handle h) {
     HIPCHK(hipSetDevice(h->device));
     for (int i = 0; i < 2; ++i)   // a solve still in flight writes the outputs this clears
         if (h->solve_pending[i]) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_solve[i], 0)); h->solve_pending[i] = false; }
+    for (int i = 0; i < DEKF_SNAP_SETS; ++i) h->snap_busy[i] = false;  // (every solve is behind the two events just waited for)
+    for (int i = 0; i < 2; ++i)   // ... and an all-gather's snapshot copy on the communication stream may still be reading v_b
+        if (h->vb_read_pending[i]) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_vb_read[i], 0)); h->vb_read_pending[i] = false; }
     for (int i = 0; i < (h->pipelined ? 2 : 1); ++i) {
         k_reset_state<<<(h->c.B + 255) / 256, 256, 0, h->stream>>>(h->c, h->sp[i]);
         HIPCHK(hipGetLastError());
@@ -560,10 +573,19 @@ dekf_status dekf_update(dekf_handle h, int T) {
     if (T != h->next_T) return fail(DEKF_ERR_ORDER, "update(T) must be called with T = 1, 2, 3, ... (EstSub.cpp:58-75)");
     if (h->c.est_type == 0) {
         const int par = h->pipelined ? (T & 1) : 0;
-        const DevState& sp = h->sp[par];
+        DevState sp = h->sp[par];
         hipStream_t ss = h->pipelined ? h->solve_stream[par] : h->stream;
-        // the solve of step T - 2 read this set's snapshot and wrote its outputs and slabs: the assemble that refills it waits
-        if (h->pipelined && h->solve_pending[par]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_solve[par], 0));
+        const int snap_set = h->pipelined ? T % DEKF_SNAP_SETS : 0;
+        if (h->pipelined) {
+            // The assemble writes the solve's input snapshot.  With two copies it had to wait for the solve of step T - 2, and by
+            // then step T - 1's 768 persistent workgroups hold every slot of the machine: the assemble crawled in (0.41 instead of
+            // 0.07 ms) as they left, and the solve of step T started that much late — the pipeline ran on its dependencies, not on
+            // the machine (profiles/r05_step_pipelining_timeline.txt).  With three copies it waits for step T - 3, which is long
+            // over: the small kernels of a step run while the step before the previous one drains, and the solve of step T is
+            // ready the moment a slot frees.  (Outputs and scratch slabs stay at two sets: solves on one stream are in order.)
+            sp.snap = h->s.snap + (size_t)snap_set * h->c.snap_len * h->c.B;
+            if (h->snap_busy[snap_set]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_snap_free[snap_set], 0));
+        }
         {
             Timed t(h, 1);
             k_mhe_assemble<<<h->c.B, 64, h->lds_asm, h->stream>>>(h->c, sp, T, h->pushes);
@@ -572,8 +594,8 @@ dekf_status dekf_update(dekf_handle h, int T) {
         if (h->pipelined) {
             HIPCHK(hipEventRecord(h->ev_asm[par], h->stream));
             HIPCHK(hipStreamWaitEvent(ss, h->ev_asm[par], 0));
-            // an all-gather in flight still reads this set's v_b until its snapshot copy is through (dekf_allgather_vb)
-            if (h->ag_pending) HIPCHK(hipStreamWaitEvent(ss, h->ev_vb_ready, 0));
+            // the all-gather of step T - 2 read THIS set's v_b until its snapshot copy was through (dekf_allgather_vb)
+            if (h->vb_read_pending[par]) { HIPCHK(hipStreamWaitEvent(ss, h->ev_vb_read[par], 0)); h->vb_read_pending[par] = false; }
             // A recorded event between the stream-waits and the launch: measured, not understood.  Without it the solve of step
             // T + 1 does not start under the last round of step T's solve and the mode gains nothing (2.09 M steps/s, Go1 at 4096);
             // with it the two overlap (2.16 M).  Found because bench.py's timing events had the same effect; an event recorded only
@@ -592,6 +614,8 @@ dekf_status dekf_update(dekf_handle h, int T) {
         if (h->pipelined) {
             HIPCHK(hipEventRecord(h->ev_solve[par], ss));
             h->solve_pending[par] = true;
+            HIPCHK(hipEventRecord(h->ev_snap_free[snap_set], ss));
+            h->snap_busy[snap_set] = true;
         }
         h->last_par = par;
     } else {
@@ -781,10 +805,12 @@ dekf_status dekf_comm_init(dekf_handle h, int world, int rank, const void* id) {
     // a failure on the way leaves the handle exactly as it was (h->comm == nullptr: dekf_allgather_vb refuses, a retry
     // is accepted) instead of half-initialised.
     hipStream_t cs = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr, e3 = nullptr;
     double* snap = nullptr;
     auto rollback = [&] {
         if (snap) (void)hipFree(snap);
+        if (e3) (void)hipEventDestroy(e3);
+        if (e2) (void)hipEventDestroy(e2);
         if (e1) (void)hipEventDestroy(e1);
         if (e0) (void)hipEventDestroy(e0);
         if (cs) (void)hipStreamDestroy(cs);
@@ -792,6 +818,8 @@ dekf_status dekf_comm_init(dekf_handle h, int world, int rank, const void* id) {
     hipError_t he = hipStreamCreateWithFlags(&cs, hipStreamNonBlocking);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e0, hipEventDisableTiming);
     if (he == hipSuccess) he = hipEventCreateWithFlags(&e1, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e2, hipEventDisableTiming);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&e3, hipEventDisableTiming);
     if (he == hipSuccess) he = hipMalloc((void**)&snap, 3 * (size_t)h->c.B * sizeof(double));
     if (he != hipSuccess) {
         rollback();
@@ -807,6 +835,9 @@ dekf_status dekf_comm_init(dekf_handle h, int world, int rank, const void* id) {
     h->comm_stream = cs;
     h->ev_vb_ready = e0;
     h->ev_ag_done = e1;
+    h->ev_vb_read[0] = e2;
+    h->ev_vb_read[1] = e3;
+    h->vb_read_pending[0] = h->vb_read_pending[1] = false;
     h->vb_snapshot = snap;
     h->world = world;
     h->rank = rank;
@@ -822,14 +853,15 @@ dekf_status dekf_allgather_vb(dekf_handle h, double* v_b_all_dev) {
     if (h->pipelined) {
         // Everything on the communication stream, which is in order (the previous all-gather has read the snapshot): wait for the
         // solve that produced v_b, copy it, exchange.  The handle's stream is not involved, so the next step's pushes, EKF tick and
-        // assemble are not held back; the solve that will overwrite this set's v_b waits for ev_vb_ready (dekf_update).
+        // assemble are not held back; the solve that will overwrite this set's v_b (two steps on) waits for ev_vb_read (dekf_update).
         if (h->solve_pending[h->last_par]) HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_solve[h->last_par], 0));
         else {  // (T = 0: no solve yet; v_b is what the reset / initialise kernels on the handle's stream left)
             HIPCHK(hipEventRecord(h->ev_vb_ready, h->stream));
             HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_vb_ready, 0));
         }
         HIPCHK(hipMemcpyAsync(h->vb_snapshot, h->sp[h->last_par].v_b, n * sizeof(double), hipMemcpyDeviceToDevice, h->comm_stream));
-        HIPCHK(hipEventRecord(h->ev_vb_ready, h->comm_stream));
+        HIPCHK(hipEventRecord(h->ev_vb_read[h->last_par], h->comm_stream));
+        h->vb_read_pending[h->last_par] = true;
     } else {
     // the previous all-gather must have read the snapshot before it is overwritten (it finished a step ago)
     if (h->ag_pending) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_ag_done, 0));

@@ -75,7 +75,9 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     c.B = B; c.L = p.num_legs; c.nj = p.joints_per_leg; c.N = p.N; c.nm = 3 * p.num_legs;
     c.ft = p.leg_odom_type; c.ns = 9 + 3 * c.ft * c.L;
     c.SV = 2 * c.ns + c.nm + 3; c.SC = c.nm + c.ns + 3;
-    c.ring = 4 * p.N + 1; c.wcap = p.N + 1; c.rec = Rec::len(c.L, c.ft);
+    // window records: N + 1 slots (the N of a window and the one the next step fills); one more when steps are pipelined, because
+    // the term construction of step T then runs while the solve of step T - 2 may still be reading its window (dekf_capi.hip)
+    c.ring = 4 * p.N + 1; c.wcap = p.N + 1 + ((p.solve_pipeline == 1 && p.est_type == 0) ? 1 : 0); c.rec = Rec::len(c.L, c.ft);
     c.snap_len = c.ns * c.ns + c.ns + 4 * c.wcap;
     c.est_type = p.est_type;
     c.marg_info = p.leg_odom_type == 1 && p.arrival_cost_form == 1;
@@ -125,6 +127,7 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
 // every persistent array: alloc(bytes) must return zero-filled memory
 // `copies` (1 or 2): sets of the per-solve data (input snapshot, outputs, solver scratch, section stamps); set 1 follows set 0
 // in each allocation (second_set() moves a DevState's pointers over)
+constexpr int DEKF_SNAP_SETS = 3;  // input snapshots of a pipelined handle (by T mod 3; outputs and solver scratch: by T mod 2)
 template <class Alloc>
 inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc alloc, int copies = 1) {
     const size_t B = (size_t)c.B, L = (size_t)c.L, nj = (size_t)c.nj;
@@ -139,7 +142,7 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
     s.st_time = D((size_t)c.ring * B); s.st_R = D((size_t)c.ring * 9 * B); s.st_dtime = I((size_t)c.ring * B);
     const size_t ns = (size_t)c.ns;
     s.rec = D((size_t)c.wcap * c.rec * B); s.Mp = D(ns * ns * B); s.np_ = D(ns * B);
-    s.snap = D((size_t)copies * c.snap_len * B);
+    s.snap = D((size_t)(copies > 1 ? DEKF_SNAP_SETS : 1) * c.snap_len * B);
     s.wp = D(12 * B); s.wpt = D(4 * B); s.wp_count = I(B);
     s.p_vo = D(3 * B); s.vo_ins_idx = I(B); s.vo_ins_dtime = I(B);
     Gws g;
@@ -157,7 +160,7 @@ inline DevState second_set(const DevCfg& c, const DevState& s, int solve_slots) 
     Gws g;
     g.init(c.N, c.L, c.ft, c.gws_wt);
     DevState t = s;
-    t.snap += (size_t)c.snap_len * B;
+    // (snap: one of DEKF_SNAP_SETS copies by T mod 3, chosen per launch — dekf_update)
     t.gws += (size_t)solve_slots * g.total;
     t.x_mhe += ns * B; t.v_b += 3 * B;
     t.status += B; t.iters += B; t.rho_updates += B; t.polish_status += B;

@@ -538,3 +538,41 @@ def test_pipelined_steps_with_the_rows_in_registers_kernel():
     for key in ("x", "v_b", "quat", "status"):
         assert np.array_equal(a[key], b[key]), key
     assert np.array_equal(ia["iters"], ib["iters"]) and np.array_equal(ia["pri_res"], ib["pri_res"])
+
+
+def test_pipelined_steps_at_the_bench_batch_run_two_steps_ahead():
+    """At 4096 Go1 instances the persistent solve workgroups hold every slot of the machine, and the handle's stream — pushes, EKF
+    tick, term construction — runs up to two steps ahead of the solves (three copies of the solve's input snapshot, N + 2 window
+    records: dekf_capi.hip, dekf_update).  75 ticks with visual-odometry intervals rewriting the bounds of older window records,
+    without a single read in between; then the same again with a read at every seventh tick: all bit-identical to the in-order run."""
+    p = go1_params()
+    p.ekf_rate = p.rate
+    B, K = 4096, 75
+    s = make_streams(p, 64, K)
+    big = _tile(s, B // 64)
+    sd = streams_to_device(big)
+
+    def run(pipeline, read_every=0):
+        q = p.copy()
+        q.solve_pipeline = pipeline
+        est = BatchedEstimator(q, B)
+        mid = []
+        for k in range(K):
+            est.push_stream_step(sd, k)
+            est.step(k)
+            if read_every and k % read_every == read_every - 1:
+                mid.append(est.get()["x"][:64].copy())
+        out = (est.get(), est.solver_info(), mid)
+        est.close()
+        return out
+
+    ref = run(0, 7)
+    assert (ref[0]["status"] == 1).all()
+    for read_every in (0, 7):
+        got = run(1, read_every)
+        for key in ("x", "v_b", "quat", "p_vo", "status"):
+            assert np.array_equal(got[0][key], ref[0][key]), (read_every, key)
+        for key in ("iters", "rho_updates", "pri_res", "dua_res"):
+            assert np.array_equal(got[1][key], ref[1][key]), (read_every, key)
+        for i, x in enumerate(got[2]):
+            assert np.array_equal(x, ref[2][i]), (read_every, i)
