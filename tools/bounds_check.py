@@ -64,6 +64,10 @@ CASES = [  # (kernel set = library suffix, name, params maker, batch, ticks, ove
     ("legs1", "pogox N=100 with osqp.polish (factor streamed from the slab)", "pogox", 64, 110, dict(polish=1)),
     ("legs1", "pogox N=100 with osqp.polish, 320 instances (k_mhe_solve_rr_1_pol)", "pogox", 320, 112, dict(polish=1)),
     ("foot4", "go1 leg_odom_type 1 with osqp.polish", "go1", 128, 30, dict(leg_odom_type=1, polish=1)),
+    # solve_pipeline = 1: N + 2 window records, three copies of the solve's input snapshot, two sets of outputs and slabs
+    ("go1", "go1 N=20, pipelined steps (1000 instances: two rounds per launch, the handle's stream two steps ahead)", "go1", 1000, 70, dict(solve_pipeline=1)),
+    ("legs1", "pogox N=100, pipelined steps, 320 instances (k_mhe_solve_rr_1)", "pogox", 320, 128, dict(solve_pipeline=1)),
+    ("foot4", "go1 leg_odom_type 1, pipelined steps", "go1", 256, 45, dict(leg_odom_type=1, solve_pipeline=1)),
 ]
 MAKERS = {"go1": go1_params, "cassie": cassie_params, "pogox": pogox_params}
 
