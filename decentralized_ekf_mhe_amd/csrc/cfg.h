@@ -164,6 +164,12 @@ struct DevState {
     double *st_time, *st_R;
     int* st_dtime;
     double *rec, *Mp, *np_;
+    // The arrival cost of the NEXT step, computed ahead of time (k_mhe_marginalize_early, on a second stream under the tail of the
+    // current solve): folding window step T - N into (M_p, n_p) needs nothing of step T unless a vision pose arriving at step T
+    // rewrites that record's bound (GetMeasurement comes first in the reference's update).  marg_tag[b] = the step the pair was
+    // computed for; the assemble of that step takes it if no vision interval arrived, and runs the marginalisation itself otherwise.
+    double *Mp_next, *np_next;
+    int* marg_tag;
     // What a solve reads of the state the NEXT step's assemble overwrites (arrival cost, VO flags / bounds of the window), copied
     // by k_mhe_assemble at its end: [B][snap_len].  A pipelined handle has three copies (by T mod 3; outputs and solver scratch: two,
     // by parity of T), so that the EKF tick and the assemble of step T + 1 — and of step T + 2 — can run while step T's solve is

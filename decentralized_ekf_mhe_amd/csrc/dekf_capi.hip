@@ -21,6 +21,7 @@ extern "C" {
 __global__ void k_ekf_tick(DevCfg c, DevState s, int count);
 __global__ void k_mhe_initialize(DevCfg c, DevState s);
 __global__ void k_mhe_assemble(DevCfg c, DevState s, int T, int pushes);
+__global__ void k_mhe_marginalize_early(DevCfg c, DevState s, int T);
 // every solve kernel and its twin with OSQP's polishing step (kernels.hip: DEKF_SOLVE_KERNEL_BODY)
 #define DEKF_DECL_K(NAME)                                                              \
     __global__ void NAME(DevCfg c, DevState s, int kstart, int K, int gws_len);        \
@@ -100,6 +101,13 @@ struct dekf_handle_s {
     bool snap_busy[3] = {false, false, false};
     bool solve_pending[2] = {false, false};
     int last_par = 0;             // set the newest results are in
+    // In-order mode: the arrival cost of step T + 1 is computed ahead of time on early_stream (k_mhe_marginalize_early), behind the
+    // assemble of step T and beside its solve — i.e. in the slots that solve frees in its partly empty last round — and the assemble
+    // of step T + 1 takes it unless a vision interval arrived (cfg.h: DevState::Mp_next).  44 of the 67 us of term construction in
+    // front of every solve leave the critical path; results are the same bits.
+    hipStream_t early_stream = nullptr;
+    hipEvent_t ev_asm_done = nullptr, ev_early_done = nullptr, ev_early_mark = nullptr;
+    bool early_pending = false;
     // RCCL: the all-gather runs on its own stream out of a snapshot of v_b, so that it overlaps the next step
     void* comm = nullptr;
     int world = 1, rank = 0;
@@ -372,6 +380,23 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     }
     h->sp[0] = h->s;
     h->sp[1] = h->pipelined ? second_set(h->c, h->s, solve_slots) : h->s;
+#ifndef DEKF_DEBUG_NO_EARLY_MARGINALIZE
+    // (N = 1: the record folded at step T gets its gains AT step T.  DEKF_DEBUG_NO_EARLY_MARGINALIZE in the environment: diagnostic switch,
+    // everything on the handle's stream as before round 5 — same bits either way, tests/test_gpu_configs.py)
+    if (!h->pipelined && c.est_type == 0 && c.N >= 2 && !getenv("DEKF_DEBUG_NO_EARLY_MARGINALIZE")) {
+        int prio_least = 0, prio_greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+        // least priority: background work that is to take the slots the solve leaves, not to compete for them when both are ready
+        // (and a priority class of its own: never on a hardware queue with the caller's streams — see the solve streams below)
+        if (hipStreamCreateWithPriority(&h->early_stream, hipStreamNonBlocking, prio_least) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_asm_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->ev_early_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreate(&h->ev_early_mark) != hipSuccess) {
+            dekf_destroy(h);
+            return fail(DEKF_ERR_HIP, "could not create the stream of the early marginalisation");
+        }
+    }
+#endif
     if (h->pipelined) {
         // The two solve streams are created at the greatest stream priority: HIP maps streams round-robin onto a few hardware queues
         // PER PRIORITY CLASS (GPU_MAX_HW_QUEUES, default 4), and a stream-wait is a barrier packet that holds its whole queue — with
@@ -415,6 +440,10 @@ dekf_status dekf_destroy(dekf_handle h) {
         if (h->ev_mark[i]) (void)hipEventDestroy(h->ev_mark[i]);
     }
     for (int i = 0; i < DEKF_SNAP_SETS; ++i) if (h->ev_snap_free[i]) (void)hipEventDestroy(h->ev_snap_free[i]);
+    if (h->early_stream) { (void)hipStreamSynchronize(h->early_stream); (void)hipStreamDestroy(h->early_stream); }
+    if (h->ev_asm_done) (void)hipEventDestroy(h->ev_asm_done);
+    if (h->ev_early_done) (void)hipEventDestroy(h->ev_early_done);
+    if (h->ev_early_mark) (void)hipEventDestroy(h->ev_early_mark);
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     if (h->comm) rccl_destroy(h->comm);
     if (h->ev_vb_ready) (void)hipEventDestroy(h->ev_vb_ready);
@@ -437,6 +466,7 @@ dekf_status dekf_reset(dekf_handle h) {
     for (int i = 0; i < 2; ++i)   // a solve still in flight writes the outputs this clears
         if (h->solve_pending[i]) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_solve[i], 0)); h->solve_pending[i] = false; }
     for (int i = 0; i < DEKF_SNAP_SETS; ++i) h->snap_busy[i] = false;  // (every solve is behind the two events just waited for)
+    if (h->early_pending) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_early_done, 0)); h->early_pending = false; }  // (k_reset_state clears its tags)
     for (int i = 0; i < 2; ++i)   // ... and an all-gather's snapshot copy on the communication stream may still be reading v_b
         if (h->vb_read_pending[i]) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_vb_read[i], 0)); h->vb_read_pending[i] = false; }
     for (int i = 0; i < (h->pipelined ? 2 : 1); ++i) {
@@ -586,11 +616,13 @@ dekf_status dekf_update(dekf_handle h, int T) {
             sp.snap = h->s.snap + (size_t)snap_set * h->c.snap_len * h->c.B;
             if (h->snap_busy[snap_set]) HIPCHK(hipStreamWaitEvent(h->stream, h->ev_snap_free[snap_set], 0));
         }
+        if (h->early_pending) { HIPCHK(hipStreamWaitEvent(h->stream, h->ev_early_done, 0)); h->early_pending = false; }
         {
             Timed t(h, 1);
             k_mhe_assemble<<<h->c.B, 64, h->lds_asm, h->stream>>>(h->c, sp, T, h->pushes);
         }
         HIPCHK(hipGetLastError());
+        if (h->early_stream) HIPCHK(hipEventRecord(h->ev_asm_done, h->stream));
         if (h->pipelined) {
             HIPCHK(hipEventRecord(h->ev_asm[par], h->stream));
             HIPCHK(hipStreamWaitEvent(ss, h->ev_asm[par], 0));
@@ -618,6 +650,15 @@ dekf_status dekf_update(dekf_handle h, int T) {
             h->snap_busy[snap_set] = true;
         }
         h->last_par = par;
+        if (h->early_stream) {
+            // behind the assemble of this step (the arrival cost and the records as it left them), beside this step's solve
+            HIPCHK(hipStreamWaitEvent(h->early_stream, h->ev_asm_done, 0));
+            HIPCHK(hipEventRecord(h->ev_early_mark, h->early_stream));  // (as before a pipelined solve launch: see there)
+            k_mhe_marginalize_early<<<h->c.B, 64, h->lds_asm, h->early_stream>>>(h->c, h->s, T + 1);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipEventRecord(h->ev_early_done, h->early_stream));
+            h->early_pending = true;
+        }
     } else {
         Timed t(h, 1);
         k_kf_update<<<h->c.B, 64, h->lds_kf, h->stream>>>(h->c, h->s, h->pushes);

@@ -142,6 +142,7 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
     s.st_time = D((size_t)c.ring * B); s.st_R = D((size_t)c.ring * 9 * B); s.st_dtime = I((size_t)c.ring * B);
     const size_t ns = (size_t)c.ns;
     s.rec = D((size_t)c.wcap * c.rec * B); s.Mp = D(ns * ns * B); s.np_ = D(ns * B);
+    s.Mp_next = D(ns * ns * B); s.np_next = D(ns * B); s.marg_tag = I(B);
     s.snap = D((size_t)(copies > 1 ? DEKF_SNAP_SETS : 1) * c.snap_len * B);
     s.wp = D(12 * B); s.wpt = D(4 * B); s.wp_count = I(B);
     s.p_vo = D(3 * B); s.vo_ins_idx = I(B); s.vo_ins_dtime = I(B);

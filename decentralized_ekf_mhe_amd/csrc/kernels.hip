@@ -62,6 +62,12 @@ __global__ void __launch_bounds__(64, DEKF_ASM_WAVES) k_mhe_assemble(DevCfg c, D
     extern __shared__ double lds[];
     assemble_update(c, s, blockIdx.x, T, pushes, lds);
 }
+// the arrival cost of step T ahead of time (mhe_assemble_core.h: marginalize_early; launched on a second stream behind the assemble
+// of step T - 1, so that it runs in the slots the solve of step T - 1 frees in its last round)
+__global__ void __launch_bounds__(64, DEKF_ASM_WAVES) k_mhe_marginalize_early(DevCfg c, DevState s, int T) {
+    extern __shared__ double lds[];
+    marginalize_early(c, s, blockIdx.x, T, lds);
+}
 #endif  // DEKF_MISC_KERNELS
 
 // three placements of the factor (mhe_solve_core.h: SolveLayout): _ll all in LDS (Go1, N = 20),
@@ -271,6 +277,7 @@ __global__ void k_reset_state(DevCfg c, DevState s) {
     s.dua_res[b] = 0.0;
     s.vo_ins_idx[b] = 0;
     s.vo_ins_dtime[b] = 0;
+    s.marg_tag[b] = -1;
 }
 
 #endif  // DEKF_MISC_KERNELS

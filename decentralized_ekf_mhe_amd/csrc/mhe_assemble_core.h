@@ -183,7 +183,10 @@ DEKF_FN void leg_terms(const DevCfg& c, const double* R, const double* gyro, con
 
 // GetMeasurement(T): returns through LDS/HBM; `pushes` = samples already on the stack.
 // sm: LDS scratch (>= 16 doubles used here)
-DEKF_FN void get_measurement(const DevCfg& c, const DevState& s, int b, int T, int pushes, double* sm) {
+// Returns whether a vision interval rewrote VO flags / bounds of window records at this step (wave-uniform): the one thing of step T
+// that the marginalisation of step T depends on (marginalize_early).
+DEKF_FN bool get_measurement(const DevCfg& c, const DevState& s, int b, int T, int pushes, double* sm) {
+    bool vo_rewrite = false;
     const int ring = c.ring;
     double* st_time = s.st_time + (size_t)b * ring;
     double* st_R = s.st_R + (size_t)b * ring * 9;
@@ -238,6 +241,7 @@ DEKF_FN void get_measurement(const DevCfg& c, const DevState& s, int b, int T, i
                 for (int a = 0; a < 3; ++a) pv[a] = acc[a];
             }
             if (idx_now > win_start && nw >= 4) {
+                vo_rewrite = true;
                 double t_interval = tw[3] - tw[0];
                 double u0 = (t_interp - tw[0]) / t_interval;
                 double uinc = c.dt / t_interval;
@@ -272,6 +276,7 @@ DEKF_FN void get_measurement(const DevCfg& c, const DevState& s, int b, int T, i
     }
     (void)sm;
     DEKF_SYNC();
+    return vo_rewrite;
 }
 
 // measurement-side part of the record of step T from the latched sample (after get_measurement);
@@ -972,9 +977,9 @@ DEKF_FN bool marginalize_step(const DevCfg& c, const DevState& s, int b, int ste
     return marginalize_generic<0, -1>(c, s, b, r, sm);
 }
 
-// everything update(T) does before initQP/solveQP; T >= 1
-DEKF_FN void assemble_update(const DevCfg& c, const DevState& s, int b, int T, int pushes, double* sm) {
-    // UpdateMHE part 1: gains of step T-1 from stack.back()
+// UpdateMHE part 1: gains of step T - 1 (Q_dyn^-1, R Q_vo R') from its rotation, into its window record.  Depends on nothing
+// of step T: assemble_update runs it unless marginalize_early has (same code, same bits).
+DEKF_FN void gains_of_previous_step(const DevCfg& c, const DevState& s, int b, int T) {
     double* rprev = s.rec + ((size_t)b * c.wcap + ((T - 1) % c.wcap)) * c.rec;
 #if DEKF_DEVICE_BUILD
     {   // step_gains with the 6x6 inverse spread over six lanes (column j of G C G' in lane j)
@@ -1005,10 +1010,57 @@ DEKF_FN void assemble_update(const DevCfg& c, const DevState& s, int b, int T, i
         for (int i = 0; i < 6; ++i) rprev[Rec::QC + i] = qc[i];
     }
 #endif
+}
+
+// marginalizeQP(T - N) ahead of time, into (Mp_next, np_next): see DevState::Mp_next.  Same functions, same operands, same order of
+// operations as the in-place call of assemble_update — only earlier and into a copy.
+DEKF_FN void marginalize_early(const DevCfg& c, const DevState& s, int b, int T, double* sm) {
+    const int ns = c.ns, ns2 = c.ns * c.ns;
+    gains_of_previous_step(c, s, b, T);
     DEKF_SYNC();
-    get_measurement(c, s, b, T, pushes, sm);
+    if (T >= c.N) {
+        const double* Mp = s.Mp + (size_t)ns2 * b;
+        const double* np = s.np_ + (size_t)ns * b;
+        double* Mn = s.Mp_next + (size_t)ns2 * b;
+        double* nn = s.np_next + (size_t)ns * b;
+        wfor(ns2 + ns, [&](int e) {
+            if (e < ns2) Mn[e] = Mp[e];
+            else nn[e - ns2] = np[e - ns2];
+        });
+    }
+    DEKF_SYNC();
+    if (T >= c.N) {
+        DevState s2 = s;
+        s2.Mp = s.Mp_next;
+        s2.np_ = s.np_next;
+        marginalize_step(c, s2, b, T - c.N, sm);
+    }
+    DEKF_SYNC();
+    if (DEKF_LANE() == 0) s.marg_tag[b] = T;
+}
+
+// everything update(T) does before initQP/solveQP; T >= 1
+DEKF_FN void assemble_update(const DevCfg& c, const DevState& s, int b, int T, int pushes, double* sm) {
+    const bool early = s.marg_tag[b] == T;  // wave-uniform: marginalize_early ran for this step
+    if (!early) gains_of_previous_step(c, s, b, T);
+    DEKF_SYNC();
+    const bool vo_rewrite = get_measurement(c, s, b, T, pushes, sm);
     write_measurement_record(c, s, b, T);
-    if (T >= c.N) marginalize_step(c, s, b, T - c.N, sm);
+    if (T >= c.N) {
+        if (!vo_rewrite && early) {  // wave-uniform: the pair computed ahead of time is the pair this step would compute
+            const int ns = c.ns, ns2 = c.ns * c.ns;
+            double* Mp = s.Mp + (size_t)ns2 * b;
+            double* np = s.np_ + (size_t)ns * b;
+            const double* Mn = s.Mp_next + (size_t)ns2 * b;
+            const double* nn = s.np_next + (size_t)ns * b;
+            wfor(ns2 + ns, [&](int e) {
+                if (e < ns2) Mp[e] = Mn[e];
+                else np[e - ns2] = nn[e - ns2];
+            });
+        } else {
+            marginalize_step(c, s, b, T - c.N, sm);
+        }
+    }
     // the solve's input snapshot (cfg.h: DevState::snap): the arrival cost as this step leaves it and the VO flag / bound of every
     // ring slot — the two things update(T + 1) rewrites in place while the solve of step T may still be reading them
     DEKF_SYNC();

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_bench_line_has_the_contract_fields():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "256", "--steps", "8", "--warmup", "24"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--batch", "256", "--steps", "8", "--warmup", "24", "--pipelined-leg"],
                        capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -576,3 +576,56 @@ def test_pipelined_steps_at_the_bench_batch_run_two_steps_ahead():
             assert np.array_equal(got[1][key], ref[1][key]), (read_every, key)
         for i, x in enumerate(got[2]):
             assert np.array_equal(x, ref[2][i]), (read_every, i)
+
+
+def test_arrival_cost_computed_ahead_of_time_gives_the_same_bits(monkeypatch):
+    """In-order handles compute the arrival cost of step T + 1 (and the gains of step T) on a second stream beside step T's solve
+    (k_mhe_marginalize_early) and take it at step T + 1 unless a vision interval arrived then.  Against a handle with the diagnostic
+    switch DEKF_DEBUG_NO_EARLY_MARGINALIZE (everything in the assemble, as before): 75 ticks at 4096 without a read (the early kernel really
+    runs under the solve's tail), with a read at every tick (it runs alone), across a reset, with polishing, on a small batch and on
+    the foot-state shape — all bit-identical."""
+    def run(p, B, distinct, K, read_every, no_early, reset_at=None):
+        if no_early:
+            monkeypatch.setenv("DEKF_DEBUG_NO_EARLY_MARGINALIZE", "1")
+        else:
+            monkeypatch.delenv("DEKF_DEBUG_NO_EARLY_MARGINALIZE", raising=False)
+        sd = streams_to_device(_tile(make_streams(p, distinct, K), B // distinct))
+        est = BatchedEstimator(p, B)
+        mids = []
+        for rep in range(2 if reset_at else 1):
+            for k in range(reset_at if (reset_at and rep == 0) else K):
+                est.push_stream_step(sd, k)
+                est.step(k)
+                if read_every and k % read_every == read_every - 1:
+                    mids.append(est.get()["x"][:distinct].copy())
+            if reset_at and rep == 0:
+                est.reset()
+        out = (est.get(), est.solver_info(), mids)
+        est.close()
+        return out
+
+    def same(a, b, what):
+        for key in ("x", "v_b", "quat", "p_vo", "status"):
+            assert np.array_equal(a[0][key], b[0][key]), (what, key)
+        for key in ("iters", "rho_updates", "pri_res", "dua_res"):
+            assert np.array_equal(a[1][key], b[1][key]), (what, key)
+        assert len(a[2]) == len(b[2])
+        for i, (x, y) in enumerate(zip(a[2], b[2])):
+            assert np.array_equal(x, y), (what, i)
+
+    p = go1_params()
+    p.ekf_rate = p.rate
+    for what, args in (("4096, no reads", (p, 4096, 64, 75, 0)), ("4096, read every tick", (p, 4096, 64, 60, 1)),
+                       ("96 instances", (p, 96, 96, 60, 5)), ("reset after 33 ticks", (p, 1024, 64, 60, 7, 33))):
+        a = run(*args[:5], True, *args[5:])
+        b = run(*args[:5], False, *args[5:])
+        assert (a[0]["status"] == 1).all(), what
+        same(a, b, what)
+    q = p.copy()
+    q.polish = 1
+    same(run(q, 1024, 64, 50, 0, True), run(q, 1024, 64, 50, 0, False), "polish")
+    f = p.copy()
+    f.leg_odom_type = 1
+    same(run(f, 256, 32, 60, 0, True), run(f, 256, 32, 60, 0, False), "foot states")
+    g = _params(pogox_params)
+    same(run(g, 320, 32, 125, 0, True), run(g, 320, 32, 125, 0, False), "pogox")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Regenerates every artefact under profiles/ that DESIGN.md quotes, on ONE GPU box, into gpurun_out/final/:
 #   bench.json                    python bench.py (default flags, with cpu_baseline)
+#   bench_with_pipelined_leg.json python bench.py --no-cpu-baseline --pipelined-leg (the line + the same steps with solve_pipeline = 1)
 #   kernel_stats.csv              rocprofv3 --kernel-trace --stats of bench.py --steps 100 --warmup 30
 #   bench_under_rocprof.json      bench.py's own line in that profiled run
 #   kernel_trace_timed.json       average of the 100 timed solve launches from the kernel trace
@@ -13,6 +14,7 @@ OUT=$R/gpurun_out/final
 mkdir -p $OUT
 cd $R
 timeout 900 python3 bench.py 2> $OUT/bench.err | tail -1 > $OUT/bench.json
+timeout 900 python3 bench.py --no-cpu-baseline --pipelined-leg 2> $OUT/bench_pl.err | tail -1 > $OUT/bench_with_pipelined_leg.json
 ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -- python3 $R/bench.py --steps 100 --warmup 30 --no-cpu-baseline > $OUT/prof_stdout.log 2>&1 )
 grep "^{\"metric\"" $OUT/prof_stdout.log | tail -1 > $OUT/bench_under_rocprof.json
 python3 - "$OUT" <<'PY'
