@@ -367,6 +367,10 @@ def run_bench(args, env, rank, world):
                          # the contract's roofline is the HBM one; what actually limits this kernel is the chain of
                          # dependent mat-vec steps inside every ADMM iteration, so both honest fractions ride along:
                          "limiter": "dependent-issue latency (ADMM iterations x dependent 9x9 mat-vec steps), not HBM",
+                         # a rocprofv3 --stats table of this command also lists k_mhe_marginalize_early with a long wall time: it is
+                         # background work on a second stream at the least priority (the next step's arrival cost, ~0.05 ms of machine
+                         # time) whose workgroups wait for the slots this kernel frees in its last round
+                         "concurrent_background_kernel": "k_mhe_marginalize_early (second stream, least priority; wall time = waiting for slots)",
                          "flops_per_step": fl["total"], "flops_per_admm_iteration": fl["per_iteration"],
                          "flop_peak_tflops": FP64_VECTOR_TFLOPS,
                          "flop_frac": fl["total"] * per_gpu_rate / (FP64_VECTOR_TFLOPS * 1e12),
