@@ -380,7 +380,6 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     }
     h->sp[0] = h->s;
     h->sp[1] = h->pipelined ? second_set(h->c, h->s, solve_slots) : h->s;
-#ifndef DEKF_DEBUG_NO_EARLY_MARGINALIZE
     // (N = 1: the record folded at step T gets its gains AT step T.  DEKF_DEBUG_NO_EARLY_MARGINALIZE in the environment: diagnostic switch,
     // everything on the handle's stream as before round 5 — same bits either way, tests/test_gpu_configs.py)
     if (!h->pipelined && c.est_type == 0 && c.N >= 2 && !getenv("DEKF_DEBUG_NO_EARLY_MARGINALIZE")) {
@@ -396,7 +395,6 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             return fail(DEKF_ERR_HIP, "could not create the stream of the early marginalisation");
         }
     }
-#endif
     if (h->pipelined) {
         // The two solve streams are created at the greatest stream priority: HIP maps streams round-robin onto a few hardware queues
         // PER PRIORITY CLASS (GPU_MAX_HW_QUEUES, default 4), and a stream-wait is a barrier packet that holds its whole queue — with
