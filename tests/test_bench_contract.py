@@ -50,7 +50,7 @@ def test_bench_at_the_8_gpu_per_rank_batch_on_one_gpu():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["window_fill_steps_before_warmup"] == 48
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 2 and d["window_fill_steps_before_warmup"] == 62
     assert d["config"]["workload"] == "Go1, batch=8192 synthetic IMU+encoder+vision streams, 20-step MHE, 1xMI355X"
     assert d["config"]["batch_per_gpu"] == 8192 and d["config"]["global_batch"] == 8192
     assert d["config"]["allgather"] == "none"

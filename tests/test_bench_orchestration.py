@@ -49,9 +49,9 @@ def _worker(rank, world, port, out_dir, preflight_fails_on, slow_s=0.0):
         env.make_estimator = make_slow
     line = bench.run_bench(args, env, rank, world)
     est = made[0]
-    assert est.k == 50 + 7 - 1 and est.timed_steps == 7          # 45 fill + 5 warm-up + exactly 7 timed steps
+    assert est.k == 64 + 7 - 1 and est.timed_steps == 7          # 59 fill + 5 warm-up + exactly 7 timed steps
     if preflight_fails_on is None:
-        assert est.comm == "up" and est.gathers == 57 and est.layout_checked == 57
+        assert est.comm == "up" and est.gathers == 71 and est.layout_checked == 71
     else:
         assert est.comm is None and est.gathers == 0                 # nobody entered the collective init
     assert (line is None) == (rank != 0)
@@ -70,7 +70,7 @@ def _run(tmp_path, preflight_fails_on, world=2, slow_s=0.0):
 
 def test_two_ranks_own_communicator(tmp_path):
     d = _run(tmp_path, None)
-    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 5 and d["window_fill_steps_before_warmup"] == 45
+    assert d["n_gpus"] == 2 and d["steps"] == 7 and d["warmup"] == 5 and d["window_fill_steps_before_warmup"] == 59
     assert d["config"]["allgather"].startswith("dekf_allgather_vb") and d["config"]["global_batch"] == 12
     assert abs(d["value"] - 2 * 6 * 7 / (d["ms_per_step"] * 7e-3)) / d["value"] < 1e-9
     rf = d["roofline"]

@@ -53,7 +53,7 @@ def run(name, maker, B, steps, pipelined_leg=True, **kw):
     p.ekf_rate = p.rate
     for k, v in kw.items():
         setattr(p, k, v)
-    W = p.N + 10
+    W = max(p.N + 10, 64)   # (past the transient of the first vision intervals: ticks 40-56 on the N = 20 shapes, see bench.py)
     s = make_streams(p, B, W + steps)
     sd = streams_to_device(s)
     est = BatchedEstimator(p, B)
