@@ -16,7 +16,7 @@ DEKF_OK, DEKF_ERR_INVALID, DEKF_ERR_NO_DEVICE, DEKF_ERR_HIP, DEKF_ERR_ORDER, DEK
 DEKF_HOST, DEKF_DEVICE = 0, 1
 DEKF_SOLVE_NONE, DEKF_SOLVE_OK, DEKF_SOLVE_MAX_ITER, DEKF_SOLVE_NUMERIC = 0, 1, 2, -1
 DEKF_UNIQUE_ID_BYTES = 128
-DEKF_ABI_VERSION = 3  # include/dekf.h; the ctypes mirror of dekf_params (params.py) is laid out for exactly this version
+DEKF_ABI_VERSION = 4  # include/dekf.h; the ctypes mirror of dekf_params (params.py) is laid out for exactly this version
 
 _dp, _ip, _vp = C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p
 

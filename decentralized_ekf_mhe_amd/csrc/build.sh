@@ -44,10 +44,17 @@ else
     unit() {  # unit <mask> <flags...>
         local m=$1; shift
         if ! $HIPCC $FLAGS "$@" -Rpass-analysis=kernel-resource-usage -c -DDEKF_KSET=$m -DDEKF_KSET_ONLY -o "$T/k_$m.o" kernels.hip $EXTRA 2> "$T/ru_$m.txt"; then
+            # Retry without the hidden flag ONLY for the known compiler crash (its signature below); anything else — a genuine source
+            # error that might happen to compile without the flag — fails the build with the diagnostics of THIS attempt.  The first
+            # attempt's output is kept (first_$m.txt) and its non-remark lines go into the notes of the resource-usage file.
             case " $* " in *" -disable-machine-licm "*)
-                echo "build.sh: kernel set $m failed with -mllvm -disable-machine-licm, retrying without it" >&2
-                $HIPCC $FLAGS -Rpass-analysis=kernel-resource-usage -c -DDEKF_KSET=$m -DDEKF_KSET_ONLY -o "$T/k_$m.o" kernels.hip $EXTRA 2> "$T/ru_$m.txt" \
-                    && echo "set $m: compiled WITHOUT -disable-machine-licm (retry)" >> "$T/ru_notes.txt" && return 0;;
+                if grep -q "Illegal instruction detected\|LLVM ERROR\|PLEASE submit a bug report" "$T/ru_$m.txt"; then
+                    cp "$T/ru_$m.txt" "$T/first_$m.txt"
+                    echo "build.sh: kernel set $m: compiler crash with -mllvm -disable-machine-licm, retrying without it" >&2
+                    { echo "set $m: first attempt (with -disable-machine-licm) died:"; grep -v "remark:\|^ *[0-9]* | \|^ *| " "$T/first_$m.txt" | head -20; } >> "$T/ru_notes.txt"
+                    $HIPCC $FLAGS -Rpass-analysis=kernel-resource-usage -c -DDEKF_KSET=$m -DDEKF_KSET_ONLY -o "$T/k_$m.o" kernels.hip $EXTRA 2> "$T/ru_$m.txt" \
+                        && echo "set $m: compiled WITHOUT -disable-machine-licm (retry)" >> "$T/ru_notes.txt" && return 0
+                fi;;
             esac
             grep -v "remark:" "$T/ru_$m.txt" >&2
             return 1

@@ -22,6 +22,11 @@ namespace dekf {
 #define DEKF_SOLVE_THREADS 256  // lanes of the workgroup that solves one instance (4 wavefronts)
 #endif
 
+#ifndef DEKF_QUEUE_MODE
+#define DEKF_QUEUE_MODE 2  // the solve kernels' instance queue (kernels.hip: DEKF_QUEUE_LOOP); 0: static grid-stride, A/B builds only
+#endif
+#define DEKF_R4_THREADS 192  // the four-per-CU kernels' workgroup: the solve wavefront + two workers (mhe_admm_core.h: admm_chunk_r4)
+
 constexpr int DEKF_PROF_SLOTS = 32;  // section stamps per instance, diagnostic build only (DevState::prof)
 constexpr double OSQP_INFTY = 1e30;
 constexpr double RHO_MIN = 1e-6, RHO_MAX = 1e6, RHO_EQ_OVER_RHO_INEQ = 1e3, RHO_TOL = 1e-4;
@@ -57,6 +62,7 @@ struct DevCfg {
     int max_iter, scaling, check_termination, adaptive_rho, adaptive_rho_interval;
     double adaptive_rho_tolerance;
     int polish, polish_refine_iter;  // osqp.polish (DecentralEst.cpp:207), OSQP's polish_refine_iter (default 3)
+    int polish_accept_osqp;          // 1: polish.c's acceptance test verbatim (dekf_params.polish_accept_osqp); 0: third clause symmetric
     double delta;                    // osqp.delta (DecentralEst.cpp:211)
     // EKF (orien_ekf.cpp:13-31)
     double ekf_dt, ekf_Cgyro[3], ekf_Caccel[3], ekf_Cvo[4], ekf_P0[4], ekf_q0[4];
@@ -180,6 +186,7 @@ struct DevState {
     double* p_vo;
     int *vo_ins_idx, *vo_ins_dtime;
     double* gws;
+    int* queue;  // the solve kernels' instance queue: [0] next instance, [1] workgroups that have left (kernels.hip: solve_queue_leave); one pair per output set
     // KF
     double *kf_x, *kf_C;
     // outputs

@@ -32,6 +32,8 @@ DEKF_DECL_K(k_mhe_solve_lg_2_n20)
 #ifndef DEKF_NO_R3
 DEKF_DECL_K(k_mhe_solve_r3_4_n20)
 DEKF_DECL_K(k_mhe_solve_r3_2_n20)
+DEKF_DECL_K(k_mhe_solve_r4_4_n20)
+DEKF_DECL_K(k_mhe_solve_r4_2_n20)
 #endif
 DEKF_DECL_SOLVE(1)
 #ifndef DEKF_NO_RR
@@ -45,6 +47,7 @@ DEKF_DECL_SOLVE_FOOT(1)
 DEKF_DECL_SOLVE_FOOT(2)
 DEKF_DECL_SOLVE_FOOT(3)
 DEKF_DECL_SOLVE_FOOT(4)
+__global__ void k_gap();
 __global__ void k_kf_initialize(DevCfg c, DevState s);
 __global__ void k_kf_update(DevCfg c, DevState s, int pushes);
 __global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* t_pre, const double* t_now,
@@ -79,6 +82,7 @@ struct dekf_handle_s {
     // full windows (K == N) of the fixed-horizon shapes: the three-workgroups-per-CU kernel (kernels.hip), its own grid and LDS size
     void (*solve_kernel_full)(DevCfg, DevState, int, int, int) = nullptr;
     int solve_grid_full = 0;
+    int solve_threads_full = DEKF_SOLVE_THREADS;  // (the four-per-CU kernels: DEKF_R4_THREADS)
     size_t lds_solve_full = 0;
     const char *solve_name = nullptr, *solve_name_full = nullptr;  // kernel symbols, for dekf_solve_kernel_name
     size_t lds_solve = 0, lds_asm = 0, lds_kf = 0;
@@ -259,6 +263,9 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     if (const char* pad = getenv("DEKF_DEBUG_LDS_PAD")) h->lds_solve += (size_t)atol(pad);
 #endif
     typedef void (*SolveFn)(DevCfg, DevState, int, int, int);
+#ifndef DEKF_R4_SELECT
+#define DEKF_R4_SELECT(cap) ((cap) == 4)
+#endif
     {
         struct Named { SolveFn fn; const char* name; SolveFn fn_pol; const char* name_pol; };
 #define DEKF_K(sym) {sym, #sym, sym##_pol, #sym "_pol"}
@@ -307,7 +314,29 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
     long slots = (long)per_cu * prop.multiProcessorCount;
     h->solve_grid = (int)(slots < batch ? slots : batch);
 #ifndef DEKF_NO_R3
-    if (!c.ft && c.N == 20 && (c.L == 4 || c.L == 2) && (cap == 0 || cap > per_cu)) {
+    // Four workgroups of three wavefronts per CU (round 6, admm_chunk_r4): solve_workgroups_per_cu = DEKF_R4_SELECT selects them
+    if (!c.ft && c.N == 20 && (c.L == 4 || c.L == 2) && DEKF_R4_SELECT(cap)) {
+        const SolveFn full = c.polish ? (c.L == 4 ? k_mhe_solve_r4_4_n20_pol : k_mhe_solve_r4_2_n20_pol) : (c.L == 4 ? k_mhe_solve_r4_4_n20 : k_mhe_solve_r4_2_n20);
+        const char* const full_name = c.polish ? (c.L == 4 ? "k_mhe_solve_r4_4_n20_pol" : "k_mhe_solve_r4_2_n20_pol") : (c.L == 4 ? "k_mhe_solve_r4_4_n20" : "k_mhe_solve_r4_2_n20");
+        hipFuncAttributes fa;
+        size_t static_lds = 512;
+        if (hipFuncGetAttributes(&fa, (const void*)full) == hipSuccess) static_lds = fa.sharedSizeBytes;
+        if (lay.r4_fits(c.L, static_lds)) {
+            const long sf = 4L * prop.multiProcessorCount;
+            int gridf = (int)(sf < batch ? sf : batch);
+#ifdef DEKF_AB_KNOBS  // A/B builds only (tools/r4_check.py): another persistent grid
+            if (const char* ge = getenv("DEKF_DEBUG_R4_GRID")) { const int gv = atoi(ge); if (gv > 0 && gv <= batch) gridf = gv; }
+#endif
+            if (gridf > h->solve_grid) {
+                h->lds_solve_full = lay.r4_lds_bytes();
+                h->solve_grid_full = gridf;
+                h->solve_threads_full = DEKF_R4_THREADS;
+                h->solve_kernel_full = full;
+                h->solve_name_full = full_name;
+            }
+        }
+    }
+    if (!h->solve_kernel_full && !c.ft && c.N == 20 && (c.L == 4 || c.L == 2) && (cap == 0 || cap > per_cu)) {
         const SolveFn full = c.polish ? (c.L == 4 ? k_mhe_solve_r3_4_n20_pol : k_mhe_solve_r3_2_n20_pol) : (c.L == 4 ? k_mhe_solve_r3_4_n20 : k_mhe_solve_r3_2_n20);
         const char* const full_name = c.polish ? (c.L == 4 ? "k_mhe_solve_r3_4_n20_pol" : "k_mhe_solve_r3_2_n20_pol") : (c.L == 4 ? "k_mhe_solve_r3_4_n20" : "k_mhe_solve_r3_2_n20");
         // the kernel's static LDS (reduction scratch of wave.h) counts against the same allocation as the dynamic part
@@ -485,6 +514,9 @@ dekf_status dekf_sync(dekf_handle h) {
     for (int i = 0; i < 2; ++i)
         if (h->solve_stream[i]) HIPCHK(hipStreamSynchronize(h->solve_stream[i]));
     if (h->comm_stream) HIPCHK(hipStreamSynchronize(h->comm_stream));
+    // (the arrival cost of the next step may still be running beside the last solve: dekf.h promises that ALL work is complete here,
+    // and an asynchronous failure of that kernel must surface here too)
+    if (h->early_stream) HIPCHK(hipStreamSynchronize(h->early_stream));
     return DEKF_OK;
 }
 int dekf_batch(dekf_handle h) { return h ? h->c.B : 0; }
@@ -636,8 +668,12 @@ dekf_status dekf_update(dekf_handle h, int T) {
         {
             Timed t(h, 2, ss);
             const int K = T - kstart + 1;
+#ifdef DEKF_AB_KNOBS  // A/B builds only: a quiet gap (an empty kernel) between the term construction and the solve launch
+            { static const int gap = getenv("DEKF_DEBUG_GAP_KERNEL") ? atoi(getenv("DEKF_DEBUG_GAP_KERNEL")) : 0;
+              for (int i = 0; i < gap; ++i) k_gap<<<1, 64, 0, ss>>>(); }
+#endif
             if (h->solve_kernel_full && K == h->c.N)
-                h->solve_kernel_full<<<h->solve_grid_full, DEKF_SOLVE_THREADS, h->lds_solve_full, ss>>>(h->c, sp, kstart, K, h->gws_len);
+                h->solve_kernel_full<<<h->solve_grid_full, h->solve_threads_full, h->lds_solve_full, ss>>>(h->c, sp, kstart, K, h->gws_len);
             else
                 h->solve_kernel<<<h->solve_grid, DEKF_SOLVE_THREADS, h->lds_solve, ss>>>(h->c, sp, kstart, K, h->gws_len);
         }

@@ -43,7 +43,7 @@ inline void default_params(dekf_params* p) {
     p->ekf_quaternion_init[0] = 1.0;
     p->ekf_rate = 500; p->ekf_history = 256;
     p->polish_refine_iter = 3;
-    p->arrival_cost_form = 0; p->solve_pipeline = 0; p->solve_workgroups_per_cu = 0;
+    p->arrival_cost_form = 0; p->solve_pipeline = 0; p->solve_workgroups_per_cu = 0; p->polish_accept_osqp = 0;
 }
 
 // returns nullptr when ok, else a message
@@ -114,6 +114,7 @@ inline const char* fill_cfg(const dekf_params& p, int B, DevCfg& c) {
     c.adaptive_rho = p.adapt_rho; c.adaptive_rho_interval = p.adaptive_rho_interval;
     c.adaptive_rho_tolerance = p.adaptive_rho_tolerance;
     c.polish = p.polish; c.polish_refine_iter = p.polish_refine_iter; c.delta = p.delta;
+    c.polish_accept_osqp = p.polish_accept_osqp != 0;
     c.ekf_dt = 1.0 / (double)p.ekf_rate;
     for (int i = 0; i < 4; ++i) {
         c.ekf_Cvo[i] = sq(p.ekf_vo_meas_std[i]);
@@ -150,6 +151,7 @@ inline void alloc_state(const DevCfg& c, DevState& s, int solve_slots, Alloc all
     g.init(c.N, c.L, c.ft, c.gws_wt);
     const size_t cp = (size_t)copies;
     s.gws = D(cp * solve_slots * g.total);
+    s.queue = I(cp * 2);
     s.kf_x = D(ns * B); s.kf_C = D(ns * ns * B);
     s.x_mhe = D(cp * ns * B); s.v_b = D(cp * 3 * B);
     s.status = I(cp * B); s.iters = I(cp * B); s.rho_updates = I(cp * B); s.polish_status = I(cp * B);
@@ -163,6 +165,7 @@ inline DevState second_set(const DevCfg& c, const DevState& s, int solve_slots) 
     DevState t = s;
     // (snap: one of DEKF_SNAP_SETS copies by T mod 3, chosen per launch — dekf_update)
     t.gws += (size_t)solve_slots * g.total;
+    t.queue += 2;
     t.x_mhe += ns * B; t.v_b += 3 * B;
     t.status += B; t.iters += B; t.rho_updates += B; t.polish_status += B;
     t.pri_res += B; t.dua_res += B;

@@ -32,6 +32,78 @@ extern "C" __global__ void k_bounds_selftest(double* a) {
 }
 #endif
 
+// The solve kernels' instance queue (round 6).  A persistent workgroup takes its next instance from a device-side counter instead of
+// striding over the batch by the grid size: instances whose solves take different numbers of ADMM iterations (a fleet that is not in
+// lock-step) balance themselves, and a workgroup that the hardware could not place next to the others (four per CU fit on 96-99 % of
+// the CUs, tools/probes/r4_residency_probe.hip) finds the queue empty when it finally starts instead of holding the launch for a
+// whole round of its own.  queue[0]: next instance; queue[1]: workgroups that have left — the last one resets both, so the counter
+// needs nothing from the host and nothing between launches (every workgroup's final fetch has returned before it counts itself out).
+__device__ __forceinline__ void solve_queue_leave(const dekf::DevState& s) {
+#if DEKF_QUEUE_MODE == 0
+    return;
+#endif
+    if (threadIdx.x == 0 && atomicAdd(s.queue + 1, 1) == (int)gridDim.x - 1) {
+        s.queue[0] = 0;
+        s.queue[1] = 0;
+    }
+}
+
+// Two forms of the loop.  STATIC FIRST (every kernel whose grid is placed at once — all of them but the four-per-CU kernels): the first
+// instance of a workgroup is its own index (no stampede of gridDim.x atomics on one address when a launch starts); the counter counts
+// instances beyond the first gridDim.x.  DYNAMIC (the four-per-CU kernels, whose last workgroups the hardware places late on 2-9 % of
+// the CUs, profiles/r06_go1_four_per_cu_3waves.txt): every instance comes from the counter, so a workgroup that starts late holds no
+// instance hostage.  In both the fetch of the NEXT instance is issued from INSIDE the current solve (solve_window_t, in front of the
+// first ADMM iterations: SolveInfo::next_fetch) — in lock-step every workgroup of a round fetches at the same moment, the atomics on
+// one address serialise (about 4 us for 768 of them), and a wavefront's memory operations return in order: issued where the
+// wavefront runs LDS-only iterations for the next 60 us, nobody waits for it.
+// Measured (Go1, 4096): a lock-step fleet pays 0.2 % for the queue (1.8558 -> 1.860 ms per launch), a mixed fleet (cameras at 5-50 Hz,
+// every tenth robot blind: 21 % of the solves stop at 50 iterations, 78 % at 75) gains 4.2 % (1.92 -> 1.84 ms)
+// (profiles/r06_fleet_not_in_lock_step.txt).  -DDEKF_QUEUE_MODE=0 (cfg.h): the static grid-stride of rounds 1-5, for A/B builds.
+#if DEKF_QUEUE_MODE == 0
+#define DEKF_QUEUE_LOOP(...) \
+        for (int b = blockIdx.x; b < c.B; b += gridDim.x) { (void)(__VA_ARGS__); DEKF_WG_TRACE_COUNT; }
+#define DEKF_QUEUE_LOOP_DYNAMIC(...) DEKF_QUEUE_LOOP(__VA_ARGS__)
+#else
+#define DEKF_QUEUE_LOOP(...)                                                                         \
+        for (int b = blockIdx.x; b < c.B;) {                                                         \
+            const dekf::SolveInfo si_ = (__VA_ARGS__);                                               \
+            DEKF_WG_TRACE_COUNT;                                                                     \
+            if (threadIdx.x == 0) next_instance = si_.next_fetch + (int)gridDim.x;                   \
+            __syncthreads();                                                                         \
+            b = next_instance;                                                                       \
+            __syncthreads();                                                                         \
+        }
+#define DEKF_QUEUE_LOOP_DYNAMIC(...)                                                                 \
+        int nb_ = 0;                                                                                 \
+        if (threadIdx.x == 0) nb_ = atomicAdd(s.queue, 1);                                           \
+        for (;;) {                                                                                   \
+            if (threadIdx.x == 0) next_instance = nb_;                                               \
+            __syncthreads();                                                                         \
+            const int b = next_instance;                                                             \
+            if (b >= c.B) break;                                                                     \
+            const dekf::SolveInfo si_ = (__VA_ARGS__);                                               \
+            DEKF_WG_TRACE_COUNT;                                                                     \
+            nb_ = si_.next_fetch;                                                                    \
+        }
+#endif
+
+// A/B builds only (-DDEKF_AB_KNOBS, tools/probes/r4_wg_trace.py): when each persistent workgroup started and left (100 MHz wall clock),
+// how many instances it solved and where it ran, into the section-stamp buffer (slots 0..3 of row blockIdx.x)
+#ifdef DEKF_AB_KNOBS
+#define DEKF_WG_TRACE_BEGIN const long long wg_t0_ = wall_clock64(); int wg_n_ = 0;
+#define DEKF_WG_TRACE_COUNT ++wg_n_
+#define DEKF_WG_TRACE_END                                                                                           \
+    if (threadIdx.x == 0 && blockIdx.x < c.B) {                                                                     \
+        double* o_ = s.prof + (size_t)blockIdx.x * dekf::DEKF_PROF_SLOTS;                                           \
+        o_[0] = (double)wg_t0_; o_[1] = (double)wall_clock64(); o_[2] = (double)wg_n_;                              \
+        o_[3] = (double)((__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 0xf) * 65536u + (__builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4) & 0xffffu)); \
+    }
+#else
+#define DEKF_WG_TRACE_BEGIN
+#define DEKF_WG_TRACE_COUNT (void)0
+#define DEKF_WG_TRACE_END
+#endif
+
 extern "C" {
 
 // -DDEKF_KSET_ONLY (the parallel product build, build.sh): this translation unit carries ONLY the kernels of its mask — no stubs
@@ -104,11 +176,16 @@ __global__ void __launch_bounds__(64, DEKF_ASM_WAVES) k_mhe_marginalize_early(De
     __global__ void NAME(DevCfg, DevState, int, int, int) {}     \
     __global__ void NAME##_pol(DevCfg, DevState, int, int, int) {}
 #endif
-#define DEKF_SOLVE_KERNEL_BODY_(NAME, WAVES, POLISH, ...)                                                                    \
-    __global__ void __launch_bounds__(DEKF_SOLVE_THREADS, WAVES) NAME(DevCfg c, DevState s, int kstart, int K, int gws_len) { \
+#define DEKF_SOLVE_KERNEL_BODY_(NAME, WAVES, POLISH, ...) DEKF_SOLVE_KERNEL_BODY_T_(NAME, DEKF_SOLVE_THREADS, DEKF_QUEUE_LOOP, WAVES, POLISH, __VA_ARGS__)
+#define DEKF_SOLVE_KERNEL_BODY_T_(NAME, THREADS, LOOP, WAVES, POLISH, ...)                                                   \
+    __global__ void __launch_bounds__(THREADS, WAVES) NAME(DevCfg c, DevState s, int kstart, int K, int gws_len) {            \
         extern __shared__ double lds[];                                                                                      \
+        __shared__ int next_instance;                                                                                        \
         double* gws = s.gws + (size_t)blockIdx.x * gws_len;                                                                  \
-        for (int b = blockIdx.x; b < c.B; b += gridDim.x) solve_window_t<POLISH, __VA_ARGS__>(c, s, b, kstart, K, lds, gws);  \
+        DEKF_WG_TRACE_BEGIN                                                                                                  \
+        LOOP(solve_window_t<POLISH, __VA_ARGS__>(c, s, b, kstart, K, lds, gws))                                              \
+        solve_queue_leave(s);                                                                                                \
+        DEKF_WG_TRACE_END                                                                                                    \
     }
 #ifdef DEKF_NO_POLISH_KERNELS  // (A/B and diagnostic builds: half the compile time; osqp.polish true is then refused by the stubs' owner, dekf_create)
 #define DEKF_SOLVE_KERNEL_BODY(NAME, WAVES, ...)            \
@@ -182,6 +259,26 @@ __global__ void __launch_bounds__(64, DEKF_ASM_WAVES) k_mhe_marginalize_early(De
 // two-workgroup kernel
 DEKF_SOLVE_KERNEL_IF(0, k_mhe_solve_ll_4_n20, 2, 4, true, true, 20)
 DEKF_SOLVE_KERNEL_IF(0, k_mhe_solve_r3_4_n20, DEKF_R3_WAVES, 4, true, true, 20, 0, true)
+// the same full windows on workgroups of THREE wavefronts at FOUR per CU (round 6; mhe_admm_core.h: admm_chunk_r4, SolveLayout::r4_*)
+#ifdef DEKF_NO_POLISH_KERNELS
+#define DEKF_SOLVE_KERNEL_R4(NAME, ...)                                              \
+    DEKF_SOLVE_KERNEL_BODY_T_(NAME, DEKF_R4_THREADS, DEKF_QUEUE_LOOP_DYNAMIC, DEKF_R3_WAVES, false, __VA_ARGS__) \
+    __global__ void NAME##_pol(DevCfg, DevState, int, int, int) {}
+#else
+#define DEKF_SOLVE_KERNEL_R4(NAME, ...)                                              \
+    DEKF_SOLVE_KERNEL_BODY_T_(NAME, DEKF_R4_THREADS, DEKF_QUEUE_LOOP_DYNAMIC, DEKF_R3_WAVES, false, __VA_ARGS__) \
+    DEKF_SOLVE_KERNEL_BODY_T_(NAME##_pol, DEKF_R4_THREADS, DEKF_QUEUE_LOOP_DYNAMIC, DEKF_R3_WAVES, true, __VA_ARGS__)
+#endif
+#if DEKF_KSET & 1
+DEKF_SOLVE_KERNEL_R4(k_mhe_solve_r4_4_n20, 4, true, false, 20, 0, true)
+#else
+DEKF_STUB_KERNEL(k_mhe_solve_r4_4_n20)
+#endif
+#if DEKF_KSET & 2
+DEKF_SOLVE_KERNEL_R4(k_mhe_solve_r4_2_n20, 2, true, false, 20, 0, true)
+#else
+DEKF_STUB_KERNEL(k_mhe_solve_r4_2_n20)
+#endif
 // Cassie (2 legs, N = 20; its factor-time temporary does not fit next to the vectors: _lg placement)
 DEKF_SOLVE_KERNEL_IF(1, k_mhe_solve_lg_2_n20, 2, 2, true, false, 20)
 DEKF_SOLVE_KERNEL_IF(1, k_mhe_solve_r3_2_n20, DEKF_R3_WAVES, 2, true, true, 20, 0, true)
@@ -204,6 +301,7 @@ DEKF_SOLVE_KERNELS_FOOT(8, 3)
 DEKF_SOLVE_KERNELS_FOOT(9, 4)
 
 #if DEKF_MISC_KERNELS
+__global__ void k_gap() {}
 __global__ void __launch_bounds__(64) k_kf_initialize(DevCfg c, DevState s) {
     extern __shared__ double lds[];
     kf_initialize(c, s, blockIdx.x, lds);

@@ -391,7 +391,8 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha, int lane_in = -1) {
     // the x blocks of x and D: inside the full variable vector (stride SV per step), or compact (R3: [K][9] in LDS)
     constexpr int XST = Q::R3 ? 9 : SV;
     dptr xs = q.xs, xd = q.xd, x = Q::R3 ? q.xb : q.x;
-    cdptr Dx = q.D;  // (always inside the full scaling vector: stride SV)
+    cdptr Dx = Q::R4 ? q.Dxb : q.D;  // inside the full scaling vector (stride SV); R4: the compact LDS copy of the x blocks' entries (D is in the slab)
+    constexpr int DST = Q::R4 ? 9 : SV;
     struct Ops { double w[9], rhs; };
     // ---------------- forward: step s = 1..M
     cdptr fm = (leg ? q.Wk : q.Sinv) + ((top ? 0 : (leg ? K - 2 : K - 1)) * 81 + 9 * i);  // block of step 1
@@ -438,7 +439,7 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha, int lane_in = -1) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) w[t] = W[t * wst];
         const int blk = top ? M : M + 1;                          // rows 0 / 1 own blocks M / M + 1
-        const double dm = Dx[blk * SV + i], xm = x[blk * XST + i];
+        const double dm = Dx[blk * DST + i], xm = x[blk * XST + i];
         const double f0 = all_rows_from_row0(v), f1 = all_rows_from_row1(v);
         const double src = (row == 0 || row == 3) ? f0 : f1;
         const double part = -chain_matvec_dpp(src, w, 0.0);       // (chain_matvec_dpp returns rhs - W v)
@@ -457,8 +458,8 @@ DEKF_FN void sweeps_one_wave(Q& q, double alpha, int lane_in = -1) {
         const int b0 = top ? M : M + 1;
         dptr xdp = own ? xd + 9 * b0 + i : dummy;       // the leg's start block; step s is at +- s blocks
         dptr xp = own ? x + b0 * XST + i : dummy;
-        cdptr Dp = own ? Dx + b0 * SV + i : dummy;
-        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0, dstep = own ? (top ? -SV : SV) : 0;
+        cdptr Dp = own ? Dx + b0 * DST + i : dummy;
+        const int xdstep = own ? (top ? -9 : 9) : 0, xstep = own ? (top ? -XST : XST) : 0, dstep = own ? (top ? -DST : DST) : 0;
         cdptr Wp = q.Wk + M * 81 + i;              // row 0: W_{M-s}', row 1: W^_{M+s}'
         const int wstep = top ? -81 : 81;
         auto bload = [&](int s, Bops& o) {
@@ -1791,6 +1792,118 @@ DEKF_FN void admm_chunk_r3(Q& q, int iters, double alpha, double sigma) {
         else worker(std::integral_constant<int, 2>{});
     }
 #undef DEKF_R3_T
+    DEKF_PROF_MARK(q, 9);
+    DEKF_SYNC();
+    q.cold = false;
+    DEKF_PROF_MARK(q, 15);
+}
+
+// ---------------------------------------------------------------- four workgroups of THREE wavefronts per CU (R4, round 6)
+// The three-workgroup kernel's workers wait three quarters of an iteration for the solve wavefront; a CU holds 12 wavefronts at 168
+// VGPRs either way.  Here a workgroup is the solve wavefront plus TWO workers that carry the three row tiles and the three x-column
+// tiles between them, so that a CU holds FOUR solves (one solve wavefront per SIMD) instead of three:
+//   wavefront 1   the Dyn lane pairs (the long pole of the row phase)             + the velocity columns (the longest gather)
+//   wavefront 2   the first 64 Meas leg blocks, then VO / bias / remaining Meas   + the position and the bias columns
+// Same barriers, same per-block arithmetic and the same owners' stores as admm_chunk_r3: bit-identical iterates.  LDS holds only what
+// an iteration shares (SolveLayout::r4_*: 38.5 KiB); D, E, the stash of y / z and the factor-time product live in the slab.
+template <int NF, class Q>
+DEKF_FN void admm_chunk_r4(Q& q, int iters, double alpha, double sigma) {
+    constexpr int L = Q::LEGS;
+    static_assert(3 * NF <= 64 && 2 * (NF - 1) <= 64, "one tile per kind");
+    static_assert(NF * L <= 64 || (NF * L - 64) + 2 * (NF - 1) <= 64, "the Meas blocks beyond 64 fit the VO / bias tile");
+    const int w = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), lane = DEKF_LANE() & 63;
+#if defined(DEKF_PROFILE_TL)
+#define DEKF_R4_T(var) const long long var = clock64()
+#else
+#define DEKF_R4_T(var) ((void)0)
+#endif
+    if (w == 0) {
+        DEKF_SYNC();  // B0: w, gb of the (re)start complete
+        DEKF_PROF_MARK(q, 14);
+        for (int it = 0; it < iters; ++it) {
+            DEKF_R4_T(t0);
+            DEKF_SYNC();  // B1
+            DEKF_R4_T(t1);
+            __builtin_amdgcn_s_setprio(3);
+            sweeps_one_wave<NF>(q, alpha, lane);
+            __builtin_amdgcn_s_setprio(0);
+#if defined(DEKF_PROFILE_TL)
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            DEKF_R4_T(t2);
+            DEKF_SYNC();  // B2
+            DEKF_SYNC();  // B3
+            DEKF_R4_T(t3);
+            DEKF_TL_ADD(q, 0, t1, t2);
+            DEKF_TL_ADD(q, 4, t2, t3);
+            DEKF_TL_ADD(q, 8, t0, t1);
+        }
+    } else if (w == 1) {
+        RowRegsT<1> t;
+        row_regs_load<1>(q, lane, sigma, t);
+        DEKF_SYNC();  // B0
+        const bool cold = q.cold;
+        XcolRegs<1> xc;
+        xcols_regs_load<1>(q, lane, xc);
+        for (int it = 0; it < iters; ++it) {
+            DEKF_R4_T(t0);
+            xcols_regs_tile<1>(q, xc, sigma);
+#if defined(DEKF_PROFILE_TL)
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            DEKF_R4_T(t1);
+            DEKF_SYNC();  // B1
+            DEKF_SYNC();  // B2
+            DEKF_R4_T(t2);
+            row_regs_iter<1>(q, t, alpha, sigma, cold && it == 0 && !q.polishing());
+#if defined(DEKF_PROFILE_TL)
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            DEKF_R4_T(t3);
+            DEKF_SYNC();  // B3
+            DEKF_TL_ADD(q, w, t0, t1);
+            DEKF_TL_ADD(q, 4 + w, t2, t3);
+            DEKF_TL_ADD(q, 8 + w, t1, t2);
+        }
+        row_regs_store<1>(q, t);
+    } else {
+        RowRegsT<0> ta;
+        RowRegsT<2> tb;
+        row_regs_load<0>(q, lane, sigma, ta);
+        row_regs_load<2>(q, lane, sigma, tb);
+        DEKF_SYNC();  // B0
+        const bool cold = q.cold;
+        XcolRegs<0> xa;
+        XcolRegs<2> xb;
+        xcols_regs_load<0>(q, lane, xa);
+        xcols_regs_load<2>(q, lane, xb);
+        for (int it = 0; it < iters; ++it) {
+            DEKF_R4_T(t0);
+            xcols_regs_tile<0>(q, xa, sigma);
+            xcols_regs_tile<2>(q, xb, sigma);
+#if defined(DEKF_PROFILE_TL)
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            DEKF_R4_T(t1);
+            DEKF_SYNC();  // B1
+            DEKF_SYNC();  // B2
+            DEKF_R4_T(t2);
+            const bool fc = cold && it == 0 && !q.polishing();
+            row_regs_iter<0>(q, ta, alpha, sigma, fc);
+            row_regs_iter<2>(q, tb, alpha, sigma, fc);
+#if defined(DEKF_PROFILE_TL)
+            __builtin_amdgcn_s_waitcnt(0);
+#endif
+            DEKF_R4_T(t3);
+            DEKF_SYNC();  // B3
+            DEKF_TL_ADD(q, w, t0, t1);
+            DEKF_TL_ADD(q, 4 + w, t2, t3);
+            DEKF_TL_ADD(q, 8 + w, t1, t2);
+        }
+        row_regs_store<0>(q, ta);
+        row_regs_store<2>(q, tb);
+    }
+#undef DEKF_R4_T
     DEKF_PROF_MARK(q, 9);
     DEKF_SYNC();
     q.cold = false;

@@ -122,6 +122,26 @@ struct SolveLayout {
         const size_t granule = 1536, need = (r3_lds_bytes() + static_lds + granule - 1) / granule * granule;
         return ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && DEKF_R3_WAVES * need <= 160 * 1024;
     }
+    // Four-workgroup placement (R4, round 6; mhe_admm_core.h: admm_chunk_r4): workgroups of THREE wavefronts (the solve + two
+    // workers) at four per CU = 12 wavefronts per CU = the 168 VGPRs of the three-workgroup kernels.  LDS holds only what an
+    // ITERATION shares between lanes; what the rare phases read (D, E, the factor-time product, the stash of y and of the VO rows'
+    // z between chunks) lives in the workgroup's slab:
+    //   R | xb | xd | at (= the stash of the slack x between chunks) | xs | gb | pad (-> 4928 doubles) | tmp | Sinv | Wk
+    // The compact copy of the x blocks' scaling that the solve wavefront reads in every step (Dxb, [K][ns]) ends at tmp + 96: the
+    // pad and the first Gauss-Jordan scratch, free between factorisations (rebuilt after each).  During the Ruiz passes D | E sit in
+    // xb .. pad (dead until the cold start) and go to the slab afterwards.
+    static constexpr int R4_DOUBLES = 4928;  // (160 KiB / 4 in 1536 B granules, less 512 B of static LDS)
+    static constexpr int R4_DXB_IN_TMP = 96;
+    DEKF_HD int r4_iter_doubles() const { return 9 * K + ns * K + (2 * ns * K + m_pad + 3 * K) + solve_tmp_len(ns) + 2 * K * ns * ns; }
+    DEKF_HD int r4_pad() const { return R4_DOUBLES - r4_iter_doubles(); }
+    DEKF_HD size_t r4_lds_bytes() const { return (size_t)R4_DOUBLES * 8; }
+    DEKF_HD bool r4_fits(int L, size_t static_lds = 512) const {
+        const int ps = K * (6 * L + 27) + ns * (ns + 1) / 2;
+        const size_t granule = 1536, need = (r4_lds_bytes() + static_lds + granule - 1) / granule * granule;
+        return ns == 9 && r4_pad() >= 0 && r4_pad() + R4_DXB_IN_TMP >= ns * K &&                  // Dxb
+               n_pad + m_pad <= ns * K + 2 * ns * K + m_pad + 3 * K + r4_pad() &&                   // D | E during the Ruiz passes
+               ps + 2 * n_pad + m_pad <= 2 * K * ns * ns && 4 * need <= 160 * 1024;
+    }
     // Rows in registers at a run-time horizon with the factor in the slab (RR, mhe_admm_core.h: admm_chunk_rr):
     //   R | D | E | xb | xd | at (= the stash of the slack x between chunks) | xs | gb | tmp
     // The stash of y and of the VO rows' z between chunks, the scaled bounds, the slack-block inverses and the factor live in the slab;
@@ -179,8 +199,10 @@ DEKF_FN double mul_rounded(double a, double b) {
     return p;
 }
 
-template <int L, int NF = 0, bool FLDS = true, int FT = 0, bool R3_ = false, bool POLISH_ = false>
+template <int L, int NF = 0, bool FLDS = true, int FT = 0, bool R3_ = false, bool POLISH_ = false, bool R4_ = false>
 struct SolveCtx {
+    static constexpr bool R4 = R4_;  // four workgroups of three wavefronts per CU (round 6): R3's split with D, E and the factor-time product in the slab
+    static constexpr int WAVES = R4_ ? 3 : 4;  // wavefronts of the workgroup
     static constexpr bool POLISH = POLISH_;  // the kernel carries OSQP's polishing step (its own instantiations, k_mhe_solve_*_pol:
                                              // the code behind it costs the others 87 spilled VGPRs when it is merely compiled in)
     static constexpr bool R3 = R3_;  // three workgroups per CU: row state in registers, x blocks compact in LDS (xb)
@@ -196,6 +218,7 @@ struct SolveCtx {
     // LDS always
     dptr x, z, y, xt, zt, at, xs, xd, tmp;
     dptr xb;       // R3: the x blocks of x, [K][NS], the only part of x an iteration shares between lanes
+    dptr Dxb;      // R4: the scaling of the x blocks, compact [K][NS] in LDS (D itself is in the slab); rebuilt after every factorisation
     dptr sx, sy, sz;  // R3: where the row state rests between chunks, by row: slack x (= at), y, z of the VO rows (from the first VO row)
     bool cold;        // R3: no chunk has run yet (x = z = y = 0)
     dptr cf;  // per row rho E D (aliases xt, which only the factorisation uses otherwise)
@@ -283,6 +306,10 @@ DEKF_FN void stage_p(Q& q) {
         if (e < K * PS) {
             int k = e / PS, o = e - k * PS;
             cdptr r = q.rec(k);
+            // INVARIANT: Qd | Qc of the NEWEST record (k = K - 1) are not read.  They are the gains of a step whose successor does not
+            // exist yet — no consumer uses them (every one guards k < K - 1) — and k_mhe_marginalize_early of the NEXT step writes them
+            // on another stream while this solve runs (mhe_assemble_core.h: gains_of_previous_step).  Zeros in their place.
+            if (k == K - 1 && o >= 6 * L && o < 6 * L + 27) { Pst[e] = 0.0; return; }
             // [Qm 6L | Qd 21 | Qc 6 | Qf 6L (foot states)]: the last block is contiguous with Qm in the record
             Pst[e] = ld_stream(r, o < 6 * L ? Rec::qm(NM) + o
                                              : (o < 6 * L + 21 ? Rec::QD + o - 6 * L : (o < 6 * L + 27 ? Rec::QC + o - 6 * L - 21 : Rec::qf(NM) + o - 6 * L - 27)));
@@ -680,7 +707,26 @@ DEKF_FN void solve_scale(Q& q) {
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)  // per-wavefront: tile phase | wait at its barrier | x_0 norms + sum (slots 24.., 28.., 20..)
             const long long tr0 = clock64();
 #endif
-            for (int t = rz_wave; t < ntiles; t += rz_nw) psum += fused(t, rz_lane, cc, Dr, Er, Dw, Ew);
+            // Three-wavefront workgroups (R4): the sum of the column norms keeps the association of the four-wavefront kernels — tile t
+            // belongs to "virtual wavefront" t & 3, whose lanes add up their tiles and are then summed by DPP — so that the cost scaling
+            // c, and with it every later bit, does not depend on the workgroup's shape.  A physical wavefront hosts whole virtual ones
+            // (RZ_PW: the virtual wavefront with the Dyn lane-pair tile, the longest, alone); the x-column tiles contribute exactly 0.0
+            // to the sum and go wherever the load is lightest.
+            constexpr bool RZ3 = Q::WAVES == 3;
+            constexpr int RZ_PW[4] = {0, Q::LEGS == 4 ? 1 : 2, Q::LEGS == 4 ? 2 : 1, Q::LEGS == 4 ? 1 : 0};
+            const int rz_nrow = ntm + ntp + 2 * ntd + ntf;
+            auto rz_phys = [&](int t) { return t < rz_nrow ? RZ_PW[t & 3] : 2 - (t - rz_nrow) % 3; };
+            double pv[4] = {0.0, 0.0, 0.0, 0.0};
+            if constexpr (RZ3) {
+                for (int t = 0; t < ntiles; ++t) {
+                    if (rz_phys(t) != rz_wave) continue;  // (scalar)
+                    const double f = fused(t, rz_lane, cc, Dr, Er, Dw, Ew);
+                    const int v = t & 3;
+                    pv[0] += v == 0 ? f : 0.0; pv[1] += v == 1 ? f : 0.0; pv[2] += v == 2 ? f : 0.0; pv[3] += v == 3 ? f : 0.0;
+                }
+            } else {
+                for (int t = rz_wave; t < ntiles; t += rz_nw) psum += fused(t, rz_lane, cc, Dr, Er, Dw, Ew);
+            }
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
             long long tr1 = 0, tr2 = 0;
 #endif
@@ -692,8 +738,14 @@ DEKF_FN void solve_scale(Q& q) {
             {
                 const int wv = __builtin_amdgcn_readfirstlane(DEKF_LANE() >> 6), ln = DEKF_LANE() & 63;
                 dptr part = q.tmp + 176 + 4 * (it & 1);  // (the Gauss-Jordan scratch, dead during the scaling)
-                psum = wave_sum_dpp(psum);
-                if (ln == 0) part[wv] = psum;
+                if constexpr (RZ3) {
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+                        if (RZ_PW[v] == wv) { const double sv_ = wave_sum_dpp(pv[v]); if (ln == 0) part[v] = sv_; }
+                } else {
+                    psum = wave_sum_dpp(psum);
+                    if (ln == 0) part[wv] = psum;
+                }
 #if defined(DEKF_PROFILE) && defined(DEKF_PROFILE_RUIZ)
                 __builtin_amdgcn_s_waitcnt(0);
                 tr1 = clock64();
@@ -719,9 +771,9 @@ DEKF_FN void solve_scale(Q& q) {
                 const int cpos = j < 3 ? 1 : (j < 6 ? 0 : 2);  // (the order of the column tiles: velocity, position, bias)
                 // (a foot-position column of x_0 sits in lane j - 9 of the first foot-column tile)
                 const int otile = j < 9 ? ntm + ntp + 2 * ntd + cpos * ntx : ntm + ntp + 2 * ntd + 3 * ntx + ntf;
-                if (ln < NS && (otile & (DEKF_NLANES() / WAVE - 1)) == wv) pc[j] = v;
+                if (ln < NS && (RZ3 ? rz_phys(otile) : (otile & (DEKF_NLANES() / WAVE - 1))) == wv) pc[j] = v;
                 const double x0 = wave_sum_dpp(ln < NS ? v : 0.0);
-                const int nw = DEKF_NLANES() >> 6;
+                const int nw = RZ3 ? 4 : DEKF_NLANES() >> 6;
                 double tot = part[0];
                 for (int i = 1; i < nw; ++i) tot += part[i];
                 psum = tot + x0;
@@ -1622,7 +1674,8 @@ template <int NFIX, class Q>
 DEKF_FN void polish_step(Q& q) {
 #if DEKF_DEVICE_BUILD
     if constexpr (Q::R3) {
-        if constexpr (Q::FACTOR_LDS) admm_chunk_r3<NFIX>(q, 1, 1.0, q.sigma());
+        if constexpr (Q::R4) admm_chunk_r4<NFIX>(q, 1, 1.0, q.sigma());
+        else if constexpr (Q::FACTOR_LDS) admm_chunk_r3<NFIX>(q, 1, 1.0, q.sigma());
         else admm_chunk_rr(q, 1, 1.0, q.sigma());
     } else
 #endif
@@ -1707,10 +1760,18 @@ DEKF_FN void polish_accumulate(Q& q, const PolishScratch<Q>& ps) {
     DEKF_SYNC();
 }
 
+// R4: the x blocks' scaling, compact, where the solve wavefront reads it in every step (the Gauss-Jordan scratch it shares is free now)
+template <class Q>
+DEKF_FN void r4_fill_dxb(Q& q) {
+    constexpr int NS = Q::NS, SV = 2 * NS + 3 + 3 * Q::LEGS;
+    wfor(q.K * NS, [&](int e) { const int k = e / NS, j = e - NS * k; q.Dxb[e] = q.D[k * SV + j]; });
+}
+
 struct SolveInfo {
     int iters, status, rho_updates;
     double pri_res, dua_res, rho;
     int polished = 0;  // 0 polishing off or not reached, 1 the polished point was accepted, -1 rejected (the ADMM iterate stays)
+    int next_fetch = 0;  // lane 0 of the workgroup: what the instance queue returned for the workgroup's NEXT instance (kernels.hip: DEKF_QUEUE_LOOP)
 };
 
 // osqp_setup + osqp_solve + extraction.  window = steps kstart .. kstart+K-1 (newest = T).
@@ -1727,8 +1788,10 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     lay.init(NH, L, FT);
     Gws g;
     g.init(NH, L, FT, !FACTOR_LDS && !FT);  // (WT sits behind everything else: a kernel that does not use it sees the layout without it)
-    SolveCtx<L, NFIX, FACTOR_LDS, FT, R3, POLISH> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
+    constexpr bool R4 = R3 && FACTOR_LDS && !PA_LDS;  // four workgroups of three wavefronts per CU (SolveLayout::r4_*)
+    SolveCtx<L, NFIX, FACTOR_LDS, FT, R3, POLISH, R4> q{c, s, b, K, kstart, 0, 0, IdxT<L, FT>(K)};
     q.xb = nullptr;
+    q.Dxb = nullptr;
     q.WT = nullptr;
     {   // carve LDS: iterates first; xt, zt, at adjacent so PA can alias them at factor time.  Every array is handed out with its
         // extent (DEKF_SPAN: a plain pointer in the product builds, a checked one in the -DDEKF_BOUNDS build, wave.h)
@@ -1765,8 +1828,32 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
             q.Sv = gs(g.Sv, NH * 6 * L); q.Sw = gs(g.Sw, NH * SWS); q.Sc = gs(g.Sc, NH * 6);
             q.Wm = gs(g.Wm, NH * 6 * L); q.Wd = gs(g.Wd, NH * 24); q.Wc = gs(g.Wc, NH * 6);
         }
-        if constexpr (R3 && FACTOR_LDS) {
-            static_assert(!R3 || !FACTOR_LDS || (PA_LDS && NFIX != 0 && FT == 0), "R3: fixed horizon, 9 states, factor in LDS");
+        if constexpr (R4) {
+            static_assert(!R4 || (NFIX != 0 && FT == 0), "R4: fixed horizon, 9 states, factor in LDS, everything the rare phases read in the slab");
+            q.R = take(9 * NH);
+            q.xb = take(NS * NH);
+            q.xd = take(NS * NH);
+            q.at = take(lay.m_pad);
+            q.xs = take(NS * NH);
+            q.gb = take(3 * NH);
+            (void)take(lay.r4_pad());
+            q.Dxb = DEKF_SPAN(p + SolveLayout::R4_DXB_IN_TMP - NS * NH, NS * NH);  // ends at tmp + 96 (pad | Gauss-Jordan scratch of side 0)
+            q.tmp = take(TM::LEN);
+            q.Sinv = take(b2K);
+            q.Wk = take(b2K);
+            q.D = gs(g.D, lay.n_pad); q.E = gs(g.E, lay.m_pad);  // (in LDS during the Ruiz passes, below)
+            q.PA = gs(g.PA, b2K);
+            q.sx = q.at;
+            q.sy = gs(g.y, lay.m_pad); q.sz = gs(g.z, lay.m_pad);
+            q.Sf = nullptr; q.Wf = nullptr;
+            q.x = nullptr; q.y = nullptr; q.z = nullptr; q.zt = nullptr; q.cf = nullptr; q.xt = nullptr;
+            q.lo = gs(g.lo, lay.m_pad); q.hi = gs(g.hi, lay.m_pad);
+            q.cold = true;
+            q.Sv = gs(g.Sv, NH * 6 * L); q.Sw = gs(g.Sw, NH * SWS); q.Sc = gs(g.Sc, NH * 6);
+            q.Wm = gs(g.Wm, NH * 6 * L); q.Wd = gs(g.Wd, NH * 24); q.Wc = gs(g.Wc, NH * 6);
+        }
+        if constexpr (R3 && FACTOR_LDS && !R4) {
+            static_assert(!R3 || !FACTOR_LDS || R4 || (PA_LDS && NFIX != 0 && FT == 0), "R3: fixed horizon, 9 states, factor in LDS");
             q.R = take(9 * NH);
             q.D = take(lay.n_pad);
             q.E = take(lay.m_pad);
@@ -1883,6 +1970,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
 #if defined(DEKF_PROFILE) && DEKF_DEVICE_BUILD
     q.prof_last = clock64();
     const long long prof_t0 = q.prof_last;
+    const long long prof_w0 = wall_clock64();  // (constant 100 MHz: slot 23 / slot 13 gives the shader clock the solve really ran at)
     if (DEKF_LANE() == 0)
         for (int i = 0; i < DEKF_PROF_SLOTS; ++i) q.prof[i] = 0.0;
 #endif
@@ -1898,16 +1986,26 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
         q.zt = nullptr; q.xt = nullptr;
         wfor(K * NS, [&](int e) { q.xb[e] = 0.0; });
     } else if constexpr (R3) {
-        // D and E stay in LDS for the whole solve; the Ruiz passes' temporaries pc, En, Dn sit behind the staged P blocks inside
-        // S^-1 | W, which are not live before the first factorisation.
+        // D and E stay in LDS for the whole solve (R4: for the Ruiz passes, in xb .. pad, and go to the slab behind them); the Ruiz
+        // passes' temporaries pc, En, Dn sit behind the staged P blocks inside S^-1 | W, which are not live before the first factorisation.
         constexpr int PSL = NFIX * (6 * L + 27) + NS * (NS + 1) / 2;
         dptr xg = q.x, ztg = nullptr;
         double* const sb = raw_of(q.Sinv);
         q.x = DEKF_SPAN(sb + PSL, lay.n_pad);                            // pc
         q.zt = DEKF_SPAN(sb + PSL + lay.n_pad, lay.m_pad);               // En
         q.xt = DEKF_SPAN(sb + PSL + lay.n_pad + lay.m_pad, lay.n_pad);   // Dn
+        dptr Dg = q.D, Eg = q.E;
+        if constexpr (R4) {
+            q.D = DEKF_SPAN(raw_of(q.xb), lay.n_pad);
+            q.E = DEKF_SPAN(raw_of(q.xb) + lay.n_pad, lay.m_pad);
+        }
         if (c.scaling > 0) solve_scale(q);
         else { wfor(n + m, [&](int e) { if (e < n) q.D[e] = 1.0; else q.E[e - n] = 1.0; }); }
+        if constexpr (R4) {
+            cdptr Dl = q.D, El = q.E;
+            wfor(n + m, [&](int e) { if (e < n) Dg[e] = Dl[e]; else Eg[e - n] = El[e - n]; });
+            q.D = Dg; q.E = Eg;
+        }
         q.x = xg; q.zt = ztg; q.xt = nullptr;
         wfor(K * NS, [&](int e) { q.xb[e] = 0.0; });
     } else {
@@ -1935,6 +2033,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     });
     DEKF_PROF_MARK(q, 19);
     bool ok = solve_factor(q);
+    if constexpr (R4) r4_fill_dxb(q);
     // scaled linear cost on x_0 (LDS copy for the per-lane look-ups)
     wfor(NS, [&](int j) { q.tmp[TM::QSL + j] = q.cc * q.D[ix.x(0, j)] * q.np[j]; });
     const double sigma = c.sigma, alpha = c.alpha;
@@ -1942,6 +2041,11 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     const double eps_rel_cinv = uni_pin(c.eps_rel * cinv);  // (the compiler forms and hoists this product anyway: into a VGPR pair that lives for the whole solve)
     int iter = 0;
     bool done = false;
+#if DEKF_DEVICE_BUILD && DEKF_QUEUE_MODE != 0
+    // The workgroup's next instance, fetched HERE: the first wavefront runs nothing but LDS for the next 25 iterations, so the
+    // atomic's round trip (microseconds when every workgroup of a lock-step round fetches at once) is waited for by nobody
+    if (DEKF_LANE() == 0) info.next_fetch = atomicAdd(s.queue, 1);
+#endif
     if constexpr (!R3) {  // (R3: the first chunk's load of the row blocks is the restart)
     if (ok) phase_rows<true>(q, alpha, sigma);  // cold start: cf, t = 0, w = 0 (the factorisation scratch aliased xt | zt | at)
     }
@@ -1954,7 +2058,8 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
             int nxt = c.max_iter;
             if (c.check_termination > 0) { const int e = (iter / c.check_termination + 1) * c.check_termination; nxt = e < nxt ? e : nxt; }
             if (c.adaptive_rho && c.adaptive_rho_interval > 0) { const int e = (iter / c.adaptive_rho_interval + 1) * c.adaptive_rho_interval; nxt = e < nxt ? e : nxt; }
-            if constexpr (FACTOR_LDS) admm_chunk_r3<NFIX>(q, nxt - iter, alpha, sigma);
+            if constexpr (R4) admm_chunk_r4<NFIX>(q, nxt - iter, alpha, sigma);
+            else if constexpr (FACTOR_LDS) admm_chunk_r3<NFIX>(q, nxt - iter, alpha, sigma);
             else admm_chunk_rr(q, nxt - iter, alpha, sigma);
             iter = nxt;
             DEKF_PROF_MARK(q, 9);
@@ -1994,8 +2099,8 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
                     q.rho = uni_pin(rho_new);
                     info.rho_updates++;
                     DEKF_SYNC();
-                    if constexpr (R3 && FACTOR_LDS) {  // the factorisation's temporaries take the LDS the row state rests in: over to the slab and back
-                        // (RR: the factor-time product lives in the slab, nothing of the factorisation touches the stash)
+                    if constexpr (R3 && FACTOR_LDS && !R4) {  // the factorisation's temporaries take the LDS the row state rests in: over to the slab and back
+                        // (RR, R4: the factor-time product lives in the slab, nothing of the factorisation touches the stash)
                         const int mp = lay.m_pad, nz = 3 * NH;
                         wfor(2 * mp + nz, [&](int e) {
                             if (e < mp) q.x[e] = q.sx[e];
@@ -2004,7 +2109,8 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
                         });
                     }
                     ok = solve_factor(q);
-                    if constexpr (R3 && FACTOR_LDS) {
+                    if constexpr (R4) r4_fill_dxb(q);
+                    if constexpr (R3 && FACTOR_LDS && !R4) {
                         const int mp = lay.m_pad, nz = 3 * NH;
                         wfor(2 * mp + nz, [&](int e) {
                             if (e < mp) q.sx[e] = q.x[e];
@@ -2057,6 +2163,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
             });
         }
         bool okp = solve_factor(q);
+        if constexpr (R4) r4_fill_dxb(q);
         if constexpr (!R3) {
             if (okp) phase_rows<true>(q, 1.0, q.sigma());
         }
@@ -2086,7 +2193,8 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
             // then let a point with pri_res 8.6e-4 (x off by 0.11) — or, on a marginal dual comparison, 3e-7 (x off by 2e-5) — replace an
             // iterate at 1e-9 of the optimum, where OSQP, its own iterate less accurate, rejects the same point.  Here the clause also asks
             // the polished primal residual to be numerically zero: a polished point never trades a primal residual of 1e-11 for one of 1e-7.
-            const bool good = (prp < pri0 && dup < dua0) || (prp < pri0 && dua0 < 1e-10) || (dup < dua0 && pri0 < 1e-10 && prp < 1e-10);
+            // (dekf_params.polish_accept_osqp = 1 restores polish.c's clause verbatim, for strict OSQP parity)
+            const bool good = (prp < pri0 && dup < dua0) || (prp < pri0 && dua0 < 1e-10) || (dup < dua0 && pri0 < 1e-10 && (c.polish_accept_osqp || prp < 1e-10));
             double xP[NS];
             bool finp = true;
             for (int j = 0; j < NS; ++j) {
@@ -2133,7 +2241,7 @@ DEKF_FN SolveInfo solve_window_t(const DevCfg& c, const DevState& s, int b, int 
     DEKF_SYNC();
 #if defined(DEKF_PROFILE) && DEKF_DEVICE_BUILD
     DEKF_PROF_MARK(q, 12);
-    if (DEKF_LANE() == 0) q.prof[13] = (double)(clock64() - prof_t0);
+    if (DEKF_LANE() == 0) { q.prof[13] = (double)(clock64() - prof_t0); q.prof[23] = (double)(wall_clock64() - prof_w0); }
 #endif
     return info;
 }

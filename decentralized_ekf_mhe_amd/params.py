@@ -34,6 +34,7 @@ class DekfParams(C.Structure):
         ("ekf_vo_meas_std", D4), ("ekf_quaternion_init", D4),
         ("ekf_rate", C.c_int), ("ekf_history", C.c_int),
         ("polish_refine_iter", C.c_int), ("arrival_cost_form", C.c_int), ("solve_pipeline", C.c_int), ("solve_workgroups_per_cu", C.c_int),
+        ("polish_accept_osqp", C.c_int),
     ]
 
     def copy(self):
@@ -89,7 +90,7 @@ def go1_params():
     _set(p.ekf_quaternion_init, [1.0, 0.0, 0.0, 0.0])
     p.ekf_rate, p.ekf_history = 500, 256
     p.polish_refine_iter = 3
-    p.arrival_cost_form, p.solve_pipeline, p.solve_workgroups_per_cu = 0, 0, 0
+    p.arrival_cost_form, p.solve_pipeline, p.solve_workgroups_per_cu, p.polish_accept_osqp = 0, 0, 0, 0
     return p
 
 

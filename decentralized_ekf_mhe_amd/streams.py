@@ -79,9 +79,14 @@ def leg_kinematics(q, leg, nj):
 
 
 def make_streams(params, batch, nsteps, first_instance=0, vo=True, vo_rate=30.0, vo_latency=0.03,
-                 seed0=SEED0, gait_hz=2.0):
+                 seed0=SEED0, gait_hz=2.0, desync=False):
     """Return a dict of [nsteps][batch][...] arrays (+ ground truth under 'gt_*').  gait_hz: contact cycles per second
-    (2 Hz trot, 60 % duty); the long-run parity cases raise it to pack more swing phases into a log."""
+    (2 Hz trot, 60 % duty); the long-run parity cases raise it to pack more swing phases into a log.
+    desync: a fleet that is NOT in lock-step, as the reference deploys it — every robot's camera runs on its own clock
+    (EstSub.cpp:45-56: vo_callback latches whenever ITS front-end delivers), so per instance the VO frame phase is U[0, 1 / vo_rate),
+    the delivery latency U[10, 60] ms and the gait 1-3 Hz (drawn from a second generator per instance: the default streams keep
+    their bits); desync=2 additionally draws every camera's frame rate from U[5, 50] Hz and leaves every tenth robot without vision.
+    With the default the whole batch receives its vision intervals at the same ticks."""
     L, nj = params.num_legs, params.joints_per_leg
     dt = 1.0 / params.rate
     B, K = batch, nsteps
@@ -89,6 +94,22 @@ def make_streams(params, batch, nsteps, first_instance=0, vo=True, vo_rate=30.0,
     ph = np.stack([r.uniform(0, 2 * np.pi, 8) for r in rngs])  # [B, 8]
     bias = np.stack([r.normal(0, 0.05, 3) for r in rngs])  # [B, 3]
 
+    if desync:
+        rng2 = [np.random.default_rng(seed0 + 0x10000000 + first_instance + i) for i in range(B)]
+        vo_phase = np.array([r.uniform(0.0, 1.0 / vo_rate) for r in rng2])
+        vo_lat = np.array([r.uniform(0.010, 0.060) for r in rng2])
+        gait_hz = np.array([r.uniform(1.0, 3.0) for r in rng2])  # [B]
+        vo_rate_b = np.full(B, float(vo_rate))
+        if desync == 2:  # ... and a MIXED fleet: every camera at its own frame rate, U[5, 50] Hz, every tenth robot blind
+            vo_rate_b = np.array([r.uniform(5.0, 50.0) for r in rng2])
+            vo_phase = vo_phase * vo_rate / vo_rate_b
+            blind = np.array([r.uniform() < 0.1 for r in rng2])
+            vo_phase = np.where(blind, 1e9, vo_phase)
+    else:
+        vo_phase = np.zeros(B)
+        vo_lat = np.full(B, float(vo_latency))
+        vo_rate_b = np.full(B, float(vo_rate))
+    gait_b = np.broadcast_to(np.asarray(gait_hz, dtype=np.float64), (B,))
     k = np.arange(K)[:, None]  # [K,1]
     jitter = np.stack([r.uniform(0, 0.2e-3, K) for r in rngs], axis=1)  # [K,B]
     t = k * dt + 0 * ph[None, :, 0]  # [K,B] nominal time
@@ -140,9 +161,9 @@ def make_streams(params, batch, nsteps, first_instance=0, vo=True, vo_rate=30.0,
     nominal = np.array([0.0] + [0.8, -1.6] * nj)[:nj]
     n_qd = np.stack([r.normal(0, 1.0, (K, L, nj)) for r in rngs], axis=1)
     for leg in range(L):
-        cyc = (gait_hz * t + gait_phase[leg] + ph[:, 5] / (2 * np.pi)) % 1.0
+        cyc = (gait_b * t + gait_phase[leg] + ph[:, 5] / (2 * np.pi)) % 1.0
         contact[:, :, leg] = (cyc < 0.6).astype(np.float64)
-        q = nominal + 0.3 * np.sin(2 * np.pi * gait_hz * t[..., None] + ph[:, 6, None] + leg + np.arange(nj))
+        q = nominal + 0.3 * np.sin(2 * np.pi * gait_b[:, None] * t[..., None] + ph[:, 6, None] + leg + np.arange(nj))
         q_joint[:, :, leg] = q
         p, Jl = leg_kinematics(q, leg, nj)
         p_foot[:, :, leg] = p
@@ -168,26 +189,29 @@ def make_streams(params, batch, nsteps, first_instance=0, vo=True, vo_rate=30.0,
     if vo:
         n_dp = [r.normal(0, 1.5e-5, (K, 3)) for r in rngs]
         n_q = [r.normal(0, 1e-4, (K, 4)) for r in rngs]
-        nframes = int(np.floor((K - 1) * dt * vo_rate)) + 1
+        nframes = int(np.floor((K - 1) * dt * float(np.max(vo_rate_b)))) + 1
+        ib = np.arange(B)
         for f in range(1, nframes):
-            t_pre, t_now = (f - 1) / vo_rate, f / vo_rate
-            kk = int(np.ceil((t_now + vo_latency) / dt - 1e-9))
-            if kk >= K:
+            tp = vo_phase + (f - 1) / vo_rate_b                                 # [B]: every instance's own camera clock
+            tn = vo_phase + f / vo_rate_b
+            kk = np.ceil((tn + vo_lat) / dt - 1e-9).astype(np.int64)            # the tick at which the pair is delivered
+            ok = kk < K
+            if not ok.any():
                 break
-            tp = np.full(B, t_pre)
-            tn = np.full(B, t_now)
             r_, p_, y_, _, _, _ = euler(tp)
             R_pre = _rot_zyx(y_, p_, r_)
             r2, p2, y2, _, _, _ = euler(tn)
             q_now = _quat_from_rot(_rot_zyx(y2, p2, r2))
-            dp = np.einsum("bji,bj->bi", R_pre, pos(tn) - pos(tp))
-            vo_mask[kk] = 1
-            vo_t_pre[kk] = t_pre
-            vo_t_now[kk] = t_now
-            vo_t_pose[kk] = t_now
-            vo_dp[kk] = dp + np.stack([n[f] for n in n_dp])
+            dp = np.einsum("bji,bj->bi", R_pre, pos(tn) - pos(tp)) + np.stack([n[f] for n in n_dp])
             qn = q_now + np.stack([n[f] for n in n_q])
-            vo_q[kk] = qn / np.linalg.norm(qn, axis=-1, keepdims=True)
+            qn = qn / np.linalg.norm(qn, axis=-1, keepdims=True)
+            kv, iv = kk[ok], ib[ok]
+            vo_mask[kv, iv] = 1
+            vo_t_pre[kv, iv] = tp[ok]
+            vo_t_now[kv, iv] = tn[ok]
+            vo_t_pose[kv, iv] = tn[ok]
+            vo_dp[kv, iv] = dp[ok]
+            vo_q[kv, iv] = qn[ok]
     out.update(vo_mask=vo_mask, vo_t_pre=vo_t_pre, vo_t_now=vo_t_now, vo_dp=vo_dp,
                vo_t_pose=vo_t_pose, vo_q=vo_q)
     for key, val in out.items():

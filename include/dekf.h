@@ -32,7 +32,8 @@
 extern "C" {
 #endif
 
-#define DEKF_ABI_VERSION 3 /* 3: osqp.polish implemented: dekf_params.polish_refine_iter, dekf_get_polish_status;
+#define DEKF_ABI_VERSION 4 /* 4: dekf_params.polish_accept_osqp (appended), solve_workgroups_per_cu = 4 selects the four-per-CU kernels;
+                            * 3: osqp.polish implemented: dekf_params.polish_refine_iter, dekf_get_polish_status;
                             * 2: dekf_params.solve_workgroups_per_cu, dekf_solve_kernel_name, dekf_launch_info; dim_state-sized rows */
 #define DEKF_MAX_LEGS 4
 #define DEKF_MAX_JOINTS 8 /* joints per leg */
@@ -75,7 +76,13 @@ typedef struct dekf_params {
     int leg_odom_type;  /* 0: foot-velocity measurements, dim_state 9.  1: foot positions are states,
                          * dim_state = 9 + 3 num_legs (21 on Go1), DecentralEst.cpp:20.  How the arrival cost of type 1 is
                          * updated is chosen by `arrival_cost_form` below; its default (0) is the reference's covariance-form
-                         * saddle inverse (MheSrb.cpp:527-651). */
+                         * saddle inverse (MheSrb.cpp:527-651).
+                         * CONTRACT of type 1: the BASE states (p, v, accel bias: what the node logs and publishes) are inside the
+                         * 1e-4 relative tolerance of the reference formula (measured 0.16 x of it over 32 x 2000 ticks); the
+                         * FOOT-POSITION states are OUTSIDE that contract: <= 3 x the tolerance (measured 1.83 x; form 1: <= 5 x,
+                         * measured 3.24 x).  The reference formula itself moves by 1.5 x the tolerance on those states when its
+                         * 33-dim saddle inverse is evaluated in another pivot order (a 1e20 - 1e20 cancellation at every
+                         * touch-down, DecentralEst.cpp:432-451, 550-563; MheSrb.cpp:527-651) — INTEGRATION.md section 5. */
     double joint_position_std[DEKF_MAX_JOINTS];
     double joint_velocity_std[DEKF_MAX_JOINTS];
     double foot_slide_std[3];
@@ -122,13 +129,23 @@ typedef struct dekf_params {
                                      * B = 4096 (2.19 M against 2.14 M steps/s), +4 ... +6 % on the other shapes at 1024-4096, more below (EXPERIMENTS.md round 5 section 8): it hides the 0.09 ms of EKF + term
                                      * construction + launch gaps in front of every solve and the partly empty last round.  The two solve streams are created
                                      * at the greatest stream priority (their own hardware-queue class). */
-    int solve_workgroups_per_cu;    /* 0: as many as the CU holds (3 for full Go1 / Cassie windows when the batch exceeds the 512
+    int solve_workgroups_per_cu;    /* 0: the default residency (3 for full Go1 / Cassie windows when the batch exceeds the 512
                                      * slots of the two-workgroup kernels, 2 for full PogoX windows above 256); 1 or 2: cap — 2
-                                     * keeps the two-workgroup solve kernels for full windows too.  A launch-tuning knob only: every
+                                     * keeps the two-workgroup solve kernels for full windows too; 4 (round 6, Go1 / Cassie full
+                                     * windows, batches above 512): workgroups of THREE wavefronts at four per CU
+                                     * (k_mhe_solve_r4_*): +36 / +12 / +7 % at 1024 / 2048 / 3072 robots, +-1 % from 4096 on, where
+                                     * the hardware leaves 2-9 % of these workgroups unplaced until others finish
+                                     * (profiles/r06_go1_four_per_cu_3waves.txt) — an opt-in for fleets of 800-3000 robots per GPU.
+                                     * A launch-tuning knob only: every
                                      * kernel family produces the SAME BITS for a given robot log (since round 5 the iteration phases
                                      * are compiled with floating-point contraction off and explicit fma; tests/test_gpu_configs.py
                                      * holds r3 == ll, r3 == lg and rr == gg with array_equal), so a robot's estimate does not depend
                                      * on the size of the fleet it is batched with. */
+    int polish_accept_osqp;         /* osqp.polish only.  0 (default): OSQP's acceptance test for a polished point with its third clause
+                                     * made symmetric — `pol_dua < dua && pri < 1e-10 && pol_pri < 1e-10` — so that a polished point never
+                                     * trades a primal residual of 1e-11 for one of 1e-7 (this solver's iterates
+                                     * reach that clause where OSQP's own do not).  1: polish.c's test verbatim
+                                     * (`pol_dua < dua && pri < 1e-10`), for strict OSQP parity. */
 } dekf_params;
 
 typedef struct dekf_handle_s* dekf_handle;

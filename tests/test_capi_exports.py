@@ -20,7 +20,7 @@ def test_every_declared_symbol_is_exported():
     missing = [n for n in names if not hasattr(lib, n)]
     assert not missing, missing
     assert set(names) == set(capi.PROTOTYPES), set(names) ^ set(capi.PROTOTYPES)
-    assert lib.dekf_abi_version() == capi.DEKF_ABI_VERSION == 3
+    assert lib.dekf_abi_version() == capi.DEKF_ABI_VERSION == 4
 
 
 def test_default_params_match_python_and_yaml_values():

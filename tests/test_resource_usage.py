@@ -22,6 +22,11 @@ DESIGN_POINTS = {
     # three workgroups per CU: 7 spilled VGPRs at the end of round 4, none of them in an iteration loop
     "k_mhe_solve_r3_4_n20": (168, 3, 16),
     "k_mhe_solve_r3_2_n20": (168, 3, 16),
+    # four workgroups of three wavefronts per CU (round 6, opt-in: solve_workgroups_per_cu = 4): the same 168-VGPR budget; the worker
+    # that carries two row tiles spills a few more (16 / 14; the polishing twin 68)
+    "k_mhe_solve_r4_4_n20": (168, 3, 24),
+    "k_mhe_solve_r4_2_n20": (168, 3, 24),
+    "k_mhe_solve_r4_4_n20_pol": (168, 3, 96),
     # rows in registers at a run-time horizon, two workgroups per CU: spill-free (40 spilled VGPRs inside its loops with machine LICM on)
     "k_mhe_solve_rr_1": (256, 2, 0),
     # window-fill ticks of the benchmark shapes

@@ -48,13 +48,14 @@ def measured_traffic(kernel, batch):
     return d.get("hbm_bytes_per_launch"), f"profiles/traffic_{kernel}.json"
 
 
-def run(name, maker, B, steps, pipelined_leg=True, **kw):
+def run(name, maker, B, steps, pipelined_leg=True, streams_kw=None, **kw):
     p = maker()
     p.ekf_rate = p.rate
     for k, v in kw.items():
         setattr(p, k, v)
     W = max(p.N + 10, 64)   # (past the transient of the first vision intervals: ticks 40-56 on the N = 20 shapes, see bench.py)
-    s = make_streams(p, B, W + steps)
+    HIST = 16 if streams_kw else 0   # ticks behind the timed region whose iteration counts are read (a read synchronises: not in the timed region)
+    s = make_streams(p, B, W + steps + HIST, **(streams_kw or {}))
     sd = streams_to_device(s)
     est = BatchedEstimator(p, B)
     # as bench.py: the small kernels are timed over the last warm-up steps, the timed region brackets only the solve launches
@@ -86,6 +87,18 @@ def run(name, maker, B, steps, pipelined_leg=True, **kw):
     o = est.get()
     kernel = est.solve_kernel_name(True)
     li = est.launch_info()
+    hist = None
+    if HIST:  # ADMM iterations per instance and launch: how far from lock-step the fleet is
+        import numpy as np
+        its = []
+        for k in range(W + steps, W + steps + HIST):
+            est.push_stream_step(sd, k)
+            est.step(k)
+            its.append(est.solver_info()["iters"].copy())
+        its = np.array(its)
+        vals, cnt = np.unique(its, return_counts=True)
+        hist = {"iterations": {int(v): round(float(c) / its.size, 4) for v, c in zip(vals, cnt)}, "mean": float(its.mean()),
+                "max_over_mean_per_launch": float((its.max(axis=1) / its.mean(axis=1)).mean()), "ticks": HIST}
     est.close()
     piped = None
     if int(p.est_type) == 0 and pipelined_leg:  # the same steps with consecutive steps overlapped (bit-identical results; reported beside the in-order figure)
@@ -127,6 +140,7 @@ def run(name, maker, B, steps, pipelined_leg=True, **kw):
                 "traffic": traffic, "traffic_source": src, "traffic_rate_gbs": (traffic / avg_s / 1e9) if traffic else None}
     print(json.dumps({"shape": name, "roofline": roof, "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items()}, "legs": p.num_legs, "N": p.N, "batch": B, "steps": steps,
                       "estimator_steps_per_s": B * steps / dt, "ms_per_step": 1e3 * dt / steps, "with_step_pipelining_steps_per_s": piped,
+                      "iteration_histogram": hist, "solve_kernel": kernel, "lib": os.environ.get("DEKF_LIB", "product"),
                       "mean_iters": float(info["iters"].mean()), "solved_frac": float((o["status"] == 1).mean()),
                       "polish_accepted_frac": float((info["polish_status"] == 1).mean())}), flush=True)
 
@@ -138,15 +152,22 @@ SHAPES = {  # the single-shape form (profilers put `python3 tools/bench_shapes.p
     "cassie": ("cassie N=20", cassie_params, 4096, 30, {}),
     "pogox": ("pogox N=100", pogox_params, 1024, 12, {}),
     "go1foot": ("go1 with foot-position states (leg_odom_type 1, 21-dim blocks)", go1_params, 4096, 8, dict(leg_odom_type=1)),
+    # a fleet that is not in lock-step (round 6): every robot's camera on its own clock, latency U[10, 60] ms, gait 1-3 Hz (streams.py: desync)
+    "go1_desync": ("go1 N=20, de-synchronised fleet (own camera clock, latency 10-60 ms, gait 1-3 Hz per robot)", go1_params, 4096, 100,
+                   dict(streams_kw=dict(desync=True))),
+    "go1_mixed": ("go1 N=20, MIXED fleet (cameras at 5-50 Hz on their own clocks, every tenth robot blind, gait 1-3 Hz)", go1_params, 4096, 100,
+                  dict(streams_kw=dict(desync=2))),
+    "go1_desync_8192": ("go1 N=20, de-synchronised fleet, per-rank batch of the 8-GPU config", go1_params, 8192, 60, dict(streams_kw=dict(desync=True))),
 }
 
 if __name__ == "__main__":
     if len(sys.argv) > 1:
         nm, maker, B, steps, kw = SHAPES[sys.argv[1]]
         # (profilers wrap this form: the in-order launches only, so that 'the last launches' of a trace are what the line is about)
-        run(nm, maker, B, int(sys.argv[2]) if len(sys.argv) > 2 else steps, pipelined_leg=False, **kw)
+        run(nm, maker, B, int(sys.argv[2]) if len(sys.argv) > 2 else steps, pipelined_leg=("desync" in sys.argv[1] or "mixed" in sys.argv[1]), **kw)
         sys.exit(0)
     run("go1 N=20 (bench line shape)", go1_params, 4096, 100)
+    run(*SHAPES["go1_desync"][:4], **SHAPES["go1_desync"][4])
     run("go1 N=20, per-rank batch of the 8-GPU config", go1_params, 8192, 60)
     run("go1 N=20, the WHOLE batch of the 8-GPU config (65 536) on one GPU", go1_params, 65536, 20)
     run("cassie N=20", cassie_params, 4096, 100)

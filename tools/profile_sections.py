@@ -41,6 +41,8 @@ def main():
     shape = sys.argv[3] if len(sys.argv) > 3 else "go1"
     p = {"go1": go1_params, "cassie": cassie_params, "pogox": pogox_params, "go1foot": go1_params}[shape]()
     p.ekf_rate = p.rate
+    if os.environ.get("DEKF_WGS"):  # solve_workgroups_per_cu (4: the four-per-CU kernels of round 6)
+        p.solve_workgroups_per_cu = int(os.environ["DEKF_WGS"])
     if shape == "go1foot":
         p.leg_odom_type = 1  # foot positions as states: 21-dim blocks, factor streamed from the HBM slab
     s = make_streams(p, B, K)
