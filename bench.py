@@ -144,6 +144,27 @@ def cpu_baseline(params, total_steps, seed_first, gpu_x_final=None):
                      f"{short} steps on 1 thread.  The port is an fp64 restatement of the Eigen+OSQP path that keeps "
                      f"H and A as DENSE matrices, re-slices them at every marginalisation and factors a generic sparse "
                      f"KKT matrix per step: slower than Eigen-sparse + QDLDL would be, stated as a baseline only"}
+    # A CPU build that EXPLOITS THE STRUCTURE, beside the port: the device cores themselves (same block-tridiagonal algorithm, same
+    # code: decentralized_ekf_mhe_amd/csrc/*_core.h) compiled lane-sequentially for the host with g++ -O3 -march=native
+    # (tests/hostsim: test infrastructure, never a fallback of the product) on the same logs — what a CPU implementation that never
+    # materialises the QP costs, as opposed to the Eigen + OSQP-shaped port above.
+    try:
+        import hostsim_lib
+        t_b = time.time()
+        hostsim_lib.build(fast=True)
+        t_b = time.time() - t_b
+        _, s1 = hostsim_lib.run_streams_timed(params, one, nthreads=1)
+        inst_s = 4 * nt
+        ss = make_streams(params, inst_s, total_steps, first_instance=seed_first)
+        xs, sm = hostsim_lib.run_streams_timed(params, ss, nthreads=nt)
+        n_cmp = min(inst, inst_s)
+        out["structured"] = {"value": inst_s * total_steps / sm, "unit": "estimator-steps/s", "cores": nt, "single_thread_value": 2 * short / s1,
+                             "kind": "the product's own cores (block-tridiagonal ADMM, QP never materialised) built lane-sequentially for the host: "
+                                     "g++ -O3 -march=native, tests/hostsim",
+                             "sample": f"{inst_s} Go1 instances x {total_steps} steps on {nt} thread(s); single_thread_value = 2 instances x {short} steps",
+                             "max_abs_diff_vs_port": float(np.abs(xs[:n_cmp] - x_ref[total_steps - 1, :n_cmp]).max()), "build_s": round(t_b, 1)}
+    except Exception as e:  # noqa: BLE001  (an extra beside the contract's figure: it must not cost the line)
+        out["structured"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
     if gpu_x_final is not None:
         n = min(16, inst, len(gpu_x_final))
         ref, got = x_ref[total_steps - 1, :n], gpu_x_final[:n]
@@ -187,6 +208,72 @@ def pipelined_leg(env, p, B, sd, total, K):
     return {"value": B * K / dt, "unit": "estimator-steps/s", "ms_per_step": dt / K * 1e3, "steps": K, "solved_frac": solved,
             "what": "dekf_params.solve_pipeline = 1: consecutive steps overlap on two streams (same results bit for bit); "
                     "open-loop replay only, so it is reported beside `value`, not as it"}
+
+
+def runtime_versions():
+    out = {}
+    try:
+        import torch
+        out["torch"] = torch.__version__
+        out["hip"] = getattr(torch.version, "hip", None)
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        out["rocm"] = open("/opt/rocm/.info/version").read().strip()
+    except Exception:  # noqa: BLE001
+        out["rocm"] = None
+    try:
+        from decentralized_ekf_mhe_amd import capi
+        out["hip_runtime_version"] = int(capi.load().dekf_hip_runtime_version())
+    except Exception:  # noqa: BLE001
+        pass
+    return out
+
+
+def pipelined_leg_multi(env, dist, p, B, sd, total, K, world, rank):
+    """pipelined_leg on every rank of a multi-GPU run, with the per-step all-gather of the pipelined handle; MAX over ranks"""
+    import torch
+    p2 = p.copy()
+    p2.solve_pipeline = 1
+    out = {"value": None, "unit": "estimator-steps/s", "steps": K,
+           "what": "dekf_params.solve_pipeline = 1 on every rank, with the per-step RCCL all-gather of the pipelined handle"}
+    est = None
+    ok = 1
+    try:
+        est = env.make_estimator(p2, B)
+        uid = [env.new_unique_id() if rank == 0 else None]
+    except Exception as e:  # noqa: BLE001
+        ok, uid = 0, [None]
+        out["error"] = f"{type(e).__name__}: {e}"
+    dist.broadcast_object_list(uid, src=0)
+    flag = torch.tensor([ok if uid[0] is not None else 0], dtype=torch.int32, device=env.device)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)   # every rank reaches the collective below, or none does
+    if int(flag.item()) != 1:
+        if est is not None:
+            est.close()
+        out.setdefault("error", "a rank could not create its pipelined handle")
+        return out
+    try:
+        est.comm_init(world, rank, uid[0])
+        vb_all = torch.empty((2, world, B, 3), dtype=torch.float64, device=env.device)   # two buffers: the exchange of step T is still in flight at T + 1
+        for k in range(total - K):
+            est.push_stream_step(sd, k); est.step(k); est.allgather_vb(vb_all[k & 1])
+        est.sync(); env.device_sync(); dist.barrier()
+        t0 = time.perf_counter()
+        for k in range(total - K, total):
+            est.push_stream_step(sd, k); est.step(k); est.allgather_vb(vb_all[k & 1])
+        est.sync(); env.device_sync(); dist.barrier()
+        tt = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=env.device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+        mine = est.get()["v_b"]
+        last = (total - 1) & 1
+        good = torch.tensor([1 if np.array_equal(vb_all[last, rank].cpu().numpy(), mine) else 0], dtype=torch.int32, device=env.device)
+        dist.all_reduce(good, op=dist.ReduceOp.MIN)
+        out.update(value=world * B * K / dt, ms_per_step=dt / K * 1e3, own_shard_round_trips_on_every_rank=bool(int(good.item())))
+    finally:
+        est.close()
+    return out
 
 
 def default_batch(gpus):
@@ -280,6 +367,14 @@ def run_bench(args, env, rank, world):
         vb_all = torch.empty((world, B, 3), dtype=torch.float64, device=env.device)
     own_comm = gather_path.startswith("dekf")
     vb_mine = torch.empty((B, 3), dtype=torch.float64, device=env.device) if (vb_all is not None and not own_comm) else None
+    # What the COMMUNICATOR says (not what this script passed in): ncclCommCount / ncclCommUserRank, and one exchange of the rank
+    # numbers through the handle's own communicator and stream, checked slot by slot.  A line with comm_world == n_gpus and
+    # comm_ranks_seen == n_gpus proves that RCCL connected that many ranks.
+    comm_world = comm_rank = ranks_seen = None
+    if own_comm:
+        comm_world, comm_rank = est.comm_info()
+        ranks_seen = est.comm_ranks_seen()   # collective
+        assert comm_world == world and comm_rank == rank, (comm_world, comm_rank, world, rank)
 
     def run(k0, k1):
         for k in range(k0, k1):
@@ -358,7 +453,8 @@ def run_bench(args, env, rank, world):
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload_name(B, world, int(p.N)),
                        "robot": "go1", "legs": 4, "N": int(p.N), "batch_per_gpu": B, "global_batch": world * B,
-                       "eps": 1e-6, "parallelism": f"instances sharded x{world}, RCCL all-gather of v_b per step", "allgather": gather_path},
+                       "eps": 1e-6, "parallelism": f"instances sharded x{world}, RCCL all-gather of v_b per step", "allgather": gather_path,
+                       "comm_world": comm_world, "comm_ranks_seen": ranks_seen},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
@@ -379,11 +475,16 @@ def run_bench(args, env, rank, world):
                          "solve_workgroups": li["solve_workgroups"], "workgroups_per_cu": li["solve_workgroups"] / max(li["compute_units"], 1),
                          "chain_floor_cycles_per_solve": chain_floor, "measured_cycles_per_solve": cycles_per_solve,
                          "chain_floor_frac": chain_floor / cycles_per_solve if cycles_per_solve > 0 else None},
-            "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items()},
+            "kernel_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in tim.items() if k != "allgather"},
+            # the exchange itself, event-timed on the handle's communication stream over the timed steps (it overlaps the next step)
+            "allgather_ms_per_step": (tim["allgather"][0] / tim["allgather"][1]) if tim.get("allgather", (0, 0))[1] else None,
             "solver": {"mean_iters": mean_iters, "max_iters": int(info["iters"].max()),
                        "mean_refactorisations": mean_refactor,
                        "solved_frac": solved, "max_abs_v_err_vs_truth": v_err},
             "stream_gen_s": t_gen,
+            # the overlap of the look-ahead arrival cost (and of solve_pipeline = 1) rests on HIP runtime behaviour (dekf_capi.hip): which
+            # runtime produced this line (guarded by tests/test_gpu_configs.py::test_the_overlap_the_throughput_rests_on_is_still_there)
+            "runtime": runtime_versions() if env.real else None,
         }
         if not env.real:
             line["stand_in"] = True  # tests only: no estimator ran, nothing in this line is a measurement
@@ -400,6 +501,13 @@ def run_bench(args, env, rank, world):
             line["with_step_pipelining"] = pipelined_leg(env, p, B, sd, total, K)
         except Exception as e:  # noqa: BLE001
             line["with_step_pipelining"] = {"value": None, "error": f"{type(e).__name__}: {e}"}
+    if world > 1 and own_comm and not getattr(args, "pipeline", False) and not getattr(args, "no_pipelined_leg_multi", False):
+        # N > 1: the same K steps once more with solve_pipeline = 1 AND its all-gather (one event per output set: the exchange of step
+        # T waits for the solve that produced v_b on the communication stream only) — every rank takes part, rank 0 reports it beside
+        # `value`.  This is the only place the pipelined all-gather meets more than one rank.
+        res = pipelined_leg_multi(env, dist, p, B, sd, total, K, world, rank)
+        if line is not None:
+            line["with_step_pipelining"] = res
     return line
 
 
@@ -438,6 +546,8 @@ def parse_args(argv=None):
                     "and report that as with_step_pipelining beside value (N = 1 only).  Off by default: the extra launches of the same "
                     "kernel overlap each other, and a rocprofv3 summary of the default command is to hold the in-order launches only")
     ap.add_argument("--no-pipelined-leg", action="store_true", help=argparse.SUPPRESS)  # (accepted, the default)
+    ap.add_argument("--no-pipelined-leg-multi", dest="no_pipelined_leg_multi", action="store_true",
+                    help="N > 1: skip the extra pass with solve_pipeline = 1 and its all-gather (with_step_pipelining)")
     ap.add_argument("--pipeline", action="store_true", help="dekf_params.solve_pipeline = 1: consecutive steps overlap (A/B; the launch "
                     "durations the roofline is priced on then overlap too, so the default keeps the steps in order)")
     # test hook (tests/test_bench_orchestration.py): "module:function" returning a BenchEnv for (rank, local_rank, world);

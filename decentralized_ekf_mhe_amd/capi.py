@@ -24,6 +24,7 @@ PROTOTYPES = {
     "dekf_default_params": (None, [C.POINTER(DekfParams)]),
     "dekf_abi_version": (C.c_int, []),
     "dekf_last_error": (C.c_char_p, []),
+    "dekf_hip_runtime_version": (C.c_int, []),
     "dekf_create": (C.c_int, [C.POINTER(DekfParams), C.c_int, C.c_int, _vp, C.POINTER(_vp)]),
     "dekf_destroy": (C.c_int, [_vp]),
     "dekf_reset": (C.c_int, [_vp]),
@@ -52,6 +53,8 @@ PROTOTYPES = {
     "dekf_comm_init": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
     "dekf_allgather_vb": (C.c_int, [_vp, _vp]),
     "dekf_allgather_wait": (C.c_int, [_vp]),
+    "dekf_comm_info": (C.c_int, [_vp, _ip, _ip]),
+    "dekf_comm_ranks_seen": (C.c_int, [_vp, _ip]),
 }
 
 _lib = None

@@ -198,7 +198,7 @@ struct Timed {  // brackets one launch with events when timing is on
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
     Timed(dekf_handle h_, int cls_, hipStream_t st_ = nullptr) : h(h_), cls(cls_), st(st_ ? st_ : h_->stream) {
-        if (!h->timing || (h->timing == 2 && cls != 2)) return;
+        if (!h->timing || (h->timing == 2 && cls != 2 && cls != 3)) return;  // (3: the all-gather, on the communication stream — off the step's critical path)
         if (!h->ev_pool.empty()) { a = h->ev_pool.back().first; b = h->ev_pool.back().second; h->ev_pool.pop_back(); }
         else if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
             if (a) (void)hipEventDestroy(a);
@@ -220,6 +220,10 @@ extern "C" {
 
 void dekf_default_params(dekf_params* p) { default_params(p); }
 int dekf_abi_version(void) { return DEKF_ABI_VERSION; }
+int dekf_hip_runtime_version(void) {
+    int v = 0;
+    return hipRuntimeGetVersion(&v) == hipSuccess ? v : 0;
+}
 const char* dekf_last_error(void) { return g_err.c_str(); }
 
 dekf_status dekf_create(const dekf_params* p, int batch, int device, void* stream, dekf_handle* out) {
@@ -798,6 +802,7 @@ dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches) {
     HIPCHK(hipStreamSynchronize(h->stream));
     for (int i = 0; i < 2; ++i)
         if (h->solve_stream[i]) HIPCHK(hipStreamSynchronize(h->solve_stream[i]));
+    if (h->comm_stream && !h->ev[3].empty()) HIPCHK(hipStreamSynchronize(h->comm_stream));
     for (int c = 0; c < DEKF_TIMING_CLASSES; ++c) {
         double sum = 0.0;
         for (auto& pr : h->ev[c]) {
@@ -944,10 +949,49 @@ dekf_status dekf_allgather_vb(dekf_handle h, double* v_b_all_dev) {
     HIPCHK(hipEventRecord(h->ev_vb_ready, h->stream));
     HIPCHK(hipStreamWaitEvent(h->comm_stream, h->ev_vb_ready, 0));
     }
-    const char* e = rccl_allgather_f64(h->comm, h->vb_snapshot, v_b_all_dev, n, h->comm_stream);
-    if (e) return fail(DEKF_ERR_COMM, e);
+    {
+        Timed t(h, 3, h->comm_stream);
+        const char* e = rccl_allgather_f64(h->comm, h->vb_snapshot, v_b_all_dev, n, h->comm_stream);
+        if (e) return fail(DEKF_ERR_COMM, e);
+    }
     HIPCHK(hipEventRecord(h->ev_ag_done, h->comm_stream));
     h->ag_pending = true;
+    return DEKF_OK;
+}
+dekf_status dekf_comm_info(dekf_handle h, int* comm_world, int* comm_rank) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    if (!h->comm) return fail(DEKF_ERR_ORDER, "dekf_comm_init has not been called");
+    int cw = 0, cr = -1;
+    const char* e = rccl_comm_info(h->comm, &cw, &cr);
+    if (e) return fail(DEKF_ERR_COMM, e);
+    if (comm_world) *comm_world = cw;
+    if (comm_rank) *comm_rank = cr;
+    return DEKF_OK;
+}
+dekf_status dekf_comm_ranks_seen(dekf_handle h, int* ranks_seen) {
+    if (!h) return fail(DEKF_ERR_INVALID, "null handle");
+    if (!h->comm) return fail(DEKF_ERR_ORDER, "dekf_comm_init has not been called");
+    HIPCHK(hipSetDevice(h->device));
+    // one double per rank through the very communicator and stream the v_b exchange uses
+    double* buf = nullptr;
+    HIPCHK(hipMalloc((void**)&buf, (size_t)(h->world + 1) * sizeof(double)));
+    const double mine = (double)h->rank;
+    hipError_t he = hipMemcpyAsync(buf + h->world, &mine, sizeof(double), hipMemcpyHostToDevice, h->comm_stream);
+    if (he == hipSuccess) he = hipStreamSynchronize(h->comm_stream);  // (`mine` is a stack variable)
+    const char* e = he == hipSuccess ? rccl_allgather_f64(h->comm, buf + h->world, buf, 1, h->comm_stream) : nullptr;
+    std::vector<double> got((size_t)h->world, -1.0);
+    if (he == hipSuccess && !e) he = hipMemcpyAsync(got.data(), buf, (size_t)h->world * sizeof(double), hipMemcpyDeviceToHost, h->comm_stream);
+    if (he == hipSuccess && !e) he = hipStreamSynchronize(h->comm_stream);
+    (void)hipFree(buf);
+    if (e) return fail(DEKF_ERR_COMM, e);
+    if (he != hipSuccess) { g_err = std::string("dekf_comm_ranks_seen: ") + hipGetErrorString(he); return DEKF_ERR_HIP; }
+    std::vector<char> seen((size_t)h->world, 0);
+    int n = 0;
+    for (int i = 0; i < h->world; ++i) {
+        const int r = (int)got[(size_t)i];
+        if (got[(size_t)i] == (double)r && r >= 0 && r < h->world && got[(size_t)i] == (double)i && !seen[(size_t)r]) { seen[(size_t)r] = 1; ++n; }  // slot i must hold rank i
+    }
+    if (ranks_seen) *ranks_seen = n;
     return DEKF_OK;
 }
 dekf_status dekf_allgather_wait(dekf_handle h) {

@@ -17,6 +17,8 @@ struct RcclApi {
     ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -35,6 +37,8 @@ inline RcclApi* rccl_api(std::string& err) {
             api.AllGather = (decltype(api.AllGather))dlsym(api.lib, "ncclAllGather");
             api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.lib, "ncclCommDestroy");
             api.GetErrorString = (decltype(api.GetErrorString))dlsym(api.lib, "ncclGetErrorString");
+            api.CommCount = (decltype(api.CommCount))dlsym(api.lib, "ncclCommCount");
+            api.CommUserRank = (decltype(api.CommUserRank))dlsym(api.lib, "ncclCommUserRank");
         }
     }
     if (!api.lib || !api.GetUniqueId || !api.CommInitRank || !api.AllGather || !api.CommDestroy) {
@@ -75,6 +79,14 @@ inline const char* rccl_allgather_f64(void* comm, const double* send, double* re
     if (!a) return g_rccl_err.c_str();
     ncclResult_t r = a->AllGather(send, recv, count, ncclFloat64, (ncclComm_t)comm, st);
     return r == ncclSuccess ? nullptr : rccl_fail(a, r, "ncclAllGather");
+}
+inline const char* rccl_comm_info(void* comm, int* count, int* rank) {
+    RcclApi* a = rccl_api(g_rccl_err);
+    if (!a) return g_rccl_err.c_str();
+    if (!a->CommCount || !a->CommUserRank) { g_rccl_err = "librccl.so has no ncclCommCount / ncclCommUserRank"; return g_rccl_err.c_str(); }
+    ncclResult_t r = a->CommCount((ncclComm_t)comm, count);
+    if (r == ncclSuccess) r = a->CommUserRank((ncclComm_t)comm, rank);
+    return r == ncclSuccess ? nullptr : rccl_fail(a, r, "ncclCommCount / ncclCommUserRank");
 }
 inline void rccl_destroy(void* comm) {
     std::string e;

@@ -174,11 +174,11 @@ class BatchedEstimator:
         capi.check(self.lib.dekf_timing_enable(self.h, int(on)))
 
     def timing_read(self):
-        """{'ekf'|'assemble'|'solve': (device ms summed, launches)} since the last read"""
-        ms = (C.c_double * 3)()
-        cnt = (C.c_int * 3)()
+        """{'ekf'|'assemble'|'solve'|'allgather': (device ms summed, launches)} since the last read"""
+        ms = (C.c_double * 4)()
+        cnt = (C.c_int * 4)()
         capi.check(self.lib.dekf_timing_read(self.h, ms, cnt))
-        return {k: (ms[i], cnt[i]) for i, k in enumerate(("ekf", "assemble", "solve"))}
+        return {k: (ms[i], cnt[i]) for i, k in enumerate(("ekf", "assemble", "solve", "allgather"))}
 
     def launch_info(self):
         """{'solve_workgroups', 'compute_units', 'clock_hz'} of the solve kernel's launch on this device"""
@@ -195,6 +195,18 @@ class BatchedEstimator:
     def comm_init(self, world, rank, unique_id: bytes):
         buf = C.create_string_buffer(unique_id, capi.DEKF_UNIQUE_ID_BYTES)
         capi.check(self.lib.dekf_comm_init(self.h, world, rank, buf))
+
+    def comm_info(self):
+        """(world, rank) as the RCCL communicator itself reports them (ncclCommCount / ncclCommUserRank)"""
+        w, r = C.c_int(0), C.c_int(-1)
+        capi.check(self.lib.dekf_comm_info(self.h, C.byref(w), C.byref(r)))
+        return w.value, r.value
+
+    def comm_ranks_seen(self):
+        """collective: all-gathers every rank's number through the handle's communicator and stream; distinct rank numbers that arrived"""
+        n = C.c_int(0)
+        capi.check(self.lib.dekf_comm_ranks_seen(self.h, C.byref(n)))
+        return n.value
 
     def allgather_vb(self, out_tensor):
         """asynchronous (own stream, overlaps the next step); complete after sync() or allgather_wait()"""

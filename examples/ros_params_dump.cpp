@@ -76,7 +76,7 @@ int main(int argc, char** argv) {
         row("ekf_init_std", d.ekf_init_std, 4); row("ekf_process_std", d.ekf_process_std, 3);
         row("ekf_gravity_meas_std", d.ekf_gravity_meas_std, 3); row("ekf_vo_meas_std", d.ekf_vo_meas_std, 4);
         row("ekf_quaternion_init", d.ekf_quaternion_init, 4); row("ekf_rate", d.ekf_rate); row("ekf_history", d.ekf_history);
-        row("polish_refine_iter", d.polish_refine_iter); row("arrival_cost_form", d.arrival_cost_form); row("solve_pipeline", d.solve_pipeline); row("solve_workgroups_per_cu", d.solve_workgroups_per_cu);
+        row("polish_refine_iter", d.polish_refine_iter); row("arrival_cost_form", d.arrival_cost_form); row("solve_pipeline", d.solve_pipeline); row("solve_workgroups_per_cu", d.solve_workgroups_per_cu); row("polish_accept_osqp", d.polish_accept_osqp);
         for (const std::string& n : est.undeclared_overrides()) std::printf("undeclared %s\n", n.c_str());
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "error: %s\n", ex.what());

@@ -155,6 +155,9 @@ void dekf_default_params(dekf_params* p);
 
 int dekf_abi_version(void);
 const char* dekf_last_error(void);
+/* hipRuntimeGetVersion() of the HIP runtime this library is bound to (0 if the call fails).  The overlap of consecutive steps
+ * (solve_pipeline = 1) and of the look-ahead arrival cost rests on stream scheduling of that runtime; bench.py records it. */
+int dekf_hip_runtime_version(void);
 
 /* Replaces: constructing DecentralizedEstimation + orien_ekf for `batch` robots.
  * device = HIP device ordinal; stream = hipStream_t to run on (NULL: own stream). */
@@ -243,9 +246,10 @@ dekf_status dekf_get_kf_cov(dekf_handle h, double* cov, dekf_mem where);
 /* on = 1: every kernel launch of the hot path is bracketed by HIP events on the handle's stream; on = 2: only the
  * MHE solve launches (class 2) — an event pair costs the stream about 7 us, six of them per step are 1 % of a
  * 2 ms step, so a throughput measurement that only needs the dominant kernel's launch time asks for 2; on = 0: off.  dekf_timing_read synchronises and returns, per kernel class
- * (0 ekf tick, 1 MHE assemble/marginalise [or KF update], 2 MHE ADMM solve), the summed
+ * (0 ekf tick, 1 MHE assemble/marginalise [or KF update], 2 MHE ADMM solve, 3 all-gather of v_b), the summed
  * device milliseconds and the number of launches since the last read. */
-#define DEKF_TIMING_CLASSES 3
+#define DEKF_TIMING_CLASSES 4 /* (ABI 4: class 3 = the RCCL all-gather of v_b, bracketed on the handle's communication stream in either
+                               * timing mode — it is not on the step's critical path) */
 dekf_status dekf_timing_enable(dekf_handle h, int on);
 dekf_status dekf_timing_read(dekf_handle h, double* ms_sum, int* launches);
 
@@ -275,6 +279,13 @@ dekf_status dekf_comm_unique_id(void* id_out);
 dekf_status dekf_comm_init(dekf_handle h, int world, int rank, const void* id);
 dekf_status dekf_allgather_vb(dekf_handle h, double* v_b_all_dev);
 dekf_status dekf_allgather_wait(dekf_handle h);
+/* What the COMMUNICATOR itself says about the exchange (ncclCommCount / ncclCommUserRank of the handle's communicator), not what
+ * the caller passed to dekf_comm_init — so that a throughput line can prove how many ranks RCCL really connected.  And a device-side
+ * proof of one exchange: every rank contributes its own rank number, dekf_comm_ranks_seen all-gathers them on the communication
+ * stream, waits, and writes how many DISTINCT, in-range rank numbers arrived (== world on a working communicator).  Both are
+ * collectives over the communicator's ranks where noted.  Any out pointer may be NULL. */
+dekf_status dekf_comm_info(dekf_handle h, int* comm_world, int* comm_rank);
+dekf_status dekf_comm_ranks_seen(dekf_handle h, int* ranks_seen); /* collective */
 
 #ifdef __cplusplus
 }

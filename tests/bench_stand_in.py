@@ -41,6 +41,15 @@ class StandInEstimator:
             raise RuntimeError("stand-in communicator refused")
         self.comm = "up"
 
+    def comm_info(self):
+        assert self.comm == "up"
+        return self.world, self.rank
+
+    def comm_ranks_seen(self):
+        got = [None] * self.world
+        dist.all_gather_object(got, self.rank)     # (collective, like the real one)
+        return len({r for i, r in enumerate(got) if r == i})
+
     def allgather_vb(self, out):
         assert self.comm == "up"
         dist.all_gather_into_tensor(out.view(self.world * self.B, 3), torch.from_numpy(self.vb()))
@@ -60,7 +69,7 @@ class StandInEstimator:
 
     def timing_read(self):
         return {"ekf": (0.01 * self.timed_steps, self.timed_steps), "assemble": (0.07 * self.timed_steps, self.timed_steps),
-                "solve": (3.5 * self.timed_steps, self.timed_steps)}
+                "solve": (3.5 * self.timed_steps, self.timed_steps), "allgather": (0.02 * self.gathers, self.gathers)}
 
     def solve_kernel_name(self, full_window=True):
         return "stand-in"

@@ -77,11 +77,17 @@ def test_two_ranks_own_communicator(tmp_path):
     assert rf["bound"] == "hbm" and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-15
     assert rf["traffic"] is None and 0 < rf["flop_frac"] < 1 and rf["chain_floor_frac"] > 0
     assert "cpu_baseline" not in d and d["scaling"] == "weak" and d["vs_baseline"] is None
+    # the line proves how many ranks the communicator connected, times the exchange, and carries the pipelined pass with ITS all-gather
+    assert d["config"]["comm_world"] == 2 and d["config"]["comm_ranks_seen"] == 2
+    assert d["allgather_ms_per_step"] == pytest.approx(0.02) and "allgather" not in d["kernel_ms_per_step"]
+    wp = d["with_step_pipelining"]
+    assert wp["value"] > 0 and wp["own_shard_round_trips_on_every_rank"] is True and wp["steps"] == 7
 
 
 def test_preflight_failure_on_one_rank_moves_every_rank_to_the_fallback(tmp_path):
     d = _run(tmp_path, 1)
     assert d["config"]["allgather"] == "torch.distributed.all_gather_into_tensor"
+    assert d["config"]["comm_world"] is None and d["config"]["comm_ranks_seen"] is None and "with_step_pipelining" not in d
 
 
 @pytest.mark.parametrize("world", [4, 8])
@@ -95,6 +101,8 @@ def test_four_and_eight_ranks_layout_timing_and_preflight(tmp_path, world):
     assert d["ms_per_step"] >= 1e3 * slow                       # the slow rank's time, not rank 0's
     assert abs(d["value"] - world * 6 * 7 / (d["ms_per_step"] * 7e-3)) / d["value"] < 1e-9
     assert d["scaling"] == "weak" and "cpu_baseline" not in d
+    assert d["config"]["comm_world"] == world and d["config"]["comm_ranks_seen"] == world
+    assert d["with_step_pipelining"]["value"] > 0 and d["with_step_pipelining"]["own_shard_round_trips_on_every_rank"] is True
 
 
 def test_preflight_failure_on_the_last_of_eight_ranks_moves_all_to_the_fallback(tmp_path):

@@ -76,7 +76,7 @@ def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
                            "-L", lib_dir, "-ldekf", f"-Wl,-rpath,{lib_dir}"])
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
-    assert "abi 3 N 20 legs 4 rate 200 ring 256" in out.stdout, out.stdout
+    assert "abi 4 N 20 legs 4 rate 200 ring 256" in out.stdout, out.stdout
     import torch
     if not torch.cuda.is_available():
         assert f"create {capi.DEKF_ERR_NO_DEVICE} handle null" in out.stdout, out.stdout
