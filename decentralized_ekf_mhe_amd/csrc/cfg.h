@@ -152,6 +152,9 @@ struct Gws {
         cf = o; o += m_pad;
         pol = o; o += 2 * K * ns + 5 * m_pad;
         WT = o; o += wt && !ft ? K * b2 : 0;
+        // slack behind the last array: the run-time chain of the slab-resident factor loads its operands unconditionally, up to a ring
+        // of blocks beyond a leg's end (mhe_admm_core.h: sweeps_one_wave_rt) — never used, but it must be the workgroup's own memory
+        o += 8 * 81;
         total = o;
     }
 };

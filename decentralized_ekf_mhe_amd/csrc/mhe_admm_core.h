@@ -171,6 +171,9 @@ DEKF_FN double chain_matvec_dpp(double v, cdptr w, double rhs) {
 #ifndef DEKF_GG_RING
 #define DEKF_GG_RING 6
 #endif
+#ifndef DEKF_RT_ROUNDS
+#define DEKF_RT_ROUNDS 1  // rounds of the operand ring per loop iteration of the run-time-horizon solve with the factor in the slab (sweeps_one_wave_rt)
+#endif
 template <bool TR, bool BWD, int STEPS = 0, class Q>
 DEKF_FN void sweep_chain(Q& q, int k0, int dk, int steps, int wofs, double alpha) {
     constexpr int SV = 21 + 3 * Q::LEGS;
@@ -529,28 +532,54 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
         frr = frr + frstep;
     };
     double v = xs[(top ? 0 : 9 * (K - 1)) + i];  // f_0 = b_0 / f^_{K-1} = b_{K-1}
+    // UNCONDITIONAL operand loads (round 6).  Every step loads the operands of the step RING - 1 ahead of it — also in the last RING - 1
+    // steps of a leg, where those lie beyond the leg's end: the two legs meet in the middle of arrays that span the whole window, so
+    // the reads stay inside the arrays (forward) or inside the workgroup's slab / LDS (outward; Gws::total carries RING blocks of slack
+    // behind the last array) and their values are never used.  A load behind a branch — even a scalar one that is never taken — makes
+    // the number of loads in flight path-dependent for the compiler's wait-count pass, which then drains the whole pipeline of operand
+    // sets (s_waitcnt vmcnt(0)) in front of every round of the ring; and it drains at every loop header anyway, so a loop iteration
+    // runs ROUNDS rounds (RING * ROUNDS steps).  PogoX: 14 drains of the slab latency per ADMM iteration before, 4-5 now.
+    // (-DDEKF_BOUNDS keeps the guarded loads: the checked build counts every out-of-range read)
+    // (the LDS-resident factor keeps them too: its last array ends where the workgroup's LDS ends)
+#ifdef DEKF_BOUNDS
+    constexpr bool GUARD = true;
+#else
+    constexpr bool GUARD = Q::FACTOR_LDS;
+#endif
+    constexpr int ROUNDS = Q::FACTOR_LDS ? 1 : DEKF_RT_ROUNDS;
     {
         Ops r[RING];
         dptr gsr = gst;
-        auto fstepf = [&](const Ops& c, Ops& n, int s, int ahead) {
-            if (s + ahead <= M) fload(s + ahead, n);
+        auto fcompute = [&](const Ops& c) {
             const double src = rows23_from_rows01(v);
             const double res = chain_matvec_dpp(src, c.w, c.rhs);
             v = res;
             gsr[0] = res;
             gsr = gsr + gstep;
         };
+        auto fstepf = [&](const Ops& c, Ops& n, int s, int ahead) {
+            if (!GUARD || s + ahead <= M) fload(s + ahead, n);
+            fcompute(c);
+        };
 #pragma unroll
         for (int u = 0; u < RING - 1; ++u)
-            if (M >= u + 1) fload(u + 1, r[u]);
+            if (!GUARD || M >= u + 1) fload(u + 1, r[u]);
         int s = 1;
+        if constexpr (ROUNDS > 1) {
+            for (; s + RING * ROUNDS - 1 <= M; s += RING * ROUNDS) {
+#pragma unroll
+                for (int rep = 0; rep < ROUNDS; ++rep)
+#pragma unroll
+                    for (int u = 0; u < RING; ++u) fstepf(r[u], r[(u + RING - 1) % RING], s + rep * RING + u, RING - 1);
+            }
+        }
         for (; s + RING - 1 <= M; s += RING) {
 #pragma unroll
             for (int u = 0; u < RING; ++u) fstepf(r[u], r[(u + RING - 1) % RING], s + u, RING - 1);
         }
 #pragma unroll
         for (int u = 0; u < RING - 1; ++u)
-            if (s + u <= M) fstepf(r[u], r[RING - 1], s + u, RING);
+            if (s + u <= M) fcompute(r[u]);   // (the operands of the last RING - 1 steps are in flight already)
     }
     // ---------------- meeting block (row 0) and the last g of the bottom half (row 3)
     {
@@ -602,8 +631,7 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
             o.xo = xr[0];
         };
         Bops r[RING];
-        auto bstepf = [&](const Bops& c, Bops& n, int s, int ahead) {
-            if (s + ahead <= NOUT) bload(s + ahead, n);
+        auto bcompute = [&](const Bops& c, int s) {
             const double res = chain_matvec_dpp(v, c.w, -c.ng);
             v = res;
             xdw = xdw + xdstep;
@@ -616,17 +644,29 @@ DEKF_FN void sweeps_one_wave_rt(Q& q, double alpha) {
             dxd[0] = c.dsc * res;
             dx[0] = relax(alpha, res, c.xo);
         };
+        auto bstepf = [&](const Bops& c, Bops& n, int s, int ahead) {
+            if (!GUARD || s + ahead <= NOUT) bload(s + ahead, n);
+            bcompute(c, s);
+        };
 #pragma unroll
         for (int u = 0; u < RING - 1; ++u)
-            if (NOUT >= u + 1) bload(u + 1, r[u]);
+            if (!GUARD || NOUT >= u + 1) bload(u + 1, r[u]);
         int s = 1;
+        if constexpr (ROUNDS > 1) {
+            for (; s + RING * ROUNDS - 1 <= NOUT; s += RING * ROUNDS) {
+#pragma unroll
+                for (int rep = 0; rep < ROUNDS; ++rep)
+#pragma unroll
+                    for (int u = 0; u < RING; ++u) bstepf(r[u], r[(u + RING - 1) % RING], s + rep * RING + u, RING - 1);
+            }
+        }
         for (; s + RING - 1 <= NOUT; s += RING) {
 #pragma unroll
             for (int u = 0; u < RING; ++u) bstepf(r[u], r[(u + RING - 1) % RING], s + u, RING - 1);
         }
 #pragma unroll
         for (int u = 0; u < RING - 1; ++u)
-            if (s + u <= NOUT) bstepf(r[u], r[RING - 1], s + u, RING);
+            if (s + u <= NOUT) bcompute(r[u], s + u);
     }
 }
 #endif
@@ -733,6 +773,8 @@ DEKF_FN void sweep_legs_generic(Q& q, double alpha) {
         for (; s + RING - 1 <= smax; s += RING) {
 #pragma unroll
             for (int u = 0; u < RING; ++u) {
+                // (unconditional, clamped loads as in sweeps_one_wave_rt were measured here too, round 6: 290.7 k -> 283.7 k steps/s on
+                // Go1 with foot states — this shape runs against the slab stream itself, every extra block read costs)
                 if (s + u + RING - 1 <= smax) load(s + u + RING - 1, r[(u + RING - 1) % RING]);
                 step(s + u, r[u]);
             }
