@@ -356,9 +356,16 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             if (cap > 0 && pcf > cap) pcf = cap;
             const long sf = (long)pcf * prop.multiProcessorCount;
             h->solve_grid_full = (int)(sf < batch ? sf : batch);
-            // only where the batch really fills more slots than the two-workgroup kernel offers: below that the row state
-            // would travel through the slab for no residency gained
-            if (pcf > per_cu && h->solve_grid_full > h->solve_grid) {
+            // For EVERY batch since round 6 (it used to be only where the batch fills more slots than the two-workgroup kernel offers,
+            // "below that the row state would travel through the slab for no residency gained"): measured, the rows-in-registers
+            // kernel solves a full window in 0.278 ms against 0.350 ms even ALONE on its CU — 21-22 % less solve time at 64 ... 512
+            // instances (profiles/r06_r3_at_small_batches.txt).  The two-workgroup kernels keep the window-fill ticks, and full
+            // windows when the caller caps the residency at two.
+            bool take = pcf > per_cu;
+#ifdef DEKF_AB_KNOBS  // A/B builds only: the round-5 rule
+            if (getenv("DEKF_DEBUG_R3_ONLY_ABOVE_512")) take = pcf > per_cu && h->solve_grid_full > h->solve_grid;
+#endif
+            if (take) {
                 h->solve_kernel_full = full;
                 h->solve_name_full = full_name;
             }
@@ -386,7 +393,13 @@ dekf_status dekf_create(const dekf_params* p, int batch, int device, void* strea
             if (cap > 0 && pcf > cap) pcf = cap;
             const long sf = (long)pcf * prop.multiProcessorCount;
             h->solve_grid_full = (int)(sf < batch ? sf : batch);
-            if (pcf > per_cu && h->solve_grid_full > h->solve_grid) {
+            // (for every batch since round 6: 10-13 % less solve time than the generic kernel at 32 ... 256 instances too,
+            // profiles/r06_r3_at_small_batches.txt)
+            bool take = pcf > per_cu;
+#ifdef DEKF_AB_KNOBS  // A/B builds only: the round-5 rule
+            if (getenv("DEKF_DEBUG_RR_ONLY_ABOVE_256")) take = pcf > per_cu && h->solve_grid_full > h->solve_grid;
+#endif
+            if (take) {
                 h->solve_kernel_full = full;
                 h->solve_name_full = full_name;
             }

@@ -332,7 +332,7 @@ def test_rccl_allgather_two_ranks_equals_single_rank_results(tmp_path):
                          ids=["go1", "cassie", "go1-polish", "cassie-polish", "go1-checks-every-10", "go1-fixed-rho-capped"])
 def test_three_workgroup_kernel_agrees_with_the_two_workgroup_kernel(maker, kw):
     """ONE RESULT PER ROBOT, WHATEVER THE BATCH.  Full windows of the fixed-horizon shapes run k_mhe_solve_r3_* (three workgroups per
-    CU, row state in registers, one specialised row loop per wavefront) when the batch exceeds the two-workgroup kernels' slots;
+    CU, row state in registers, one specialised row loop per wavefront) — for every batch since round 6;
     dekf_params.solve_workgroups_per_cu = 2 keeps the two-workgroup kernel for every tick.  Same operations on the same operands, and
     since round 5 the same BITS: the iteration phases are compiled with floating-point contraction off and say fma() where they want
     one, in the same form in every code shape (csrc/mhe_admm_core.h) — until then the compiler fused an a b + c d differently in the
@@ -400,9 +400,10 @@ def test_three_workgroup_kernel_with_vo_rows_and_two_rho_updates():
 
 @pytest.mark.parametrize("polish", [0, 1], ids=["plain", "polish"])
 def test_one_legged_long_window_kernels_agree_bit_for_bit(polish):
-    """PogoX (N = 100): batches above the generic kernel's 256 slots run full windows on k_mhe_solve_rr_1 (rows in registers at a
-    run-time horizon, compact x blocks), smaller ones on k_mhe_solve_gg_1 (tile loops over LDS-resident iterates).  The same 24 logs
-    as a batch of 24 and tiled to 288: the first tile must carry the bits of the small batch."""
+    """PogoX (N = 100): full windows run on k_mhe_solve_rr_1 (rows in registers at a run-time horizon, compact x blocks; for every
+    batch since round 6), or on k_mhe_solve_gg_1 (tile loops over LDS-resident iterates) when solve_workgroups_per_cu caps the
+    residency at one.  The same 24 logs as a batch of 24 on the generic kernel and tiled to 288 on the rows-in-registers kernel:
+    the first tile must carry the bits of the small batch."""
     p = pogox_params()
     p.ekf_rate = p.rate
     p.polish = polish
@@ -410,9 +411,11 @@ def test_one_legged_long_window_kernels_agree_bit_for_bit(polish):
     s = make_streams(p, D, K)
     tiled = {k: (np.ascontiguousarray(np.tile(v, (1, reps) + (1,) * (v.ndim - 2))) if isinstance(v, np.ndarray) else v) for k, v in s.items()}
     outs = []
-    for streams, B in ((s, D), (tiled, D * reps)):
+    for streams, B, cap in ((s, D, 1), (tiled, D * reps, 0)):
         sd = streams_to_device(streams)
-        est = BatchedEstimator(p, B)
+        q = p.copy()
+        q.solve_workgroups_per_cu = cap
+        est = BatchedEstimator(q, B)
         outs.append(est.solve_kernel_name(True))
         for k in range(K):
             est.push_stream_step(sd, k)

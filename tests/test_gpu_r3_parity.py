@@ -1,8 +1,8 @@
 """The BENCHMARK kernels under every-tick oracle parity.
 
-`dekf_create` launches the three-workgroup kernels `k_mhe_solve_r3_{4,2}_n20[_pol]` only when the batch exceeds the resident slots
-of the two-workgroup kernels (B > 512).  The oracle tests of tests/test_gpu_parity.py run B <= 37 and therefore the `_ll_` / `_lg_`
-kernels; here the batch is 832 (= 13 x 64 distinct logs: more than 768 slots, so some workgroups take a second instance), the oracle
+`dekf_create` launches the three-workgroup kernels `k_mhe_solve_r3_{4,2}_n20[_pol]` for every full window of the N = 20 shapes (since
+round 6 at every batch: they are 21 % faster than the two-workgroup kernels even alone on a CU; until then only above 512 instances,
+so that the oracle tests of tests/test_gpu_parity.py, B <= 37, ran the `_ll_` / `_lg_` kernels).  Here the batch is 832 (= 13 x 64 distinct logs: more than 768 slots, so some workgroups take a second instance), the oracle
 runs the 64 (or fewer) distinct logs, and EVERY tick is compared: state blocks, v_b, quaternion, iteration counts — plus bit
 identity of the tiles (an instance's result must not depend on the slot it ran in).  The solve the reference runs every tick:
 MheSrb.cpp:340-349 (OSQP), set up per tick by MheSrb.cpp:272-338.

@@ -149,12 +149,14 @@ def test_polish_parameters_are_validated():
 @pytest.mark.gpu
 @pytest.mark.parametrize("maker,N,K,ft", [(go1_params, 20, 48, 0), (cassie_params, 20, 44, 0), (go1_params, 7, 24, 0), (go1_params, 20, 26, 1)])
 def test_gpu_polish_matches_oracle(maker, N, K, ft):
-    """Small batches (6 instances): Go1 / Cassie N = 20 run the two-workgroup kernels k_mhe_solve_{ll_4,lg_2}_n20_pol on every tick
-    (the three-workgroup twins k_mhe_solve_r3_*_pol need a batch above 512 and have their own every-tick oracle test in
-    tests/test_gpu_r3_parity.py::test_r3_polish_matches_oracle); N = 7: the generic kernels; ft = 1: the foot-state kernels (factor in
-    the HBM slab)."""
+    """Small batches (6 instances): Go1 / Cassie N = 20 on the two-workgroup kernels k_mhe_solve_{ll_4,lg_2}_n20_pol on every tick
+    (solve_workgroups_per_cu = 2: since round 6 full windows run the three-workgroup twins k_mhe_solve_r3_*_pol at every batch
+    otherwise; those have their own every-tick oracle test in tests/test_gpu_r3_parity.py::test_r3_polish_matches_oracle); N = 7: the
+    generic kernels; ft = 1: the foot-state kernels (factor in the HBM slab)."""
     from decentralized_ekf_mhe_amd.estimator import BatchedEstimator, streams_host
     p = _params(maker, N=N, leg_odom_type=ft)
+    if N == 20 and not ft:
+        p.solve_workgroups_per_cu = 2
     B = 6 if not ft else 3
     s = make_streams(p, B, K)
     x_ref, st_ref, res_ref = _oracle_run(p, s, K)
