@@ -152,9 +152,11 @@ struct Gws {
         cf = o; o += m_pad;
         pol = o; o += 2 * K * ns + 5 * m_pad;
         WT = o; o += wt && !ft ? K * b2 : 0;
-        // slack behind the last array: the run-time chain of the slab-resident factor loads its operands unconditionally, up to a ring
-        // of blocks beyond a leg's end (mhe_admm_core.h: sweeps_one_wave_rt) — never used, but it must be the workgroup's own memory
-        o += 8 * 81;
+        // slack behind the last array, only where the factor streams from here (`wt`): the run-time chain of the slab-resident factor
+        // loads its operands unconditionally, up to a ring of blocks beyond a leg's end (mhe_admm_core.h: sweeps_one_wave_rt) — never
+        // used, but it must be the workgroup's own memory.  (Every other shape keeps the slab size it had: the size of a slab decides
+        // which L2 sets its arrays share, profiles/r04_slab_pad_sweep.txt.)
+        o += wt && !ft ? 8 * 81 : 0;
         total = o;
     }
 };
