@@ -464,7 +464,8 @@ def run_bench(args, env, rank, world):
                          "alg_bytes_per_step": B_ALG_GO1, "units_per_launch": B,
                          # the contract's roofline is the HBM one; what actually limits this kernel is the chain of
                          # dependent mat-vec steps inside every ADMM iteration, so both honest fractions ride along:
-                         "limiter": "dependent-issue latency (ADMM iterations x dependent 9x9 mat-vec steps), not HBM",
+                         "limiter": "the CU's throughput on a dependent chain (ADMM iterations x dependent 9x9 mat-vec steps; three resident solves saturate a CU: "
+                                    "0.278 / 0.352 / 0.439 ms per solve with 0 / 2 / 3 neighbours, DESIGN.md section 4.6), not HBM",
                          # a rocprofv3 --stats table of this command also lists k_mhe_marginalize_early with a long wall time: it is
                          # background work on a second stream at the least priority (the next step's arrival cost, ~0.05 ms of machine
                          # time) whose workgroups wait for the slots this kernel frees in its last round

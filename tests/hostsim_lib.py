@@ -14,12 +14,23 @@ CSRC = os.path.join(os.path.dirname(HERE), "..", "decentralized_ekf_mhe_amd", "c
 _dp, _ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
 
 
+def _cpu_tag():
+    import hashlib
+    try:
+        txt = open("/proc/cpuinfo").read()
+        model = [ln for ln in txt.splitlines() if ln.startswith("model name")][:1]
+        flags = [ln for ln in txt.splitlines() if ln.startswith("flags")][:1]
+        return hashlib.md5("".join(model + flags).encode()).hexdigest()[:8]
+    except Exception:  # noqa: BLE001
+        return "unknown"
+
+
 def build(force=False, sanitize=False, fast=False):
     """fast: -O3 -march=native under another name (bench.py's cpu_baseline.structured leg times THAT build on the GPU box's host)"""
     srcs = [os.path.join(HERE, "hostsim.cpp")] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     out = LIB if not sanitize else LIB.replace(".so", "_asan.so")
     if fast:
-        out = LIB.replace(".so", "_o3.so")
+        out = LIB.replace(".so", f"_o3_{_cpu_tag()}.so")   # -march=native: a build from ANOTHER CPU (the container's, shipped with the snapshot) must never be loaded
     stale = (not os.path.exists(out)) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in srcs)
     if force or stale:
         flags = ["-O2"] if not sanitize else ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"]

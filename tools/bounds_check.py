@@ -48,6 +48,12 @@ CASES = [  # (kernel set = library suffix, name, params maker, batch, ticks, ove
     ("go1", "go1 N=20: window fill (k_mhe_solve_ll_4_n20) and full windows (k_mhe_solve_r3_4_n20), VO, two refactorisations", "go1", 1000, 70, {}),
     ("go1", "go1 N=20, two workgroups per CU for full windows too", "go1", 600, 45, dict(solve_workgroups_per_cu=2)),
     ("cassie", "cassie N=20 (k_mhe_solve_lg_2_n20, k_mhe_solve_r3_2_n20)", "cassie", 900, 60, {}),
+    # round 6: four workgroups of three wavefronts per CU (LDS carved to 4928 doubles, D / E / PA / stash in the slab, Dxb in the pad +
+    # Gauss-Jordan scratch), the instance queue with more instances than workgroups, and the three-workgroup kernel at a small batch
+    ("go1", "go1 N=20, four per CU (k_mhe_solve_r4_4_n20), 1100 instances on 1024 workgroups", "go1", 1100, 60, dict(solve_workgroups_per_cu=4)),
+    ("go1", "go1 N=20, four per CU with osqp.polish (k_mhe_solve_r4_4_n20_pol)", "go1", 1050, 40, dict(solve_workgroups_per_cu=4, polish=1)),
+    ("cassie", "cassie N=20, four per CU (k_mhe_solve_r4_2_n20)", "cassie", 1100, 50, dict(solve_workgroups_per_cu=4)),
+    ("go1", "go1 N=20, 48 instances: full windows on k_mhe_solve_r3_4_n20 (every batch since round 6)", "go1", 48, 50, {}),
     ("legs1", "pogox N=100 (factor streamed from the slab)", "pogox", 64, 130, {}),
     ("legs1", "pogox N=100, 320 instances: full windows on k_mhe_solve_rr_1 (row state in registers, two workgroups per CU)", "pogox", 320, 128, {}),
     ("legs4", "go1 N=5", "go1", 64, 30, dict(N=5)),
