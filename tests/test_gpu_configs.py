@@ -37,7 +37,11 @@ def _full_batch_run(p, B, K, distinct, n_oracle, gather=False):
     vb_all = None
     if gather:
         est.comm_init(1, 0, new_unique_id())
+        # what the bench line quotes as its proof of the communicator (ncclCommCount / ncclCommUserRank; the rank numbers all-gathered
+        # through the handle's own communicator and stream), on the one rank this box has
+        assert est.comm_info() == (1, 0) and est.comm_ranks_seen() == 1
         vb_all = torch.full((2, 1, B, 3), float("nan"), dtype=torch.float64, device="cuda")
+        est.timing_enable(2)
     sd = streams_to_device(big)
     for k in range(K):
         est.push_stream_step(sd, k)
@@ -46,6 +50,9 @@ def _full_batch_run(p, B, K, distinct, n_oracle, gather=False):
             est.allgather_vb(vb_all[k & 1])
     if gather:
         est.allgather_wait()
+        tim = est.timing_read()            # timing class 3: every exchange bracketed on the communication stream
+        assert tim["allgather"][1] == K and 0.0 < tim["allgather"][0] / K < 5.0, tim["allgather"]
+        est.timing_enable(False)
     est.sync()
     o = est.get()
     info = est.solver_info()

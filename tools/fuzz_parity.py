@@ -107,10 +107,14 @@ def draw(rng):
         kw[name] = val
     if rng.random() < 0.2:
         kw["solve_pipeline"] = 1   # device-side switch (the oracle ignores it): consecutive steps overlap, results must not change
+    if shape in ("go1", "cassie", "quad2j") and rng.random() < 0.3:
+        # round 6, device-side switch: 4 = workgroups of three wavefronts at four per CU (k_mhe_solve_r4_*), 2 = the two-workgroup
+        # kernels for full windows (which every batch ran below 512 instances until round 6)
+        kw["solve_workgroups_per_cu"] = rng.choice([4, 4, 2])
     # (the KF mode of the foot-state variant is left out: its covariance recursion is ill-conditioned in the ORACLE itself — the oracle
     # against itself spreads 1e-3 .. 10 x the tolerance, tests/test_foot_states.py — and a recursion has no exact optimum to arbitrate with)
     if rng.random() < 0.08 and shape in ("go1", "cassie"):
-        kw = {k: v for k, v in kw.items() if k in ("leg_odom_type", "N", "solve_pipeline", "_scale_std")}
+        kw = {k: v for k, v in kw.items() if k in ("leg_odom_type", "N", "solve_pipeline", "_scale_std", "solve_workgroups_per_cu")}
         kw["est_type"] = 1         # the Kalman-filter alternative (DecentralEst.cpp:592-861) instead of the QP
     if rng.random() < 0.1 and shape != "pogox":
         K *= 4      # a long log now and then: several marginalised windows, many VO intervals, drift would show
