@@ -125,8 +125,8 @@ typedef struct dekf_params {
                                      * step T runs on a second stream out of double-buffered inputs and outputs, so the pushes, the
                                      * EKF tick and the term construction of step T + 1 (and then its solve) start while the last
                                      * workgroups of step T's solve are still running; getters wait for the newest solve in stream
-                                     * order, so results are bit-identical.  Measured on MI355X, Go1, three-workgroup kernels: +2.5 % at
-                                     * B = 4096 (2.19 M against 2.14 M steps/s), +4 ... +6 % on the other shapes at 1024-4096, more below (EXPERIMENTS.md round 5 section 8): it hides the 0.09 ms of EKF + term
+                                     * order, so results are bit-identical.  Measured on MI355X, Go1, three-workgroup kernels: +3.4 % at
+                                     * B = 4096 (2.21 M against 2.14 M steps/s, round 6), +3 ... +10 % on the other shapes at 1024-4096, -4.5 % at 8192 (EXPERIMENTS.md round 5 section 8): it hides the 0.07 ms of EKF + term
                                      * construction + launch gaps in front of every solve and the partly empty last round.  The two solve streams are created
                                      * at the greatest stream priority (their own hardware-queue class). */
     int solve_workgroups_per_cu;    /* 0: the default residency (3 for full Go1 / Cassie windows when the batch exceeds the 512
