@@ -38,7 +38,7 @@ def _worker(rank, world, port, out_dir, preflight_fails_on, slow_s=0.0):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     made = []
     env = make_env(rank, rank, world, preflight_fails_on=preflight_fails_on, made=made)
-    args = argparse.Namespace(gpus=world, steps=7, warmup=5, batch=6, no_cpu_baseline=True, no_allgather=False)
+    args = argparse.Namespace(gpus=world, steps=7, warmup=5, batch=6, no_cpu_baseline=True, no_allgather=False, pipelined_leg=True)
     if slow_s:
         make0 = env.make_estimator
 
