@@ -48,7 +48,6 @@ DEKF_DECL_SOLVE_FOOT(2)
 DEKF_DECL_SOLVE_FOOT(3)
 DEKF_DECL_SOLVE_FOOT(4)
 __global__ void k_gap();
-__global__ void k_layer();
 __global__ void k_kf_initialize(DevCfg c, DevState s);
 __global__ void k_kf_update(DevCfg c, DevState s, int pushes);
 __global__ void k_latch_vo(DevCfg c, DevState s, const int* mask, const double* t_pre, const double* t_now,
@@ -688,9 +687,7 @@ dekf_status dekf_update(dekf_handle h, int T) {
             const int K = T - kstart + 1;
 #ifdef DEKF_AB_KNOBS  // A/B builds only: a quiet gap (an empty kernel) between the term construction and the solve launch
             { static const int gap = getenv("DEKF_DEBUG_GAP_KERNEL") ? atoi(getenv("DEKF_DEBUG_GAP_KERNEL")) : 0;
-              for (int i = 0; i < gap; ++i) k_gap<<<1, 64, 0, ss>>>();
-              static const int layer = getenv("DEKF_DEBUG_LAYER_KERNEL") ? atoi(getenv("DEKF_DEBUG_LAYER_KERNEL")) : 0;
-              if (layer > 0) k_layer<<<layer, 64, 0, ss>>>(); }
+              for (int i = 0; i < gap; ++i) k_gap<<<1, 64, 0, ss>>>(); }
 #endif
             if (h->solve_kernel_full && K == h->c.N)
                 h->solve_kernel_full<<<h->solve_grid_full, h->solve_threads_full, h->lds_solve_full, ss>>>(h->c, sp, kstart, K, h->gws_len);

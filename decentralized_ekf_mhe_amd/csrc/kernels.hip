@@ -302,10 +302,6 @@ DEKF_SOLVE_KERNELS_FOOT(9, 4)
 
 #if DEKF_MISC_KERNELS
 __global__ void k_gap() {}
-// A/B experiment (round 6): one wavefront per wave slot of the machine at the register footprint of the solve kernels — does a full,
-// even "layer" of wavefronts in front of the four-per-CU launch leave the CUs in the state from which all 1024 workgroups are placed
-// (as launches behind a 3072-workgroup term construction are)?
-__global__ void __launch_bounds__(64, 3) k_layer() { asm volatile("v_mov_b32 v167, 0" ::: "v167"); }
 __global__ void __launch_bounds__(64) k_kf_initialize(DevCfg c, DevState s) {
     extern __shared__ double lds[];
     kf_initialize(c, s, blockIdx.x, lds);
