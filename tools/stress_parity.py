@@ -164,6 +164,11 @@ def main():
         ok &= case("cassie N=20, 32 x 5000 ticks, tiled x 25 (B = 800)", cassie_params, 32, 5000, th, reps=25)
         ok &= case("go1 N=20 with osqp.polish, 32 x 1500 ticks, tiled x 25 (B = 800)", go1_params, 32, 1500, th, reps=25, polish=1)
         ok &= case("cassie N=20 with osqp.polish, 32 x 1500 ticks, tiled x 25 (B = 800)", cassie_params, 32, 1500, th, reps=25, polish=1)
+        # round 6: the four-per-CU kernel (more instances than its 1024 workgroups: the queue hands out the rest), a fleet that is not in
+        # lock-step (cameras at 5-50 Hz, blind robots: solves of 50 / 75 / 100 iterations within one launch), the three-workgroup kernel at a small batch
+        ok &= case("go1 N=20, four per CU (k_mhe_solve_r4_4_n20), 48 x 3000 ticks, tiled x 22 (B = 1056)", go1_params, 48, 3000, th, reps=22, solve_workgroups_per_cu=4)
+        ok &= case("go1 N=20, mixed fleet (desync = 2), 48 x 3000 ticks, tiled x 17 (B = 816)", go1_params, 48, 3000, th, reps=17, stream_kw=dict(desync=2))
+        ok &= case("go1 N=20, 48 x 2000 ticks, batch 48 (full windows on k_mhe_solve_r3_4_n20 since round 6)", go1_params, 48, 2000, th)
         ok &= case("pogox N=100, 16 x 1500 ticks, tiled x 18 (B = 288: k_mhe_solve_rr_1)", pogox_params, 16, 1500, th, reps=18)
         ok &= case("pogox N=100 with osqp.polish, 16 x 600 ticks, tiled x 18 (B = 288: k_mhe_solve_rr_1_pol)", pogox_params, 16, 600, th, reps=18, polish=1)
         sys.exit(0 if ok else 1)
